@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the session-scan -> per-user feed path on MI355X.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+A step = one scan (one `now`/`cutoff`/discipline-mask query) over the rank's resident session table,
+producing counts/offsets/idx for every user of the shard; for N > 1 followed by the all-gather of per-user
+counts and row lists (RCCL).  Workload at N = 1: BASELINE.json config 3 — 10^8 sessions / 10^5 users /
+32 disciplines, SoA int64 start/end + int32 user/disc, resident in HBM before the timed region.
+Scaling is weak: every rank holds a 10^8-row shard of its own users (user-hash sharded table of N x 10^8).
+
+One JSON line on stdout (rank 0).  Everything else goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+SEED = 0x5EED5EED
+T0_MS = 1700000000000
+DAY = 86400 * 1000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(args, U, D, now, cutoff, mask, flags):
+    """Oracle (CPU port, 1 thread) timed on a bounded sample of the same workload, on this box's host cores."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_py
+    sample = args.cpu_sample_rows
+    s, e, u, d = oracle_py.gen(SEED, args.rows, 0, sample, U, D, flags)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle_py.scan(s, e, u, d, U, now, cutoff, mask)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds or reps >= 50:
+            break
+    rows_per_s = sample * reps / dt
+    out = {
+        "value": rows_per_s * U / args.rows, "unit": "feeds/s", "cores": 1, "kind": "port",
+        "sessions_per_sec": rows_per_s,
+        "sample": "%d reps x first %d rows of the same corpus (U=%d, D=%d), oracle/pie_oracle.c scan, %.1f s; "
+                  "feeds/s scaled by U/N of the full workload; host has %d cores" % (reps, sample, U, D, dt, os.cpu_count()),
+    }
+    # reference-faithful JS (Map of {userId, createdAt, expiresAt} objects, single thread) when node exists
+    try:
+        import shutil
+        import subprocess
+        node = shutil.which("node")
+        js = os.path.join(REPO, "oracle", "ref_faithful.js")
+        if node and os.path.exists(js):
+            res = subprocess.run([node, "--max-old-space-size=8192", js, "--bench", str(args.js_rows), str(max(U // 100, 10)), str(D)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+            if res.returncode == 0:
+                out["js_reference_faithful"] = json.loads(res.stdout.strip().splitlines()[-1])
+    except Exception as ex:  # the JS leg is optional context, never fatal
+        log("js baseline skipped:", ex)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10 ** 8, help="sessions per GPU (weak scaling)")
+    ap.add_argument("--users", type=int, default=10 ** 5, help="users per GPU shard")
+    ap.add_argument("--disc", type=int, default=32)
+    ap.add_argument("--order", choices=["random", "clustered"], default="random")
+    ap.add_argument("--variant", choices=["auth", "interval"], default="auth")
+    ap.add_argument("--query", choices=["spec", "wide"], default="spec",
+                    help="spec: now=T0-6h, cutoff=T0-61d, 16/32 disciplines (SURVEY.md §8d); wide: ~25%% selected")
+    ap.add_argument("--cpu-sample-rows", type=int, default=2 * 10 ** 7)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--js-rows", type=int, default=10 ** 6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    import sph_pie_amd as pie
+    from sph_pie_amd.shard import HipShardBackend, ShardedFeeds
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the scan path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    N, U, D = args.rows, args.users, args.disc
+    flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0)
+    if args.query == "spec":
+        now, cutoff, mask = T0_MS - 6 * 3600 * 1000, T0_MS - 61 * DAY, 0x5555555555555555
+    else:
+        now, cutoff, mask = T0_MS - 100 * DAY, T0_MS - 61 * DAY, 0x5555555555555555
+    mask &= (1 << D) - 1 if D < 64 else 2 ** 64 - 1
+
+    pie.build_hip()
+    ctx = pie.PieScan(local_rank)
+    t_gen = time.perf_counter()
+    # every rank owns the users that hash to it; its shard is rows [rank*N, (rank+1)*N) of the world*N-row corpus
+    ctx.gen_synthetic(SEED, N * world, N * rank, N, U, D, flags)
+    ctx.set_disciplines(mask, D)
+    log("rank %d: generated %d rows in %.2f s" % (rank, N, time.perf_counter() - t_gen))
+
+    backend = HipShardBackend(ctx, dev) if world > 1 else None
+    feeds = ShardedFeeds(backend, rank, world, U) if world > 1 else None
+
+    def step():
+        if world == 1:
+            return ctx.scan_device(now, cutoff)
+        return feeds.scan_and_gather(now, cutoff)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.stats_reset()
+    ctx.set_profiling(True)  # HIP events around the scan kernels, on the stream they are launched on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = ctx.stats()
+    m = last if world == 1 else int(last["lengths"][rank].item())
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        k1_ms = st["k1_ms_sum"] / max(st["n_profiled"], 1)
+        scan_ms = st["scan_ms_sum"] / max(st["n_profiled"], 1)
+        alg = 24.0 * N
+        achieved = alg / (k1_ms * 1e-3) / 1e9
+        line = {
+            "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X",
+            "value": U * world / (ms_per_step * 1e-3), "unit": "feeds/s",
+            "sessions_per_sec": N * world / (ms_per_step * 1e-3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
+                            "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s variant, %s query" % (N, U, D, args.order, args.variant, args.query),
+                "sessions_per_gpu": N, "users_per_gpu": U, "disciplines": D, "selected_rows_rank0": int(m),
+                "parallelism": "user-hash shards x%d, RCCL all-gather of counts + row lists" % world if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_scan_compact", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_launch": alg, "kernel_ms": k1_ms, "scan_ms_first_to_last_kernel": scan_ms,
+                "whole_scan_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": st["n_profiled"],
+                "k1_blocks": st["k1_blocks"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, U, D, now, cutoff, mask, flags)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/*
+ * pie_scan.h — C ABI of the MI355X session-scan -> per-user feed path (libpie_hip.so).
+ *
+ * The reference (sphereisaiahmin-dev/sph-pie) is a pure Node.js app with no FFI seam; the seams this ABI
+ * sits behind are the CommonJS exports of three modules and one HTTP route.  Each entry
+ * point below names the reference interface it replaces (paths relative to /root/reference).  The Node
+ * binding (raw N-API, sph-pie_amd/csrc/pie_napi.c) and the ctypes binding (sph-pie_amd/binding.py) wrap
+ * exactly these symbols; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host buffers, no exceptions across the boundary,
+ * int status return (0 = ok, negative = PIE_E_*), text of the last failure via pie_last_error().
+ * A context is bound to one GPU and is used from one host thread at a time (the reference is a
+ * single-threaded event loop: server/index.js, no worker threads).  There is NO CPU fallback: without a
+ * HIP device pie_ctx_create() fails with PIE_E_NODEVICE.
+ */
+#ifndef PIE_SCAN_H
+#define PIE_SCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIE_ABI_VERSION 1
+
+enum {
+    PIE_OK = 0,
+    PIE_E_INVAL = -1,    /* bad argument (null pointer, negative size, n >= 2^31, user id out of range) */
+    PIE_E_NODEVICE = -2, /* no HIP device / HIP runtime error at init */
+    PIE_E_HIP = -3,      /* HIP runtime error during the call; see pie_last_error() */
+    PIE_E_NOMEM = -4,    /* device or host allocation failed */
+    PIE_E_CAPACITY = -5, /* caller buffer too small (idx_cap < M): *m_out holds the needed size */
+    PIE_E_STATE = -6     /* call out of order (scan before load, fetch before scan, ...) */
+};
+
+/* synthetic-corpus flags; identical meaning in oracle/pie_oracle.h */
+#define PIE_GEN_INTERVAL  1u /* end = start + uniform[15 min, 12 h]; default end = start + SESSION_TTL_MS */
+#define PIE_GEN_CLUSTERED 2u /* rows of one user contiguous; default uniform random users */
+
+/* sentinel for "no end" (calendarFeed.js:74 endTs === null) and for tombstoned rows: never live */
+#define PIE_END_NONE INT64_MIN
+
+typedef struct pie_ctx pie_ctx;
+
+typedef struct pie_stats {
+    uint32_t struct_size;  /* set by caller to sizeof(pie_stats) */
+    uint32_t n_profiled;   /* scans whose events were resolved into the sums below */
+    uint64_t rows;         /* N of the resident table */
+    uint64_t users;        /* U */
+    uint64_t selected;     /* M of the last scan */
+    uint64_t alg_bytes;    /* 24 * N: algorithmic bytes of one scan */
+    double k1_ms_sum;      /* sum of predicate+compaction kernel durations (HIP events, scan stream) */
+    double scan_ms_sum;    /* sum of first-kernel-start -> last-kernel-end durations */
+    uint32_t max_bucket;   /* largest per-user bucket of the last scan */
+    uint32_t n_segments;   /* block-sorted segments of the last scan */
+    uint32_t n_big;        /* buckets that needed the multi-pass merge in the last scan */
+    uint32_t k1_blocks;    /* grid of the scan kernel */
+} pie_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------- */
+int pie_abi_version(void);
+int pie_device_count(void);
+/* One context per GPU, one process per GPU.  device_id is the HIP ordinal. */
+int pie_ctx_create(int device_id, pie_ctx **ctx_out);
+int pie_ctx_destroy(pie_ctx *ctx);
+/* ctx may be NULL: returns the last error of a failed pie_ctx_create on this thread. */
+const char *pie_last_error(const pie_ctx *ctx);
+/* Run every kernel on a caller stream (a hipStream_t, e.g. torch's current stream).  NULL = ctx-owned stream. */
+int pie_ctx_set_stream(pie_ctx *ctx, void *hip_stream);
+
+/* ---- session table: replaces the in-process `sessions` Map (server/sessionStore.js:6,17) -------------
+ * Columns are SoA: start = createdAt, end = expiresAt (int64 ms), user = dense index of the userId string,
+ * disc = index into DISCIPLINES (server/disciplineConfig.js:35).  Host arrays stay caller-owned. */
+int pie_load_columns(pie_ctx *ctx, const int64_t *start, const int64_t *end, const int32_t *user,
+                     const int32_t *disc, size_t n, int32_t n_users);
+/* Fill the table on the device with rows [row0, row0+n) of the deterministic synthetic corpus. */
+int pie_gen_synthetic(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
+                      int32_t n_disc, uint32_t flags);
+/* Copy the resident columns back (any pointer may be NULL). */
+int pie_read_columns(pie_ctx *ctx, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, size_t n);
+/* touchSession (server/sessionStore.js:37-45): end[row] = new_end.  deleteSession (:47-53): new_end = PIE_END_NONE. */
+int pie_set_end(pie_ctx *ctx, const int32_t *rows, const int64_t *new_end, size_t k);
+/* deleteSessionsForUser (server/sessionStore.js:55-64): tombstone every row with user == u; *n_deleted out. */
+int pie_delete_user(pie_ctx *ctx, int32_t user, size_t *n_deleted);
+
+/* ---- discipline predicate table: replaces findDiscipline() lookups (server/disciplineConfig.js:88-97) -
+ * bit d of mask = rows of discipline d are wanted; bits >= n_disc are ignored. n_disc <= 64. */
+int pie_set_disciplines(pie_ctx *ctx, uint64_t mask, int32_t n_disc);
+
+/* ---- the scan: replaces the per-request loops (server/sessionStore.js:59-63,68-72;
+ * server/storage/sqlProvider.js:284 window filter, :276 ORDER BY start_ts ASC) -------------------------
+ * Row i is selected iff end[i] > now && start[i] >= cutoff && bit(mask, disc[i]).  Feed(u) = selected rows
+ * of user u ordered by (start asc, row index asc).  Outputs: counts[U], offsets[U+1], idx[M]. */
+int pie_scan(pie_ctx *ctx, int64_t now, int64_t cutoff, int32_t *counts_out, int64_t *offsets_out,
+             int32_t *idx_out, size_t idx_cap, size_t *m_out);
+/* Same scan, results left in device memory (for the multi-GPU gather and for benchmarking). */
+int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
+/* Device pointers of the last scan's results (valid until the next load/scan on this ctx). */
+int pie_result_device_ptrs(pie_ctx *ctx, void **counts_dev, void **offsets_dev, void **idx_dev);
+/* Copy the last scan's results into caller-owned DEVICE buffers (e.g. torch tensors that feed an RCCL
+ * all-gather), asynchronously on the context's stream.  Any pointer may be NULL; idx copies min(M, idx_cap). */
+int pie_copy_results_device(pie_ctx *ctx, void *counts_dst, void *offsets_dst, void *idx_dst, size_t idx_cap);
+/* Gather the rows named by idx (host array of m row indices) for host-side serialisation
+ * (the event object of server/calendarFeed.js:66-79).  Output pointers may be NULL. */
+int pie_fetch_rows(pie_ctx *ctx, const int32_t *idx, size_t m, int64_t *start, int64_t *end, int32_t *user,
+                   int32_t *disc);
+
+/* ---- "next" row: newly-expired change predicate -> ordered dispatch queue -----------
+ * queue = ascending row indices with prev_now < end <= now  (dead per server/sessionStore.js:69 at `now`,
+ * not yet dead at `prev_now`); order = the sequential-await order of server/storage/sqlProvider.js:834-861. */
+int pie_expired_queue(pie_ctx *ctx, int64_t prev_now, int64_t now, int32_t *queue_out, size_t cap, size_t *q_out);
+
+/* ---- measurement ------------------------------------------------------------------------------------- */
+int pie_set_profiling(pie_ctx *ctx, int enabled); /* record HIP events around the scan kernels */
+int pie_stats_get(pie_ctx *ctx, pie_stats *out);  /* resolves pending events (synchronises the stream) */
+int pie_stats_reset(pie_ctx *ctx);
+int pie_synchronize(pie_ctx *ctx);
+/* user-hash sharding rule: shard = splitmix64(user) mod n_shards.  Pure host function. */
+int32_t pie_shard_of(int32_t user, int32_t n_shards);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIE_SCAN_H */

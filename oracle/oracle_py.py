@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE — ctypes wrapper of oracle/libpie_oracle.so (the CPU restatement, oracle/pie_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product package
+(sph-pie_amd/) never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libpie_oracle.so")
+
+T0_MS = 1700000000000
+SPAN_MS = 10368000000
+TTL_MS = 43200000
+GEN_INTERVAL = 1
+GEN_CLUSTERED = 2
+INT64_MIN = -(2 ** 63)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "pie_oracle.c")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", HERE, "-B", "libpie_oracle.so"], stdout=subprocess.DEVNULL)
+        l = C.CDLL(LIB)
+        P = C.c_void_p
+        l.pie_oracle_gen.restype = None
+        l.pie_oracle_gen.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, P, P, P, P]
+        l.pie_oracle_selected.restype = C.c_int
+        l.pie_oracle_selected.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_uint64]
+        l.pie_oracle_scan.restype = C.c_int
+        l.pie_oracle_scan.argtypes = [P, P, P, P, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, P, P, P,
+                                      C.c_size_t, C.POINTER(C.c_size_t)]
+        l.pie_oracle_expired_queue.restype = C.c_int
+        l.pie_oracle_expired_queue.argtypes = [P, C.c_size_t, C.c_int64, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.pie_oracle_splitmix64.restype = C.c_uint64
+        l.pie_oracle_splitmix64.argtypes = [C.c_uint64]
+        l.pie_oracle_shard_of.restype = C.c_int32
+        l.pie_oracle_shard_of.argtypes = [C.c_int32, C.c_int32]
+        _lib = l
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gen(seed, n_total, row0, n, n_users, n_disc, flags=0):
+    s, e = np.empty(n, np.int64), np.empty(n, np.int64)
+    u, d = np.empty(n, np.int32), np.empty(n, np.int32)
+    lib().pie_oracle_gen(seed, n_total, row0, n, n_users, n_disc, flags, _p(s), _p(e), _p(u), _p(d))
+    return s, e, u, d
+
+
+def scan(start, end, user, disc, n_users, now, cutoff, mask):
+    start, end = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(end, np.int64)
+    user, disc = np.ascontiguousarray(user, np.int32), np.ascontiguousarray(disc, np.int32)
+    n = start.shape[0]
+    counts, offsets = np.empty(n_users, np.int32), np.empty(n_users + 1, np.int64)
+    idx = np.empty(max(n, 1), np.int32)
+    m = C.c_size_t(0)
+    rc = lib().pie_oracle_scan(_p(start), _p(end), _p(user), _p(disc), n, n_users, int(now), int(cutoff),
+                               int(mask) & (2 ** 64 - 1), _p(counts), _p(offsets), _p(idx), n, C.byref(m))
+    if rc != 0:
+        raise RuntimeError("pie_oracle_scan rc=%d" % rc)
+    return counts, offsets, idx[: m.value].copy()
+
+
+def expired_queue(end, prev_now, now):
+    end = np.ascontiguousarray(end, np.int64)
+    n = end.shape[0]
+    q = np.empty(max(n, 1), np.int32)
+    k = C.c_size_t(0)
+    rc = lib().pie_oracle_expired_queue(_p(end), n, int(prev_now), int(now), _p(q), n, C.byref(k))
+    if rc != 0:
+        raise RuntimeError("pie_oracle_expired_queue rc=%d" % rc)
+    return q[: k.value].copy()
+
+
+def selected(start, end, disc, now, cutoff, mask):
+    return bool(lib().pie_oracle_selected(int(start), int(end), int(disc), int(now), int(cutoff), int(mask) & (2 ** 64 - 1)))
+
+
+def shard_of(user, n_shards):
+    return lib().pie_oracle_shard_of(int(user), int(n_shards))
+
+
+def scan_numpy(start, end, user, disc, n_users, now, cutoff, mask):
+    """Independent second restatement in numpy (lexsort), used to cross-check the C oracle itself."""
+    start, end = np.asarray(start, np.int64), np.asarray(end, np.int64)
+    user, disc = np.asarray(user, np.int32), np.asarray(disc, np.int32)
+    d_ok = (disc >= 0) & (disc < 64)
+    bit = np.zeros(disc.shape, bool)
+    dd = np.where(d_ok, disc, 0).astype(np.uint64)
+    bit[d_ok] = ((np.uint64(int(mask) & (2 ** 64 - 1)) >> dd[d_ok]) & np.uint64(1)).astype(bool)
+    sel = (end > now) & (start >= cutoff) & bit
+    rows = np.nonzero(sel)[0].astype(np.int64)
+    order = np.lexsort((rows, start[rows], user[rows]))  # last key is primary
+    idx = rows[order].astype(np.int32)
+    counts = np.bincount(user[rows], minlength=n_users).astype(np.int32)
+    offsets = np.zeros(n_users + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    return counts, offsets, idx

@@ -1,0 +1,60 @@
+/*
+ * TEST INFRASTRUCTURE — CPU oracle for the session-scan -> per-user feed path.
+ *
+ * This is a plain-C restatement of the predicates, ordering rule and bucket rule that the reference
+ * (sphereisaiahmin-dev/sph-pie, mounted read-only at /root/reference) scatters over three files.  The
+ * reference has NO aggregated scan function: the composition below is the [DERIVED]
+ * contract of SURVEY.md §8(a-D).  Every predicate cites the reference line it restates.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The product
+ * path (libpie_hip.so) never links, loads or falls back to it.
+ *
+ * Parity pin: the liveness / purge / user-match predicates are pinned by tests/golden/sessionstore_g1_g4.json,
+ * which holds outputs of the real server/sessionStore.js (see oracle/gen_golden.js).  The window, de-dup and
+ * ordering rules have no executable reference here (calendarFeed.js / sqlProvider.js do not load on Node 12
+ * and need absent packages): they are pinned by hand-derived vectors only — "parity unpinned" for those rows.
+ */
+#ifndef PIE_ORACLE_H
+#define PIE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Synthetic corpus.  Row i consumes outputs 4i..4i+3 of the sequential splitmix64 stream
+ * started at `seed`; rows [row0, row0+n) are written, so a table can be produced in slices. */
+#define PIE_ORACLE_T0_MS        1700000000000LL
+#define PIE_ORACLE_SPAN_MS      10368000000LL   /* 120 d */
+#define PIE_ORACLE_TTL_MS       43200000LL      /* server/sessionStore.js:3 */
+#define PIE_ORACLE_MIN_DUR_MS   900000LL        /* 15 min, "interval" variant */
+
+#define PIE_GEN_INTERVAL   1u   /* end = start + uniform[15 min, 12 h] instead of start + TTL */
+#define PIE_GEN_CLUSTERED  2u   /* user = floor(i*U/n_total): rows of one user are contiguous */
+
+void pie_oracle_gen(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
+                    uint32_t flags, int64_t *start, int64_t *end, int32_t *user, int32_t *disc);
+
+/* Row-level predicate of the [DERIVED] contract. */
+int pie_oracle_selected(int64_t start, int64_t end, int32_t disc, int64_t now, int64_t cutoff, uint64_t disc_mask);
+
+/* Full scan: counts[U], offsets[U+1], idx[M].  Returns 0, or -1 if idx_cap < M (m_out still set), or -2 on a
+ * user id outside [0, n_users). */
+int pie_oracle_scan(const int64_t *start, const int64_t *end, const int32_t *user, const int32_t *disc, size_t n,
+                    int32_t n_users, int64_t now, int64_t cutoff, uint64_t disc_mask, int32_t *counts,
+                    int64_t *offsets, int32_t *idx, size_t idx_cap, size_t *m_out);
+
+/* "next" row: newly-expired change predicate  prev_now < end <= now  -> ordered queue. */
+int pie_oracle_expired_queue(const int64_t *end, size_t n, int64_t prev_now, int64_t now, int32_t *queue,
+                             size_t cap, size_t *q_out);
+
+/* user-hash sharding rule shared with the product: rank = splitmix64(user) mod G. */
+uint64_t pie_oracle_splitmix64(uint64_t x);
+int32_t pie_oracle_shard_of(int32_t user, int32_t n_shards);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,221 @@
+"""ctypes binding of include/pie_scan.h (libpie_hip.so).  Thin: every method is one C-ABI call.
+
+There is no CPU fallback here: if the HIP library is missing this raises, and if no GPU is present
+`PieScan()` raises with the library's own error text."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import HIP_LIB
+
+PIE_GEN_INTERVAL = 1
+PIE_GEN_CLUSTERED = 2
+PIE_END_NONE = -(2 ** 63)
+INT64_MIN = -(2 ** 63)
+
+PIE_E_CAPACITY = -5
+
+
+class PieError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("pie_scan error %d: %s" % (code, text))
+        self.code = code
+
+
+class PieStats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_profiled", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
+        ("selected", C.c_uint64), ("alg_bytes", C.c_uint64), ("k1_ms_sum", C.c_double), ("scan_ms_sum", C.c_double),
+        ("max_bucket", C.c_uint32), ("n_segments", C.c_uint32), ("n_big", C.c_uint32), ("k1_blocks", C.c_uint32),
+    ]
+
+
+# every symbol include/pie_scan.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGS = [
+    ("pie_abi_version", C.c_int, []),
+    ("pie_device_count", C.c_int, []),
+    ("pie_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("pie_ctx_destroy", C.c_int, [_P]),
+    ("pie_last_error", C.c_char_p, [_P]),
+    ("pie_ctx_set_stream", C.c_int, [_P, _P]),
+    ("pie_load_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
+    ("pie_gen_synthetic", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
+    ("pie_read_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
+    ("pie_set_end", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("pie_delete_user", C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("pie_set_disciplines", C.c_int, [_P, C.c_uint64, C.c_int32]),
+    ("pie_scan", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_scan_device", C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("pie_copy_results_device", C.c_int, [_P, _P, _P, _P, C.c_size_t]),
+    ("pie_fetch_rows", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P, _P]),
+    ("pie_expired_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_set_profiling", C.c_int, [_P, C.c_int]),
+    ("pie_stats_get", C.c_int, [_P, C.POINTER(PieStats)]),
+    ("pie_stats_reset", C.c_int, [_P]),
+    ("pie_synchronize", C.c_int, [_P]),
+    ("pie_shard_of", C.c_int32, [C.c_int32, C.c_int32]),
+]
+ABI_SYMBOLS = [s[0] for s in _SIGS]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libpie_hip.so and type its symbols.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or HIP_LIB
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing — build it first: python -c 'import __graft_entry__ as g; g.build()' "
+                           "(there is no CPU fallback for the scan path)" % path)
+    lib = C.CDLL(path)
+    for name, res, args in _SIGS:
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _col(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class PieScan:
+    """One context = one GPU = one process."""
+
+    def __init__(self, device=0, lib_path=None):
+        self._lib = load_library(lib_path)
+        self._ctx = _P()
+        rc = self._lib.pie_ctx_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            text = self._lib.pie_last_error(None).decode()
+            self._ctx = None
+            raise PieError(rc, text)
+        self.n = 0
+        self.n_users = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pie_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PieError(rc, self._lib.pie_last_error(self._ctx).decode())
+
+    # ---- table
+    def load_columns(self, start, end, user, disc, n_users):
+        start, end = _col(start, np.int64), _col(end, np.int64)
+        user, disc = _col(user, np.int32), _col(disc, np.int32)
+        n = start.shape[0]
+        if not (end.shape[0] == user.shape[0] == disc.shape[0] == n):
+            raise ValueError("column lengths differ")
+        self._check(self._lib.pie_load_columns(self._ctx, _ptr(start), _ptr(end), _ptr(user), _ptr(disc), n, int(n_users)))
+        self.n, self.n_users = n, int(n_users)
+
+    def gen_synthetic(self, seed, n_total, row0, n, n_users, n_disc, flags=0):
+        self._check(self._lib.pie_gen_synthetic(self._ctx, seed, n_total, row0, n, n_users, n_disc, flags))
+        self.n, self.n_users = int(n), int(n_users)
+
+    def read_columns(self):
+        n = self.n
+        s, e = np.empty(n, np.int64), np.empty(n, np.int64)
+        u, d = np.empty(n, np.int32), np.empty(n, np.int32)
+        self._check(self._lib.pie_read_columns(self._ctx, _ptr(s), _ptr(e), _ptr(u), _ptr(d), n))
+        return s, e, u, d
+
+    def set_end(self, rows, new_end):
+        rows, new_end = _col(rows, np.int32), _col(new_end, np.int64)
+        self._check(self._lib.pie_set_end(self._ctx, _ptr(rows), _ptr(new_end), rows.shape[0]))
+
+    def delete_user(self, user):
+        k = C.c_size_t(0)
+        self._check(self._lib.pie_delete_user(self._ctx, int(user), C.byref(k)))
+        return k.value
+
+    def set_disciplines(self, mask, n_disc):
+        self._check(self._lib.pie_set_disciplines(self._ctx, mask & (2 ** 64 - 1), int(n_disc)))
+
+    # ---- scan
+    def scan(self, now, cutoff, idx_cap=None):
+        """-> (counts[U] int32, offsets[U+1] int64, idx[M] int32), host arrays."""
+        U = self.n_users
+        counts, offsets = np.empty(U, np.int32), np.empty(U + 1, np.int64)
+        cap = self.n if idx_cap is None else int(idx_cap)
+        idx = np.empty(max(cap, 1), np.int32)
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_scan(self._ctx, int(now), int(cutoff), _ptr(counts), _ptr(offsets), _ptr(idx), cap, C.byref(m)))
+        return counts, offsets, idx[: m.value].copy() if cap > 4 * max(m.value, 1) else idx[: m.value]
+
+    def scan_device(self, now, cutoff):
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_scan_device(self._ctx, int(now), int(cutoff), C.byref(m)))
+        return m.value
+
+    def result_device_ptrs(self):
+        a, b, c = _P(), _P(), _P()
+        self._check(self._lib.pie_result_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def copy_results_device(self, counts_ptr=None, offsets_ptr=None, idx_ptr=None, idx_cap=0):
+        """D2D copy into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr()), on the ctx stream."""
+        self._check(self._lib.pie_copy_results_device(self._ctx, counts_ptr, offsets_ptr, idx_ptr, int(idx_cap)))
+
+    def fetch_rows(self, idx):
+        idx = _col(idx, np.int32)
+        m = idx.shape[0]
+        s, e = np.empty(m, np.int64), np.empty(m, np.int64)
+        u, d = np.empty(m, np.int32), np.empty(m, np.int32)
+        self._check(self._lib.pie_fetch_rows(self._ctx, _ptr(idx), m, _ptr(s), _ptr(e), _ptr(u), _ptr(d)))
+        return s, e, u, d
+
+    def expired_queue(self, prev_now, now):
+        q = C.c_size_t(0)
+        out = np.empty(max(self.n, 1), np.int32)
+        self._check(self._lib.pie_expired_queue(self._ctx, int(prev_now), int(now), _ptr(out), self.n, C.byref(q)))
+        return out[: q.value].copy()
+
+    # ---- measurement / plumbing
+    def set_stream(self, hip_stream):
+        self._check(self._lib.pie_ctx_set_stream(self._ctx, hip_stream))
+
+    def set_profiling(self, on=True):
+        self._check(self._lib.pie_set_profiling(self._ctx, 1 if on else 0))
+
+    def stats(self):
+        st = PieStats()
+        st.struct_size = C.sizeof(PieStats)
+        self._check(self._lib.pie_stats_get(self._ctx, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in PieStats._fields_}
+
+    def stats_reset(self):
+        self._check(self._lib.pie_stats_reset(self._ctx))
+
+    def synchronize(self):
+        self._check(self._lib.pie_synchronize(self._ctx))
+
+
+def shard_of(user, n_shards):
+    return load_library().pie_shard_of(int(user), int(n_shards))

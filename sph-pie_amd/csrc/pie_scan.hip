@@ -1,0 +1,628 @@
+// pie_scan.hip — C ABI (include/pie_scan.h) over the HIP kernels of pie_kernels.h.  gfx950 only.
+// There is no CPU path in this library: every entry point either runs on the GPU or returns an error.
+#include "../../include/pie_scan.h"
+#include "pie_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace pie;
+
+namespace {
+
+thread_local char g_create_error[256] = "";
+
+struct ScanEvents {
+    hipEvent_t e0, e1, e2; // before first kernel, after K1, after last kernel
+};
+
+constexpr int kEventRing = 2048;
+
+} // namespace
+
+struct pie_ctx {
+    int device = -1;
+    int n_cus = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = "";
+
+    // resident table
+    long long n = 0;
+    int n_users = 0;
+    long long cap_rows = 0;
+    int cap_users = 0;
+    long long *d_start = nullptr, *d_end = nullptr;
+    int *d_user = nullptr, *d_disc = nullptr;
+
+    // predicate table
+    unsigned long long disc_mask = ~0ull;
+    int n_disc = 64;
+
+    // scan workspace
+    int k1_blocks = 0;
+    long long rows_per_block = 0;
+    int n_tiles = 0;
+    int *d_counts = nullptr, *d_cursor = nullptr;
+    long long* d_offsets = nullptr;
+    long long* d_tile_sum = nullptr;
+    SelRec* d_sel = nullptr;
+    int* d_blk_count = nullptr;
+    long long* d_blk_off = nullptr;
+    long long* d_bkt_start = nullptr;
+    int* d_bkt_idx = nullptr;
+    int* d_out_idx = nullptr;
+    Segment* d_seg_list = nullptr;
+    int* d_big_list = nullptr;
+    Summary* d_summary = nullptr;
+    Summary* h_summary = nullptr; // pinned
+    hipEvent_t ev_summary = nullptr;
+    bool have_scan = false;
+    Summary last{};
+
+    // profiling
+    bool profiling = false;
+    std::vector<ScanEvents> ring;
+    int ring_used = 0;
+    double k1_ms_sum = 0, scan_ms_sum = 0;
+    unsigned n_profiled = 0;
+};
+
+namespace {
+
+int fail(pie_ctx* c, int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    if (c) vsnprintf(c->err, sizeof c->err, fmt, ap);
+    else vsnprintf(g_create_error, sizeof g_create_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PIE_HIP(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail((c), e_ == hipErrorOutOfMemory ? PIE_E_NOMEM : PIE_E_HIP, "%s: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                   \
+    } while (0)
+
+template <class T>
+void dfree(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_table(pie_ctx* c)
+{
+    dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc);
+    dfree(c->d_counts); dfree(c->d_cursor); dfree(c->d_offsets); dfree(c->d_tile_sum);
+    dfree(c->d_sel); dfree(c->d_blk_count); dfree(c->d_blk_off);
+    dfree(c->d_bkt_start); dfree(c->d_bkt_idx); dfree(c->d_out_idx);
+    dfree(c->d_seg_list); dfree(c->d_big_list);
+    c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0; c->have_scan = false;
+}
+
+// Grid of the scan kernel: every block owns a contiguous, kBlockTileRows-aligned row range.  Default is a
+// few blocks per CU slot so the tail of the launch is short; PIE_K1_BLOCKS overrides for tuning.
+void plan_k1(pie_ctx* c)
+{
+    long long want = (long long)c->n_cus * 16;
+    if (const char* e = getenv("PIE_K1_BLOCKS")) {
+        long long v = atoll(e);
+        if (v > 0) want = v;
+    }
+    long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
+    if (tiles < 1) tiles = 1;
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const long long tiles_per_block = (tiles + want - 1) / want;
+    c->rows_per_block = tiles_per_block * kBlockTileRows;
+    c->k1_blocks = (int)((c->n + c->rows_per_block - 1) / c->rows_per_block);
+    if (c->k1_blocks < 1) c->k1_blocks = 1;
+}
+
+int ensure_capacity(pie_ctx* c, long long n, int n_users)
+{
+    if (n < 0 || n >= (1LL << 31)) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31)", n);
+    if (n_users < 1) return fail(c, PIE_E_INVAL, "n_users must be >= 1 (got %d)", n_users);
+    const long long rows = n > 0 ? n : 1;
+    if (rows > c->cap_rows || n_users > c->cap_users) {
+        free_table(c);
+        PIE_HIP(c, hipMalloc(&c->d_start, rows * 8));
+        PIE_HIP(c, hipMalloc(&c->d_end, rows * 8));
+        PIE_HIP(c, hipMalloc(&c->d_user, rows * 4));
+        PIE_HIP(c, hipMalloc(&c->d_disc, rows * 4));
+        PIE_HIP(c, hipMalloc(&c->d_sel, rows * sizeof(SelRec)));
+        PIE_HIP(c, hipMalloc(&c->d_bkt_start, rows * 8));
+        PIE_HIP(c, hipMalloc(&c->d_bkt_idx, rows * 4));
+        PIE_HIP(c, hipMalloc(&c->d_out_idx, rows * 4));
+        const long long max_blocks = rows / kBlockTileRows + 2;
+        PIE_HIP(c, hipMalloc(&c->d_blk_count, max_blocks * 4));
+        PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks + 1) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_counts, (size_t)n_users * 4));
+        PIE_HIP(c, hipMalloc(&c->d_cursor, (size_t)n_users * 4));
+        PIE_HIP(c, hipMalloc(&c->d_offsets, ((size_t)n_users + 1) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_tile_sum, ((size_t)n_users / kScanTile + 2) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_seg_list, ((size_t)n_users + rows / kSegMax + 16) * sizeof(Segment)));
+        PIE_HIP(c, hipMalloc(&c->d_big_list, ((size_t)n_users + 16) * 4));
+        c->cap_rows = rows;
+        c->cap_users = n_users;
+    }
+    c->n = n;
+    c->n_users = n_users;
+    c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
+    c->have_scan = false;
+    plan_k1(c);
+    return PIE_OK;
+}
+
+int validate_users(pie_ctx* c)
+{
+    if (c->n == 0) return PIE_OK;
+    PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), c->stream));
+    const int grid = c->n_cus * 8;
+    hipLaunchKernelGGL(k_validate_users, dim3(grid), dim3(256), 0, c->stream, c->d_user, c->n, c->n_users,
+                       &c->d_summary->bad_rows);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_summary->bad_rows)
+        return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", c->h_summary->bad_rows, c->n_users);
+    return PIE_OK;
+}
+
+int resolve_events(pie_ctx* c)
+{
+    if (c->ring_used == 0) return PIE_OK;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->ring_used; ++i) {
+        float k1 = 0, all = 0;
+        PIE_HIP(c, hipEventElapsedTime(&k1, c->ring[i].e0, c->ring[i].e1));
+        PIE_HIP(c, hipEventElapsedTime(&all, c->ring[i].e0, c->ring[i].e2));
+        c->k1_ms_sum += k1;
+        c->scan_ms_sum += all;
+        c->n_profiled++;
+    }
+    c->ring_used = 0;
+    return PIE_OK;
+}
+
+// The whole scan, results left on the device.  One host wait in the middle of the queue (for the 32-byte
+// summary) overlaps with K3/K4a/K4b, which are already enqueued behind it.
+int run_scan(pie_ctx* c, long long now, long long cutoff)
+{
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    hipStream_t s = c->stream;
+    ScanEvents* ev = nullptr;
+    if (c->profiling) {
+        if (c->ring_used == kEventRing) {
+            int rc = resolve_events(c);
+            if (rc) return rc;
+        }
+        if ((int)c->ring.size() <= c->ring_used) {
+            ScanEvents e{};
+            PIE_HIP(c, hipEventCreate(&e.e0));
+            PIE_HIP(c, hipEventCreate(&e.e1));
+            PIE_HIP(c, hipEventCreate(&e.e2));
+            c->ring.push_back(e);
+        }
+        ev = &c->ring[c->ring_used];
+    }
+    const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
+
+    PIE_HIP(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->n_users * 4, s));
+    PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), s));
+    if (ev) PIE_HIP(c, hipEventRecord(ev->e0, s));
+    hipLaunchKernelGGL(k_scan_compact, dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, c->d_user,
+                       c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, c->d_counts, c->d_sel,
+                       c->d_blk_count, &c->d_summary->bad_rows);
+    if (ev) PIE_HIP(c, hipEventRecord(ev->e1, s));
+    hipLaunchKernelGGL(k_tile_sums, dim3(c->n_tiles + 1), dim3(256), 0, s, c->d_counts, c->n_users, c->d_tile_sum,
+                       c->n_tiles, c->d_blk_count, c->k1_blocks, c->d_blk_off, c->d_summary);
+    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, c->d_counts, c->n_users, c->d_tile_sum,
+                       c->d_offsets, c->d_cursor, c->d_seg_list, c->d_big_list, c->d_summary);
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    if (!c->ev_summary) PIE_HIP(c, hipEventCreateWithFlags(&c->ev_summary, hipEventDisableTiming));
+    hipEvent_t summary_ready = c->ev_summary;
+    PIE_HIP(c, hipEventRecord(summary_ready, s));
+
+    const int aux_grid = c->n_cus * 8;
+    hipLaunchKernelGGL(k_scatter, dim3(aux_grid), dim3(256), 0, s, c->d_sel, c->d_blk_off, c->k1_blocks,
+                       c->rows_per_block, c->d_offsets, c->d_cursor, c->d_bkt_start, c->d_bkt_idx);
+    hipLaunchKernelGGL(k_sort_tiny, dim3((c->n_users + 255) / 256), dim3(256), 0, s, c->d_counts, c->d_offsets,
+                       c->n_users, c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
+    hipLaunchKernelGGL(k_sort_segments, dim3(c->n_cus * 3), dim3(256), 0, s, c->d_seg_list, c->d_summary,
+                       c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
+    PIE_HIP(c, hipGetLastError());
+
+    PIE_HIP(c, hipEventSynchronize(summary_ready));
+    c->last = *c->h_summary;
+    if (c->last.n_big > 0) {
+        // big buckets: tiles of kSegMax are sorted in place by K4b; merge passes ping-pong between the bucket
+        // arrays and scratch carved out of the (now consumed) record staging; the last pass lands in out_idx.
+        long long* tmp_s = reinterpret_cast<long long*>(c->d_sel);
+        int* tmp_i = reinterpret_cast<int*>(tmp_s + c->cap_rows);
+        int passes = 0;
+        for (long long w = kSegMax; w < (long long)c->last.max_count; w <<= 1) ++passes;
+        bool in_bkt = true; // which buffer pair holds the current runs
+        long long w = kSegMax;
+        for (int p = 0; p < passes; ++p, w <<= 1) {
+            const long long* src_s = in_bkt ? c->d_bkt_start : tmp_s;
+            const int* src_i = in_bkt ? c->d_bkt_idx : tmp_i;
+            long long* dst_s = in_bkt ? tmp_s : c->d_bkt_start;
+            int* dst_i = (p == passes - 1) ? c->d_out_idx : (in_bkt ? tmp_i : c->d_bkt_idx);
+            const unsigned gx = (unsigned)((c->last.max_count + 255u) / 256u);
+            const unsigned gy = c->last.n_big < 65535u ? c->last.n_big : 65535u;
+            hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, s, c->d_big_list,
+                               (int)c->last.n_big, c->d_counts, c->d_offsets, w, src_s, src_i, dst_s, dst_i);
+            in_bkt = !in_bkt;
+        }
+        PIE_HIP(c, hipGetLastError());
+    }
+    if (ev) {
+        PIE_HIP(c, hipEventRecord(ev->e2, s));
+        c->ring_used++;
+    }
+    c->have_scan = true;
+    if (c->last.bad_rows)
+        return fail(c, PIE_E_INVAL, "%u selected rows carry a user id outside [0, %d)", c->last.bad_rows, c->n_users);
+    return PIE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pie_abi_version(void) { return PIE_ABI_VERSION; }
+
+int pie_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pie_last_error(const pie_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
+
+int pie_ctx_create(int device_id, pie_ctx** ctx_out)
+{
+    if (!ctx_out) return fail(nullptr, PIE_E_INVAL, "ctx_out is NULL");
+    *ctx_out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, PIE_E_NODEVICE, "no HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, PIE_E_INVAL, "device %d outside [0, %d)", device_id, n);
+    if ((e = hipSetDevice(device_id)) != hipSuccess)
+        return fail(nullptr, PIE_E_NODEVICE, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    pie_ctx* c = new (std::nothrow) pie_ctx();
+    if (!c) return fail(nullptr, PIE_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, PIE_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->d_summary, sizeof(Summary))) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) != hipSuccess) {
+        fail(nullptr, PIE_E_NODEVICE, "context setup: %s", hipGetErrorString(e));
+        delete c;
+        return PIE_E_NODEVICE;
+    }
+    c->stream = c->own_stream;
+    *ctx_out = c;
+    return PIE_OK;
+}
+
+int pie_ctx_destroy(pie_ctx* c)
+{
+    if (!c) return PIE_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_table(c);
+    for (auto& e : c->ring) {
+        (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2);
+    }
+    if (c->ev_summary) (void)hipEventDestroy(c->ev_summary);
+    if (c->d_summary) (void)hipFree(c->d_summary);
+    if (c->h_summary) (void)hipHostFree(c->h_summary);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PIE_OK;
+}
+
+int pie_ctx_set_stream(pie_ctx* c, void* hip_stream)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PIE_OK;
+}
+
+int pie_load_columns(pie_ctx* c, const int64_t* start, const int64_t* end, const int32_t* user, const int32_t* disc,
+                     size_t n, int32_t n_users)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n > 0 && (!start || !end || !user || !disc)) return fail(c, PIE_E_INVAL, "NULL column pointer");
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_capacity(c, (long long)n, n_users);
+    if (rc) return rc;
+    if (n > 0) {
+        PIE_HIP(c, hipMemcpyAsync(c->d_start, start, n * 8, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_end, end, n * 8, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_user, user, n * 4, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_disc, disc, n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = validate_users(c);
+    if (rc) { c->n = 0; return rc; }
+    return PIE_OK;
+}
+
+int pie_gen_synthetic(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
+                      int32_t n_disc, uint32_t flags)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n < 0 || row0 < 0 || n_total < row0 + n || n_disc < 1 || n_disc > 64)
+        return fail(c, PIE_E_INVAL, "bad synthetic-corpus shape");
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n, n_users);
+    if (rc) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_gen, dim3(c->n_cus * 8), dim3(256), 0, c->stream, seed, (long long)n_total, (long long)row0,
+                           (long long)n, n_users, n_disc, flags, c->d_start, c->d_end, c->d_user, c->d_disc);
+        PIE_HIP(c, hipGetLastError());
+    }
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
+int pie_read_columns(pie_ctx* c, int64_t* start, int64_t* end, int32_t* user, int32_t* disc, size_t n)
+{
+    if (!c) return PIE_E_INVAL;
+    if ((long long)n > c->n) return fail(c, PIE_E_INVAL, "asked for %zu rows, table has %lld", n, c->n);
+    PIE_HIP(c, hipSetDevice(c->device));
+    if (n) {
+        if (start) PIE_HIP(c, hipMemcpyAsync(start, c->d_start, n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (end) PIE_HIP(c, hipMemcpyAsync(end, c->d_end, n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (user) PIE_HIP(c, hipMemcpyAsync(user, c->d_user, n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (disc) PIE_HIP(c, hipMemcpyAsync(disc, c->d_disc, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
+int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t k)
+{
+    if (!c) return PIE_E_INVAL;
+    if (k == 0) return PIE_OK;
+    if (!rows || !new_end) return fail(c, PIE_E_INVAL, "NULL pointer");
+    for (size_t i = 0; i < k; ++i)
+        if (rows[i] < 0 || rows[i] >= c->n) return fail(c, PIE_E_INVAL, "row %d outside the table", rows[i]);
+    PIE_HIP(c, hipSetDevice(c->device));
+    int* d_rows = nullptr;
+    long long* d_new = nullptr;
+    PIE_HIP(c, hipMalloc(&d_rows, k * 4));
+    hipError_t e = hipMalloc(&d_new, k * 8);
+    if (e != hipSuccess) { (void)hipFree(d_rows); return fail(c, PIE_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    (void)hipMemcpyAsync(d_rows, rows, k * 4, hipMemcpyHostToDevice, c->stream);
+    (void)hipMemcpyAsync(d_new, new_end, k * 8, hipMemcpyHostToDevice, c->stream);
+    hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end, d_rows, d_new,
+                       (long long)k, c->n);
+    e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rows);
+    (void)hipFree(d_new);
+    if (e != hipSuccess) return fail(c, PIE_E_HIP, "pie_set_end: %s", hipGetErrorString(e));
+    c->have_scan = false;
+    return PIE_OK;
+}
+
+int pie_delete_user(pie_ctx* c, int32_t user, size_t* n_deleted)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_deleted) *n_deleted = 0;
+    if (c->n == 0 || user < 0 || user >= c->n_users) return PIE_OK; // unknown / falsy id: no-op (sessionStore.js:56-58)
+    PIE_HIP(c, hipSetDevice(c->device));
+    PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), c->stream));
+    hipLaunchKernelGGL(k_delete_user, dim3(c->n_cus * 8), dim3(256), 0, c->stream, c->d_user, c->d_end, c->n, user,
+                       &c->d_summary->q);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_deleted) *n_deleted = (size_t)c->h_summary->q;
+    c->have_scan = false;
+    return PIE_OK;
+}
+
+int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_disc < 0 || n_disc > 64) return fail(c, PIE_E_INVAL, "n_disc %d outside [0, 64]", n_disc);
+    c->disc_mask = mask;
+    c->n_disc = n_disc;
+    return PIE_OK;
+}
+
+int pie_scan_device(pie_ctx* c, int64_t now, int64_t cutoff, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = run_scan(c, now, cutoff);
+    if (m_out) *m_out = (size_t)c->last.m;
+    return rc;
+}
+
+int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out,
+             size_t idx_cap, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = run_scan(c, now, cutoff);
+    const size_t m = (size_t)c->last.m;
+    if (m_out) *m_out = m;
+    if (rc) return rc;
+    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, c->d_counts, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, c->stream));
+    if (offsets_out)
+        PIE_HIP(c, hipMemcpyAsync(offsets_out, c->d_offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (idx_out && m > idx_cap) {
+        PIE_HIP(c, hipStreamSynchronize(c->stream));
+        return fail(c, PIE_E_CAPACITY, "idx_cap %zu < selected rows %zu", idx_cap, m);
+    }
+    if (idx_out && m) PIE_HIP(c, hipMemcpyAsync(idx_out, c->d_out_idx, m * 4, hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
+int pie_result_device_ptrs(pie_ctx* c, void** counts_dev, void** offsets_dev, void** idx_dev)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
+    if (counts_dev) *counts_dev = c->d_counts;
+    if (offsets_dev) *offsets_dev = c->d_offsets;
+    if (idx_dev) *idx_dev = c->d_out_idx;
+    return PIE_OK;
+}
+
+int pie_copy_results_device(pie_ctx* c, void* counts_dst, void* offsets_dst, void* idx_dst, size_t idx_cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
+    PIE_HIP(c, hipSetDevice(c->device));
+    if (counts_dst)
+        PIE_HIP(c, hipMemcpyAsync(counts_dst, c->d_counts, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (offsets_dst)
+        PIE_HIP(c, hipMemcpyAsync(offsets_dst, c->d_offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    size_t m = (size_t)c->last.m;
+    if (m > idx_cap) m = idx_cap;
+    if (idx_dst && m) PIE_HIP(c, hipMemcpyAsync(idx_dst, c->d_out_idx, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    return PIE_OK;
+}
+
+int pie_fetch_rows(pie_ctx* c, const int32_t* idx, size_t m, int64_t* start, int64_t* end, int32_t* user, int32_t* disc)
+{
+    if (!c) return PIE_E_INVAL;
+    if (m == 0) return PIE_OK;
+    if (!idx) return fail(c, PIE_E_INVAL, "idx is NULL");
+    if (c->n == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    PIE_HIP(c, hipSetDevice(c->device));
+    // device scratch: [idx m*4][start m*8][end m*8][user m*4][disc m*4]
+    char* d = nullptr;
+    const size_t bytes = m * 28 + 64;
+    PIE_HIP(c, hipMalloc(&d, bytes));
+    long long* o_s = reinterpret_cast<long long*>(d);
+    long long* o_e = o_s + m;
+    int* o_u = reinterpret_cast<int*>(o_e + m);
+    int* o_d = o_u + m;
+    int* d_idx = o_d + m;
+    hipError_t e = hipMemcpyAsync(d_idx, idx, m * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fetch_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_idx, (long long)m,
+                           c->n, c->d_start, c->d_end, c->d_user, c->d_disc, o_s, o_e, o_u, o_d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && start) e = hipMemcpyAsync(start, o_s, m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && end) e = hipMemcpyAsync(end, o_e, m * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && user) e = hipMemcpyAsync(user, o_u, m * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && disc) e = hipMemcpyAsync(disc, o_d, m * 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, PIE_E_HIP, "pie_fetch_rows: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return PIE_OK;
+}
+
+int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_out, size_t cap, size_t* q_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (q_out) *q_out = 0;
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n == 0) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // reuses the scan workspace: blk_count / blk_off for the per-block prefix, out_idx as the device queue
+    hipLaunchKernelGGL(k_expired_count, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
+                       (long long)prev_now, (long long)now, c->d_blk_count);
+    hipLaunchKernelGGL(k_tile_sums, dim3(1), dim3(256), 0, s, c->d_counts, 0, c->d_tile_sum, 0, c->d_blk_count,
+                       c->k1_blocks, c->d_blk_off, c->d_summary);
+    hipLaunchKernelGGL(k_expired_write, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
+                       (long long)prev_now, (long long)now, c->d_blk_off, c->d_out_idx, c->cap_rows);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    c->have_scan = false;
+    const size_t q = (size_t)c->h_summary->m;
+    if (q_out) *q_out = q;
+    if (queue_out && q > cap) return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, q);
+    if (queue_out && q) {
+        PIE_HIP(c, hipMemcpyAsync(queue_out, c->d_out_idx, q * 4, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    }
+    return PIE_OK;
+}
+
+int pie_set_profiling(pie_ctx* c, int enabled)
+{
+    if (!c) return PIE_E_INVAL;
+    c->profiling = enabled != 0;
+    return PIE_OK;
+}
+
+int pie_stats_get(pie_ctx* c, pie_stats* out)
+{
+    if (!c || !out) return PIE_E_INVAL;
+    if (out->struct_size != sizeof(pie_stats)) return fail(c, PIE_E_INVAL, "pie_stats.struct_size mismatch");
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    out->n_profiled = c->n_profiled;
+    out->rows = (uint64_t)c->n;
+    out->users = (uint64_t)c->n_users;
+    out->selected = c->last.m;
+    out->alg_bytes = 24ull * (uint64_t)c->n;
+    out->k1_ms_sum = c->k1_ms_sum;
+    out->scan_ms_sum = c->scan_ms_sum;
+    out->max_bucket = c->last.max_count;
+    out->n_segments = c->last.n_seg;
+    out->n_big = c->last.n_big;
+    out->k1_blocks = (uint32_t)c->k1_blocks;
+    return PIE_OK;
+}
+
+int pie_stats_reset(pie_ctx* c)
+{
+    if (!c) return PIE_E_INVAL;
+    int rc = resolve_events(c);
+    c->k1_ms_sum = c->scan_ms_sum = 0;
+    c->n_profiled = 0;
+    return rc;
+}
+
+int pie_synchronize(pie_ctx* c)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
+int32_t pie_shard_of(int32_t user, int32_t n_shards)
+{
+    if (n_shards <= 1) return 0;
+    unsigned long long z = (unsigned long long)(uint32_t)user + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (int32_t)(z % (unsigned long long)n_shards);
+}
+
+} // extern "C"

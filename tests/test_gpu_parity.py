@@ -1,0 +1,211 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs — bit-exact
+counts / offsets / idx — plus the golden fixtures and size-independent properties at full size."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+INT64_MIN = -(2 ** 63)
+ALL = 2 ** 64 - 1
+DAY = 86400 * 1000
+SEED = 0x5EED5EED
+
+
+def spec_query(oracle):
+    return oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 61 * DAY, 0x5555555555555555
+
+
+def assert_same(got, want):
+    for name, a, b in zip(("counts", "offsets", "idx"), got, want):
+        assert a.dtype == b.dtype, name
+        assert np.array_equal(a, b), name
+
+
+def run_both(ctx, oracle, cols, U, D, now, cutoff, mask):
+    s, e, u, d = cols
+    ctx.load_columns(s, e, u, d, U)
+    ctx.set_disciplines(mask, D)
+    got = ctx.scan(now, cutoff)
+    m = mask if D >= 64 else mask & ((1 << D) - 1)
+    want = oracle.scan(s, e, u, d, U, now, cutoff, m)
+    assert_same(got, want)
+    return got
+
+
+def test_golden_sessionstore_vectors(gpu_ctx, oracle):
+    g = json.load(open(os.path.join(GOLDEN, "sessionstore_g1_g4.json")))
+    users = g["users"]
+    s = np.array([r["createdAt"] for r in g["sessions"]], np.int64)
+    e = np.array([r["expiresAt"] for r in g["sessions"]], np.int64)
+    u = np.array([users.index(r["user"]) for r in g["sessions"]], np.int32)
+    d = np.zeros(len(s), np.int32)
+    gpu_ctx.load_columns(s, e, u, d, len(users))
+    gpu_ctx.set_disciplines(1, 1)
+    for case in g["G1"]:
+        counts, offsets, idx = gpu_ctx.scan(case["now"], INT64_MIN)
+        live = np.zeros(len(s), int)
+        live[idx] = 1
+        assert live.tolist() == case["live"]
+    for case in g["G2"]:
+        _, _, idx = gpu_ctx.scan(case["now"], INT64_MIN)
+        assert sorted(idx.tolist()) == case["survivors"]
+        q = gpu_ctx.expired_queue(INT64_MIN, case["now"])
+        assert sorted(set(range(len(s))) - set(q.tolist())) == case["survivors"]
+        assert q.tolist() == sorted(q.tolist())
+    for case in g["G3"]:
+        gpu_ctx.load_columns(s, e, u, d, len(users))
+        k = users.index(case["user"]) if case["user"] in users else -1
+        deleted = gpu_ctx.delete_user(k)
+        _, _, idx = gpu_ctx.scan(case["observe_now"], INT64_MIN)
+        assert sorted(idx.tolist()) == case["survivors"]
+        assert deleted == len(s) - len(case["survivors"])
+    gpu_ctx.load_columns(s, e, u, d, len(users))
+    for t in g["G4"]:
+        if t["returned"] is None:
+            continue
+        gpu_ctx.set_end([t["row"]], [t["returned"]["expiresAt"]])
+        _, e2, _, _ = gpu_ctx.fetch_rows([t["row"]])
+        assert int(e2[0]) == t["after"]["expiresAt"]
+
+
+def test_hand_derived_vectors(gpu_ctx):
+    h = json.load(open(os.path.join(GOLDEN, "hand_derived_h1_h5.json")))
+    for case in h["scan_cases"]:
+        c = case["columns"]
+        gpu_ctx.load_columns(c["start"], c["end"], c["user"], c["disc"], case["n_users"])
+        gpu_ctx.set_disciplines(case["mask"], 64)
+        counts, offsets, idx = gpu_ctx.scan(case["now"], case["cutoff"])
+        assert counts.tolist() == case["expect"]["counts"], case["name"]
+        assert offsets.tolist() == case["expect"]["offsets"], case["name"]
+        assert idx.tolist() == case["expect"]["idx"], case["name"]
+
+
+@pytest.mark.parametrize("n,U,D,flags", [
+    (1000, 10, 3, 0),            # BASELINE config 1
+    (1, 1, 1, 0), (63, 2, 2, 0), (64, 2, 2, 1), (65, 3, 2, 0), (511, 5, 7, 1), (512, 5, 7, 0), (513, 5, 7, 3),
+    (2047, 11, 32, 0), (2048, 11, 32, 1), (2049, 11, 32, 2), (100003, 97, 32, 0), (300000, 1, 32, 1),
+    (1 << 20, 10 ** 4, 32, 0), (1 << 20, 10 ** 4, 32, 3), (3000017, 2049, 64, 1),
+])
+def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
+    cols = oracle.gen(SEED, n, 0, n, U, D, flags)
+    now, cutoff, mask = spec_query(oracle)
+    run_both(gpu_ctx, oracle, cols, U, D, now, cutoff, mask)
+    # everything selected (every bucket full, medium / big sort paths), nothing selected, half window
+    run_both(gpu_ctx, oracle, cols, U, D, INT64_MIN, INT64_MIN, ALL)
+    got = run_both(gpu_ctx, oracle, cols, U, D, 2 ** 62, INT64_MIN, ALL)
+    assert got[2].size == 0 and got[1][-1] == 0
+    run_both(gpu_ctx, oracle, cols, U, D, oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)
+
+
+def test_generator_parity(gpu_ctx, oracle):
+    for n, U, D, flags in [(1000, 10, 3, 0), (70001, 333, 32, 1), (70001, 333, 32, 2), (4096, 4096, 64, 3)]:
+        gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, flags)
+        got = gpu_ctx.read_columns()
+        want = oracle.gen(SEED, n, 0, n, U, D, flags)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    gpu_ctx.gen_synthetic(SEED, 10 ** 6, 123456, 5000, 100, 32, 1)  # a slice of a bigger table
+    for a, b in zip(gpu_ctx.read_columns(), oracle.gen(SEED, 10 ** 6, 123456, 5000, 100, 32, 1)):
+        assert np.array_equal(a, b)
+
+
+def test_skewed_users_big_buckets(gpu_ctx, oracle):
+    """One user owns most rows (Zipf-like head): exercises tiles + merge passes of the big-bucket path."""
+    rng = np.random.default_rng(7)
+    n, U = 700001, 50
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    u = np.where(rng.random(n) < 0.8, 3, u).astype(np.int32)
+    u[rng.random(n) < 0.05] = 17
+    s[::5] = s[0]  # many equal starts -> tie rule by row index under the merge path
+    got = run_both(gpu_ctx, oracle, (s, e, u, d), U, 32, INT64_MIN, INT64_MIN, ALL)
+    assert got[0].max() > 4096 * 64
+    st = gpu_ctx.stats()
+    assert st["n_big"] >= 2 and st["max_bucket"] == got[0].max()
+
+
+def test_sentinel_end_and_out_of_table_disciplines(gpu_ctx, oracle):
+    n, U = 5000, 9
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 7, 0)
+    e[::3] = INT64_MIN          # "no end" / tombstone: never live, even for now = INT64_MIN
+    d[1::7] = -1
+    d[2::7] = 64
+    d[3::7] = 2 ** 31 - 1
+    got = run_both(gpu_ctx, oracle, (s, e, u, d), U, 7, INT64_MIN, INT64_MIN, ALL)
+    assert not np.any(np.isin(got[2], np.arange(0, n, 3)))
+
+
+def test_bad_user_ids_are_rejected_not_faulted(gpu_ctx, pie, oracle):
+    s, e, u, d = oracle.gen(SEED, 3000, 0, 3000, 5, 3, 0)
+    u[1234] = 5
+    with pytest.raises(pie.PieError) as ei:
+        gpu_ctx.load_columns(s, e, u, d, 5)
+    assert ei.value.code == -1
+    u[1234] = -1
+    with pytest.raises(pie.PieError):
+        gpu_ctx.load_columns(s, e, u, d, 5)
+
+
+def test_idx_capacity_error(gpu_ctx, pie, oracle):
+    s, e, u, d = oracle.gen(SEED, 4000, 0, 4000, 5, 3, 0)
+    gpu_ctx.load_columns(s, e, u, d, 5)
+    gpu_ctx.set_disciplines(ALL, 64)
+    with pytest.raises(pie.PieError) as ei:
+        gpu_ctx.scan(INT64_MIN, INT64_MIN, idx_cap=10)
+    assert ei.value.code == pie.binding.PIE_E_CAPACITY
+
+
+def test_expired_queue_parity(gpu_ctx, oracle):
+    for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
+        s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)
+        gpu_ctx.load_columns(s, e, u, d, 100)
+        for prev, now in [(oracle.T0_MS - 50 * DAY, oracle.T0_MS - 20 * DAY), (INT64_MIN, 2 ** 62), (5, 4),
+                          (oracle.T0_MS - 6 * 3600 * 1000 - 60000, oracle.T0_MS - 6 * 3600 * 1000)]:
+            assert np.array_equal(gpu_ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now))
+
+
+def test_config2_parity_1e7(gpu_ctx, oracle):
+    """BASELINE config 2: 10^7 sessions / 10^4 users / 32 disciplines, generated on the device."""
+    n, U, D = 10 ** 7, 10 ** 4, 32
+    now, cutoff, mask = spec_query(oracle)
+    for flags in (0, 1, 2):
+        gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, flags)
+        gpu_ctx.set_disciplines(mask, D)
+        got = gpu_ctx.scan(now, cutoff)
+        want = oracle.scan(*oracle.gen(SEED, n, 0, n, U, D, flags), U, now, cutoff, mask & ((1 << D) - 1))
+        assert_same(got, want)
+        assert got[2].size > 0
+
+
+def test_full_size_properties_1e8(gpu_ctx, oracle):
+    """BASELINE config 3 (10^8 / 10^5 / 32): properties that need no full-size oracle run, plus an exact
+    oracle comparison on the selected rows only."""
+    n, U, D = 10 ** 8, 10 ** 5, 32
+    now, cutoff, mask = spec_query(oracle)
+    gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.set_disciplines(mask, D)
+    counts, offsets, idx = gpu_ctx.scan(now, cutoff)
+    m = idx.size
+    assert offsets[0] == 0 and offsets[-1] == m == int(counts.sum(dtype=np.int64))
+    assert np.array_equal(np.diff(offsets), counts)
+    assert np.unique(idx).size == m                      # no row twice
+    s, e, u, d = gpu_ctx.fetch_rows(idx)
+    assert np.all(e > now) and np.all(s >= cutoff) and np.all(((mask >> d.astype(np.uint64)) & 1) == 1)
+    assert np.array_equal(u, np.repeat(np.arange(U, dtype=np.int32), counts))   # buckets are per user, in user order
+    key_ok = (np.diff(s) > 0) | ((np.diff(s) == 0) & (np.diff(idx) > 0)) | (np.diff(u) != 0)
+    assert np.all(key_ok)                                # (start, row) ascending inside every bucket
+    # selectivity of the spec query is 18 h / 120 d live x 16/32 disciplines
+    assert abs(m / n - 0.5 * 18 / (120 * 24)) < 2e-4
+    # idempotence: the same query again gives the same bytes
+    c2, o2, i2 = gpu_ctx.scan(now, cutoff)
+    assert np.array_equal(c2, counts) and np.array_equal(i2, idx)
+    # exact check against the oracle in slices of 10^7 rows: slice-local feeds must be the sub-sequences
+    base = 3 * 10 ** 7
+    sl = oracle.gen(SEED, n, base, 10 ** 7, U, D, 0)
+    wc, wo, wi = oracle.scan(*sl, U, now, cutoff, mask & ((1 << D) - 1))
+    in_slice = (idx >= base) & (idx < base + 10 ** 7)
+    assert np.array_equal(idx[in_slice] - base, wi)      # same relative order (user, start, row) inside the slice
