@@ -7,8 +7,8 @@
 //   K2a k_tile_sums      per-tile sums of counts[U]  (+ prefix of K1's per-block record counts)
 //   K2b k_offsets        exclusive scan -> offsets[U+1], work lists for the sort kernels, summary
 //   K3  k_scatter        selected records -> per-user buckets (slot = offsets[u] + atomic rank)
-//   K4a k_sort_tiny      buckets of <= TINY_MAX rows: one thread per bucket, rank sort
-//   K4b k_sort_segments  buckets (or 4096-row tiles of big buckets): one block each, LDS bitonic
+//   K4  k_sort_buckets  one launch: buckets of <= 16 rows in registers (one thread each, sorting network);
+//                       larger buckets (or 4096-row tiles of big buckets) one block each, LDS bitonic
 //   K4c k_merge_pass     big buckets only: log2(n/4096) rank-merge passes
 // Order inside a bucket is (start asc, row index asc): ORDER BY start_ts ASC
 // (/root/reference/server/storage/sqlProvider.js:276) with the tie rule of SURVEY.md §8 a-D.
@@ -17,6 +17,9 @@
 #include <stdint.h>
 
 namespace pie {
+
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
 
 struct alignas(16) SelRec {
     long long start;
@@ -114,56 +117,73 @@ __global__ __launch_bounds__(256) void k_gen(unsigned long long seed, long long 
 
 struct WaveStage {
     SelRec* ring;  // this wave's LDS ring (kStage records)
+    int* ring_rank;
     int head;      // wave-uniform
     int fill;      // wave-uniform, < 64 between calls
 };
 
-// Flush 64 staged records: one LDS atomic per wave reserves 64 slots of the block's private output range,
-// every lane stores one 16-B record (1 KiB coalesced per wave).
-__device__ __forceinline__ void stage_flush(WaveStage& st, int count, SelRec* __restrict__ out, int* blk_cursor, int lane)
+// Flush staged records: one LDS atomic per wave reserves slots of the block's private output range; every
+// lane stores one 16-B record + its 4-B rank (1 KiB + 256 B coalesced per wave).
+__device__ __forceinline__ void stage_flush(WaveStage& st, int count, SelRec* __restrict__ out, int* __restrict__ out_rank,
+                                            int* blk_cursor, int lane)
 {
     int base = 0;
     if (lane == 0) base = atomicAdd(blk_cursor, count);
     base = __builtin_amdgcn_readfirstlane(base);
-    if (lane < count) out[base + lane] = st.ring[(st.head + lane) & (kStage - 1)];
+    if (lane < count) {
+        const int slot = (st.head + lane) & (kStage - 1);
+        out[base + lane] = st.ring[slot];
+        out_rank[base + lane] = st.ring_rank[slot];
+    }
     st.head = (st.head + count) & (kStage - 1);
     st.fill -= count;
 }
 
-__device__ __forceinline__ void consider_row(bool sel, long long s, int row, int u, WaveStage& st, int n_users,
-                                             int* __restrict__ counts, SelRec* __restrict__ out, int* blk_cursor,
-                                             unsigned int* bad_rows, int lane)
+__device__ __forceinline__ void stage_rows(bool sel, long long s, int row, int u, int rank, WaveStage& st,
+                                           SelRec* __restrict__ out, int* __restrict__ out_rank, int* blk_cursor, int lane)
 {
-    const bool user_ok = (unsigned)u < (unsigned)n_users;
-    if (sel & !user_ok) atomicAdd(bad_rows, 1u);
-    sel &= user_ok;
     const unsigned long long b = __ballot(sel);
     if (b == 0) return; // wave-uniform: nothing selected in this 64-row slice
     if (sel) {
-        atomicAdd(&counts[u], 1); // result unused -> no-return global_atomic_add
+        const int slot = (st.head + st.fill + prefix_in_ballot(b)) & (kStage - 1);
         SelRec r;
         r.start = s;
         r.idx = row;
         r.user = u;
-        st.ring[(st.head + st.fill + prefix_in_ballot(b)) & (kStage - 1)] = r;
+        st.ring[slot] = r;
+        st.ring_rank[slot] = rank;
     }
     st.fill += __popcll(b);
     __builtin_amdgcn_wave_barrier();
-    if (st.fill >= kWave) stage_flush(st, kWave, out, blk_cursor, lane);
+    if (st.fill >= kWave) stage_flush(st, kWave, out, out_rank, blk_cursor, lane);
     __builtin_amdgcn_wave_barrier();
+}
+
+template <bool NT, class T>
+__device__ __forceinline__ T stream_load(const T* p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 // Block b owns rows [b*rows_per_block, (b+1)*rows_per_block) and the same index range of `sel` as its
 // private output region (a block can never select more rows than it reads), so compaction needs no global
 // cursor: blk_count[b] says how many records the region holds.
+//   UNROLL  128-row units per wave iteration
+//   NT      nontemporal (streaming) loads for the read-once columns
+//   LATE_U  load user[] only in lanes whose row passed the predicate (late materialisation): the user column
+//           is output data, not predicate input, so unselected rows never need it
+template <int UNROLL, bool NT, bool LATE_U>
 __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ blk_count, unsigned int* __restrict__ bad_rows)
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, unsigned int* __restrict__ bad_rows)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
+    __shared__ int stage_rank[kK1Waves][kStage];
     __shared__ int blk_cursor;
+    constexpr int kTile = kUnitRows * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) blk_cursor = 0;
@@ -173,52 +193,81 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     long long c1 = c0 + rows_per_block;
     if (c1 > n) c1 = n;
     SelRec* out = sel + c0;
+    int* out_rank = sel_rank + c0;
     WaveStage st;
     st.ring = stage[wave];
+    st.ring_rank = stage_rank[wave];
     st.head = 0;
     st.fill = 0;
 
-    for (long long t = c0 + (long long)wave * kWaveTileRows; t < c1; t += kBlockTileRows) {
-        if (t + kWaveTileRows <= c1) {
-            // full wave-tile: 4 units x (2 rows per lane); every load is a fully used, aligned line
-            longlong2 s[kUnroll], e[kUnroll];
-            int2 u[kUnroll], d[kUnroll];
+    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
+        if (t + kTile <= c1) {
+            // full wave-tile: UNROLL units x (2 rows per lane); every load is a fully used, aligned line
+            ll2_t s[UNROLL], e[UNROLL];
+            i2_t u[UNROLL], d[UNROLL];
 #pragma unroll
-            for (int j = 0; j < kUnroll; ++j) {
+            for (int j = 0; j < UNROLL; ++j) {
                 const long long r = t + j * kUnitRows + 2 * lane;
-                e[j] = *reinterpret_cast<const longlong2*>(end + r);
-                s[j] = *reinterpret_cast<const longlong2*>(start + r);
-                d[j] = *reinterpret_cast<const int2*>(disc + r);
-                u[j] = *reinterpret_cast<const int2*>(user + r);
+                e[j] = stream_load<NT>(reinterpret_cast<const ll2_t*>(end + r));
+                s[j] = stream_load<NT>(reinterpret_cast<const ll2_t*>(start + r));
+                d[j] = stream_load<NT>(reinterpret_cast<const i2_t*>(disc + r));
+                if constexpr (!LATE_U) u[j] = stream_load<NT>(reinterpret_cast<const i2_t*>(user + r));
             }
+            bool p[2 * UNROLL];
+            int rank[2 * UNROLL];
 #pragma unroll
-            for (int j = 0; j < kUnroll; ++j) {
-                const int r = (int)(t + j * kUnitRows + 2 * lane);
-                consider_row(row_selected(s[j].x, e[j].x, d[j].x, now, cutoff, mask), s[j].x, r, u[j].x, st, n_users,
-                             counts, out, &blk_cursor, bad_rows, lane);
-                consider_row(row_selected(s[j].y, e[j].y, d[j].y, now, cutoff, mask), s[j].y, r + 1, u[j].y, st,
-                             n_users, counts, out, &blk_cursor, bad_rows, lane);
+            for (int j = 0; j < UNROLL; ++j) {
+                p[2 * j] = row_selected(s[j].x, e[j].x, d[j].x, now, cutoff, mask);
+                p[2 * j + 1] = row_selected(s[j].y, e[j].y, d[j].y, now, cutoff, mask);
+                if constexpr (LATE_U) {
+                    const long long r = t + j * kUnitRows + 2 * lane;
+                    u[j].x = 0;
+                    u[j].y = 0;
+                    if (p[2 * j]) u[j].x = user[r];
+                    if (p[2 * j + 1]) u[j].y = user[r + 1];
+                }
+            }
+            // phase A: histogram + rank.  The returning atomic's latency hides behind the streaming loads of
+            // the other waves; K3 then needs no atomics at all.
+#pragma unroll
+            for (int k = 0; k < 2 * UNROLL; ++k) {
+                const int uu = (k & 1) ? u[k >> 1].y : u[k >> 1].x;
+                rank[k] = 0;
+                if (p[k]) {
+                    if ((unsigned)uu < (unsigned)n_users) rank[k] = atomicAdd(&counts[uu], 1);
+                    else { atomicAdd(bad_rows, 1u); p[k] = false; }
+                }
+            }
+            // phase B: wave-prefix compaction into the LDS ring
+#pragma unroll
+            for (int k = 0; k < 2 * UNROLL; ++k) {
+                const int j = k >> 1;
+                const int r = (int)(t + j * kUnitRows + 2 * lane) + (k & 1);
+                stage_rows(p[k], (k & 1) ? s[j].y : s[j].x, r, (k & 1) ? u[j].y : u[j].x, rank[k], st, out, out_rank,
+                           &blk_cursor, lane);
             }
         } else {
             // ragged tail of the block's range: one row per lane, bounds-checked
-            const long long t1 = (t + kWaveTileRows < c1) ? t + kWaveTileRows : c1;
+            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
             for (long long r0 = t; r0 < t1; r0 += kWave) {
                 const long long r = r0 + lane;
-                const bool in = r < t1;
-                long long sv = 0, ev = 0;
-                int uv = 0, dv = -1;
-                if (in) {
+                bool sel_row = false;
+                long long sv = 0;
+                int uv = 0, rk = 0;
+                if (r < t1) {
                     sv = start[r];
-                    ev = end[r];
-                    uv = user[r];
-                    dv = disc[r];
+                    sel_row = row_selected(sv, end[r], disc[r], now, cutoff, mask);
+                    if (sel_row) {
+                        uv = user[r];
+                        if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[uv], 1);
+                        else { atomicAdd(bad_rows, 1u); sel_row = false; }
+                    }
                 }
-                consider_row(in && row_selected(sv, ev, dv, now, cutoff, mask), sv, (int)r, uv, st, n_users, counts, out,
-                             &blk_cursor, bad_rows, lane);
+                stage_rows(sel_row, sv, (int)r, uv, rk, st, out, out_rank, &blk_cursor, lane);
             }
         }
     }
-    if (st.fill > 0) stage_flush(st, st.fill, out, &blk_cursor, lane);
+    if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
     __syncthreads();
     if (threadIdx.x == 0) blk_count[blockIdx.x] = blk_cursor;
 }
@@ -247,25 +296,30 @@ __device__ __forceinline__ long long block_sum_256(long long v, long long* lds4)
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-// K2a: tile_sum[b] = sum of counts over tile b.  The extra last block turns K1's per-block record counts
-// into the prefix blk_off[nb+1] that K3 uses to balance its reads.
+// K2a: tile_sum[b] = sum of counts over tile b (2048 users per block).
 __global__ __launch_bounds__(256) void k_tile_sums(const int* __restrict__ counts, int n_users,
-                                                   long long* __restrict__ tile_sum, int n_tiles,
-                                                   const int* __restrict__ blk_count, int nb,
-                                                   long long* __restrict__ blk_off, Summary* __restrict__ summary)
+                                                   long long* __restrict__ tile_sum)
 {
     __shared__ long long lds4[4];
-    if ((int)blockIdx.x < n_tiles) {
-        const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
-        long long v = 0;
+    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
+    long long v = 0;
+    if (base + 8 <= n_users) {
+        const int4 a = *reinterpret_cast<const int4*>(counts + base);
+        const int4 b = *reinterpret_cast<const int4*>(counts + base + 4);
+        v = (long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (base + k < n_users) v += counts[base + k];
-        v = block_sum_256(v, lds4);
-        if (threadIdx.x == 0) tile_sum[blockIdx.x] = v;
-        return;
     }
-    // last block: exclusive prefix over blk_count[0..nb)
+    v = block_sum_256(v, lds4);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = v;
+}
+
+// exclusive prefix over blk[0..nb) by ONE block -> off[nb+1]; total also stored to *total_out (may be null)
+__global__ __launch_bounds__(256) void k_block_prefix(const int* __restrict__ blk, int nb, long long* __restrict__ off,
+                                                      unsigned long long* __restrict__ total_out)
+{
     __shared__ long long wsum[4];
     __shared__ long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -273,30 +327,32 @@ __global__ __launch_bounds__(256) void k_tile_sums(const int* __restrict__ count
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b0 = 0; b0 < nb; b0 += 256) {
         const int b = b0 + threadIdx.x;
-        const long long c = b < nb ? blk_count[b] : 0;
+        const long long c = b < nb ? blk[b] : 0;
         const long long incl = wave_incl_scan(c, lane);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         long long wbase = 0;
         for (int w = 0; w < wave; ++w) wbase += wsum[w];
         const long long carry = carry_s;
-        if (b < nb) blk_off[b] = carry + wbase + incl - c;
+        if (b < nb) off[b] = carry + wbase + incl - c;
         __syncthreads();
         if (threadIdx.x == 255) carry_s = carry + wbase + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        blk_off[nb] = carry_s;
-        summary->m = (unsigned long long)carry_s;
+        off[nb] = carry_s;
+        if (total_out) *total_out = (unsigned long long)carry_s;
     }
 }
 
-// K2b: offsets[u] = exclusive prefix of counts; cursor[u] = 0; sort work lists; max bucket.
+// K2b: offsets[u] = exclusive prefix of counts; sort work lists; max bucket; M.  Also clears the OTHER
+// counts / summary buffers, so the next scan starts from zero without a memset on its critical path.
 __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts, int n_users,
                                                  const long long* __restrict__ tile_sum,
-                                                 long long* __restrict__ offsets, int* __restrict__ cursor,
+                                                 long long* __restrict__ offsets,
                                                  Segment* __restrict__ seg_list, int* __restrict__ big_list,
-                                                 Summary* __restrict__ summary)
+                                                 Summary* __restrict__ summary, int* __restrict__ counts_next,
+                                                 Summary* __restrict__ summary_next)
 {
     __shared__ long long lds4[4];
     __shared__ long long wsum[4];
@@ -309,11 +365,22 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
     const int u0 = blockIdx.x * kScanTile + threadIdx.x * 8;
     int c[8];
     long long tsum = 0;
+    if (u0 + 8 <= n_users) {
+        const int4 a = *reinterpret_cast<const int4*>(counts + u0);
+        const int4 b = *reinterpret_cast<const int4*>(counts + u0 + 4);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        const int4 z = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4*>(counts_next + u0) = z;
+        *reinterpret_cast<int4*>(counts_next + u0 + 4) = z;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
-        tsum += c[k];
+        for (int k = 0; k < 8; ++k) {
+            c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
+            if (u0 + k < n_users) counts_next[u0 + k] = 0;
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tsum += c[k];
     const long long incl = wave_incl_scan(tsum, lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -325,7 +392,6 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
         const int u = u0 + k;
         if (u < n_users) {
             offsets[u] = run;
-            cursor[u] = 0;
             const int n = c[k];
             local_max = max(local_max, (unsigned)n);
             if (n > kTinyMax) {
@@ -352,67 +418,134 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
             run += n;
         }
     }
-    if (u0 + 8 >= n_users && u0 < n_users) offsets[n_users] = run; // thread holding the last user
+    if (u0 + 8 >= n_users && u0 < n_users) { // thread holding the last user
+        offsets[n_users] = run;
+        summary->m = (unsigned long long)run;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local_max = max(local_max, (unsigned)__shfl_xor((int)local_max, o, kWave));
     if (lane == 0 && local_max > 0) atomicMax(&summary->max_count, local_max);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        summary_next->m = 0;
+        summary_next->n_seg = 0;
+        summary_next->n_big = 0;
+        summary_next->max_count = 0;
+        summary_next->bad_rows = 0;
+        summary_next->q = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K3 scatter
 
-// Record r of the concatenated per-block regions -> bucket slot offsets[user] + rank, rank from a returning
-// atomic on cursor[user].  Slot order inside a bucket is arbitrary here; K4 makes it (start, idx) order.
-__global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel, const long long* __restrict__ blk_off,
-                                                 int nb, long long rows_per_block,
-                                                 const long long* __restrict__ offsets, int* __restrict__ cursor,
+// Records of K1 block b (blk_count[b] of them, in that block's private region) -> bucket slot
+// offsets[user] + rank.  No atomics: the rank came back from K1's histogram atomic.
+// Phase 1: one WAVE per region for the common small regions (one dependent chain per wave, all regions in
+// flight at once).  Phase 2: regions with more than kScatterWaveMax records (a time-ordered table selects
+// whole regions) are walked by a whole block each.
+constexpr int kScatterWaveMax = 1024;
+
+__device__ __forceinline__ void scatter_one(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank, long long at,
+                                            const long long* __restrict__ offsets, long long* __restrict__ bkt_start,
+                                            int* __restrict__ bkt_idx)
+{
+    const SelRec rec = sel[at];
+    const long long pos = offsets[rec.user] + sel_rank[at];
+    bkt_start[pos] = rec.start;
+    bkt_idx[pos] = rec.idx;
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank,
+                                                 const int* __restrict__ blk_count, int nb, long long rows_per_block,
+                                                 const long long* __restrict__ offsets,
                                                  long long* __restrict__ bkt_start, int* __restrict__ bkt_idx)
 {
-    const long long m = blk_off[nb];
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = nb; // last b with blk_off[b] <= r
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (blk_off[mid] <= r) lo = mid; else hi = mid;
-        }
-        const SelRec rec = sel[(long long)lo * rows_per_block + (r - blk_off[lo])];
-        const int rank = atomicAdd(&cursor[rec.user], 1);
-        const long long pos = offsets[rec.user] + rank;
-        bkt_start[pos] = rec.start;
-        bkt_idx[pos] = rec.idx;
+    const int lane = threadIdx.x & 63;
+    const int n_waves = gridDim.x * 4;
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nb; b += n_waves) {
+        const int cnt = blk_count[b];
+        if (cnt > kScatterWaveMax) continue;
+        const long long base = (long long)b * rows_per_block;
+        for (int i = lane; i < cnt; i += 64) scatter_one(sel, sel_rank, base + i, offsets, bkt_start, bkt_idx);
+    }
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int cnt = blk_count[b];
+        if (cnt <= kScatterWaveMax) continue;
+        const long long base = (long long)b * rows_per_block;
+        for (int i = threadIdx.x; i < cnt; i += 256) scatter_one(sel, sel_rank, base + i, offsets, bkt_start, bkt_idx);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ K4 order
 
-// K4a: one thread per bucket of <= kTinyMax rows: rank sort (keys (start, idx) are unique).
-__global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                   int n_users, const long long* __restrict__ bkt_start,
-                                                   const int* __restrict__ bkt_idx, int* __restrict__ out_idx)
+// Register sorting network (bitonic, fully unrolled so every index is a compile-time constant): NS slots,
+// the first n hold the bucket, the rest are +inf padding.
+template <int NS>
+__device__ __forceinline__ void sort_bucket_regs(long long o, int n, const long long* __restrict__ bkt_start,
+                                                 const int* __restrict__ bkt_idx, int* __restrict__ out_idx)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_users) return;
+    long long ks[NS];
+    int ki[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const bool in = k < n;
+        ks[k] = in ? bkt_start[o + k] : INT64_MAX;
+        ki[k] = in ? bkt_idx[o + k] : INT32_MAX;
+    }
+#pragma unroll
+    for (int k = 2; k <= NS; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool lt = key_less(ks[l], ki[l], ks[i], ki[i]); // element l sorts before element i
+                    const bool sw = up ? lt : !lt;
+                    const long long s0 = sw ? ks[l] : ks[i], s1 = sw ? ks[i] : ks[l];
+                    const int i0 = sw ? ki[l] : ki[i], i1 = sw ? ki[i] : ki[l];
+                    ks[i] = s0; ks[l] = s1; ki[i] = i0; ki[l] = i1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        if (k < n) out_idx[o + k] = ki[k];
+}
+
+// K4a: one thread per bucket of <= kTinyMax (16) rows: every load issued at once, sorting network in
+// registers (8 slots for the common case, 16 otherwise).  Keys (start, idx) are unique.
+__device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                 const long long* __restrict__ bkt_start, const int* __restrict__ bkt_idx,
+                                                 int* __restrict__ out_idx)
+{
     const int n = counts[u];
     if (n == 0 || n > kTinyMax) return;
     const long long o = offsets[u];
-    for (int j = 0; j < n; ++j) {
-        const long long sj = bkt_start[o + j];
-        const int ij = bkt_idx[o + j];
-        int rank = 0;
-        for (int k = 0; k < n; ++k) rank += key_less(bkt_start[o + k], bkt_idx[o + k], sj, ij) ? 1 : 0;
-        out_idx[o + rank] = ij;
-    }
+    if (n == 1) { out_idx[o] = bkt_idx[o]; return; }
+    if (n <= 8) sort_bucket_regs<8>(o, n, bkt_start, bkt_idx, out_idx);
+    else sort_bucket_regs<16>(o, n, bkt_start, bkt_idx, out_idx);
 }
 
 // K4b: one block per segment (<= kSegMax rows): bitonic sort of (start, idx) in LDS.
-__global__ __launch_bounds__(256) void k_sort_segments(const Segment* __restrict__ seg_list,
-                                                       const Summary* __restrict__ summary,
-                                                       long long* __restrict__ bkt_start, int* __restrict__ bkt_idx,
-                                                       int* __restrict__ out_idx)
+// K4 is ONE launch: blocks [0, tiny_blocks) run K4a, the remaining blocks walk the segment list.
+__global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                      int n_users, int tiny_blocks, const Segment* __restrict__ seg_list,
+                                                      const Summary* __restrict__ summary,
+                                                      long long* __restrict__ bkt_start, int* __restrict__ bkt_idx,
+                                                      int* __restrict__ out_idx)
 {
     __shared__ long long ks[kSegMax];
     __shared__ int ki[kSegMax];
+    if ((int)blockIdx.x < tiny_blocks) {
+        const int u = blockIdx.x * 256 + threadIdx.x;
+        if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt_start, bkt_idx, out_idx);
+        return;
+    }
     const unsigned n_seg = summary->n_seg;
-    for (unsigned w = blockIdx.x; w < n_seg; w += gridDim.x) {
+    const unsigned seg_blocks = gridDim.x - tiny_blocks;
+    for (unsigned w = blockIdx.x - tiny_blocks; w < n_seg; w += seg_blocks) {
         const Segment sg = seg_list[w];
         int p = 32;
         while (p < sg.len) p <<= 1;

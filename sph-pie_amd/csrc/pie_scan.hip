@@ -48,7 +48,11 @@ struct pie_ctx {
     int k1_blocks = 0;
     long long rows_per_block = 0;
     int n_tiles = 0;
-    int *d_counts = nullptr, *d_cursor = nullptr;
+    int* d_counts2[2] = {nullptr, nullptr}; // ping-pong: K2b of scan i clears the buffer of scan i+1
+    int* d_counts = nullptr;                 // buffer holding the last scan's counts
+    int cur = 0;
+    int* d_sel_rank = nullptr;
+    int k1_variant = 0x03; // nontemporal loads + late user materialisation (measured best, profiles/)
     long long* d_offsets = nullptr;
     long long* d_tile_sum = nullptr;
     SelRec* d_sel = nullptr;
@@ -59,7 +63,8 @@ struct pie_ctx {
     int* d_out_idx = nullptr;
     Segment* d_seg_list = nullptr;
     int* d_big_list = nullptr;
-    Summary* d_summary = nullptr;
+    Summary* d_summary = nullptr;            // scratch for table maintenance calls
+    Summary* d_sum2[2] = {nullptr, nullptr}; // per-scan summaries, ping-pong like counts
     Summary* h_summary = nullptr; // pinned
     hipEvent_t ev_summary = nullptr;
     bool have_scan = false;
@@ -103,22 +108,25 @@ void dfree(T*& p)
 void free_table(pie_ctx* c)
 {
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc);
-    dfree(c->d_counts); dfree(c->d_cursor); dfree(c->d_offsets); dfree(c->d_tile_sum);
-    dfree(c->d_sel); dfree(c->d_blk_count); dfree(c->d_blk_off);
+    dfree(c->d_counts2[0]); dfree(c->d_counts2[1]); c->d_counts = nullptr; dfree(c->d_offsets); dfree(c->d_tile_sum);
+    dfree(c->d_sel); dfree(c->d_sel_rank); dfree(c->d_blk_count); dfree(c->d_blk_off);
     dfree(c->d_bkt_start); dfree(c->d_bkt_idx); dfree(c->d_out_idx);
     dfree(c->d_seg_list); dfree(c->d_big_list);
     c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0; c->have_scan = false;
 }
 
+int k1_unroll(int variant) { return (variant >> 4) == 2 ? 2 : (variant >> 4) == 8 ? 8 : 4; }
+
 // Grid of the scan kernel: every block owns a contiguous, kBlockTileRows-aligned row range.  Default is a
 // few blocks per CU slot so the tail of the launch is short; PIE_K1_BLOCKS overrides for tuning.
 void plan_k1(pie_ctx* c)
 {
-    long long want = (long long)c->n_cus * 16;
+    long long want = (long long)c->n_cus * 48;
     if (const char* e = getenv("PIE_K1_BLOCKS")) {
         long long v = atoll(e);
         if (v > 0) want = v;
     }
+    const long long kBlockTileRows = (long long)kUnitRows * k1_unroll(c->k1_variant) * kK1Waves;
     long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
     if (tiles < 1) tiles = 1;
     if (want > tiles) want = tiles;
@@ -141,14 +149,15 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users)
         PIE_HIP(c, hipMalloc(&c->d_user, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_disc, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_sel, rows * sizeof(SelRec)));
+        PIE_HIP(c, hipMalloc(&c->d_sel_rank, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_bkt_start, rows * 8));
         PIE_HIP(c, hipMalloc(&c->d_bkt_idx, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_out_idx, rows * 4));
-        const long long max_blocks = rows / kBlockTileRows + 2;
+        const long long max_blocks = rows / (kUnitRows * 2 * kK1Waves) + 2;
         PIE_HIP(c, hipMalloc(&c->d_blk_count, max_blocks * 4));
         PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks + 1) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_counts, (size_t)n_users * 4));
-        PIE_HIP(c, hipMalloc(&c->d_cursor, (size_t)n_users * 4));
+        PIE_HIP(c, hipMalloc(&c->d_counts2[0], (size_t)n_users * 4 + 32));
+        PIE_HIP(c, hipMalloc(&c->d_counts2[1], (size_t)n_users * 4 + 32));
         PIE_HIP(c, hipMalloc(&c->d_offsets, ((size_t)n_users + 1) * 8));
         PIE_HIP(c, hipMalloc(&c->d_tile_sum, ((size_t)n_users / kScanTile + 2) * 8));
         PIE_HIP(c, hipMalloc(&c->d_seg_list, ((size_t)n_users + rows / kSegMax + 16) * sizeof(Segment)));
@@ -160,6 +169,13 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users)
     c->n_users = n_users;
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
     c->have_scan = false;
+    c->cur = 0;
+    c->d_counts = c->d_counts2[0];
+    // both ping-pong buffers start clean; afterwards every scan's K2b clears the next scan's buffers
+    PIE_HIP(c, hipMemsetAsync(c->d_counts2[0], 0, (size_t)n_users * 4, c->stream));
+    PIE_HIP(c, hipMemsetAsync(c->d_counts2[1], 0, (size_t)n_users * 4, c->stream));
+    PIE_HIP(c, hipMemsetAsync(c->d_sum2[0], 0, sizeof(Summary), c->stream));
+    PIE_HIP(c, hipMemsetAsync(c->d_sum2[1], 0, sizeof(Summary), c->stream));
     plan_k1(c);
     return PIE_OK;
 }
@@ -195,6 +211,33 @@ int resolve_events(pie_ctx* c)
     return PIE_OK;
 }
 
+// K1 variants (PIE_K1_VARIANT selects one for tuning runs; the default is the measured best).
+//   bit0: nontemporal loads   bit1: late materialisation of user[]   bits 4..: unroll (0 -> 4)
+void launch_k1(pie_ctx* c, hipStream_t s, long long now, long long cutoff, unsigned long long mask, int* counts,
+               Summary* sum)
+{
+#define PIE_K1(UN, NT, LU)                                                                                          \
+    hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+                       c->d_user, c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, counts, c->d_sel, \
+                       c->d_sel_rank, c->d_blk_count, &sum->bad_rows)
+    switch (c->k1_variant) {
+    case 0x00: PIE_K1(4, false, false); break;
+    case 0x01: PIE_K1(4, true, false); break;
+    case 0x02: PIE_K1(4, false, true); break;
+    case 0x03: PIE_K1(4, true, true); break;
+    case 0x20: PIE_K1(2, false, false); break;
+    case 0x21: PIE_K1(2, true, false); break;
+    case 0x22: PIE_K1(2, false, true); break;
+    case 0x23: PIE_K1(2, true, true); break;
+    case 0x80: PIE_K1(8, false, false); break;
+    case 0x81: PIE_K1(8, true, false); break;
+    case 0x82: PIE_K1(8, false, true); break;
+    case 0x83: PIE_K1(8, true, true); break;
+    default: PIE_K1(4, false, false); break;
+    }
+#undef PIE_K1
+}
+
 // The whole scan, results left on the device.  One host wait in the middle of the queue (for the 32-byte
 // summary) overlaps with K3/K4a/K4b, which are already enqueued behind it.
 int run_scan(pie_ctx* c, long long now, long long cutoff)
@@ -218,29 +261,30 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
     }
     const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
 
-    PIE_HIP(c, hipMemsetAsync(c->d_counts, 0, (size_t)c->n_users * 4, s));
-    PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), s));
+    int* counts = c->d_counts2[c->cur];
+    int* counts_next = c->d_counts2[c->cur ^ 1];
+    Summary* sum = c->d_sum2[c->cur];
+    Summary* sum_next = c->d_sum2[c->cur ^ 1];
     if (ev) PIE_HIP(c, hipEventRecord(ev->e0, s));
-    hipLaunchKernelGGL(k_scan_compact, dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, c->d_user,
-                       c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, c->d_counts, c->d_sel,
-                       c->d_blk_count, &c->d_summary->bad_rows);
+    launch_k1(c, s, now, cutoff, mask, counts, sum);
     if (ev) PIE_HIP(c, hipEventRecord(ev->e1, s));
-    hipLaunchKernelGGL(k_tile_sums, dim3(c->n_tiles + 1), dim3(256), 0, s, c->d_counts, c->n_users, c->d_tile_sum,
-                       c->n_tiles, c->d_blk_count, c->k1_blocks, c->d_blk_off, c->d_summary);
-    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, c->d_counts, c->n_users, c->d_tile_sum,
-                       c->d_offsets, c->d_cursor, c->d_seg_list, c->d_big_list, c->d_summary);
-    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_tile_sums, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum);
+    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum, c->d_offsets,
+                       c->d_seg_list, c->d_big_list, sum, counts_next, sum_next);
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, sum, sizeof(Summary), hipMemcpyDeviceToHost, s));
     if (!c->ev_summary) PIE_HIP(c, hipEventCreateWithFlags(&c->ev_summary, hipEventDisableTiming));
     hipEvent_t summary_ready = c->ev_summary;
     PIE_HIP(c, hipEventRecord(summary_ready, s));
 
-    const int aux_grid = c->n_cus * 8;
-    hipLaunchKernelGGL(k_scatter, dim3(aux_grid), dim3(256), 0, s, c->d_sel, c->d_blk_off, c->k1_blocks,
-                       c->rows_per_block, c->d_offsets, c->d_cursor, c->d_bkt_start, c->d_bkt_idx);
-    hipLaunchKernelGGL(k_sort_tiny, dim3((c->n_users + 255) / 256), dim3(256), 0, s, c->d_counts, c->d_offsets,
-                       c->n_users, c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
-    hipLaunchKernelGGL(k_sort_segments, dim3(c->n_cus * 3), dim3(256), 0, s, c->d_seg_list, c->d_summary,
-                       c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
+    int scat_blocks = (c->k1_blocks + 3) / 4;
+    if (scat_blocks > c->n_cus * 8) scat_blocks = c->n_cus * 8;
+    hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, s, c->d_sel, c->d_sel_rank, c->d_blk_count,
+                       c->k1_blocks, c->rows_per_block, c->d_offsets, c->d_bkt_start, c->d_bkt_idx);
+    const int tiny_blocks = (c->n_users + 255) / 256;
+    hipLaunchKernelGGL(k_sort_buckets, dim3(tiny_blocks + c->n_cus * 3), dim3(256), 0, s, counts, c->d_offsets,
+                       c->n_users, tiny_blocks, c->d_seg_list, sum, c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
+    c->d_counts = counts;
+    c->cur ^= 1;
     PIE_HIP(c, hipGetLastError());
 
     PIE_HIP(c, hipEventSynchronize(summary_ready));
@@ -315,12 +359,15 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->d_summary, sizeof(Summary))) != hipSuccess ||
+        (e = hipMalloc(&c->d_sum2[0], sizeof(Summary))) != hipSuccess ||
+        (e = hipMalloc(&c->d_sum2[1], sizeof(Summary))) != hipSuccess ||
         (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) != hipSuccess) {
         fail(nullptr, PIE_E_NODEVICE, "context setup: %s", hipGetErrorString(e));
         delete c;
         return PIE_E_NODEVICE;
     }
     c->stream = c->own_stream;
+    if (const char* v = getenv("PIE_K1_VARIANT")) c->k1_variant = (int)strtol(v, nullptr, 0);
     *ctx_out = c;
     return PIE_OK;
 }
@@ -336,6 +383,8 @@ int pie_ctx_destroy(pie_ctx* c)
     }
     if (c->ev_summary) (void)hipEventDestroy(c->ev_summary);
     if (c->d_summary) (void)hipFree(c->d_summary);
+    if (c->d_sum2[0]) (void)hipFree(c->d_sum2[0]);
+    if (c->d_sum2[1]) (void)hipFree(c->d_sum2[1]);
     if (c->h_summary) (void)hipHostFree(c->h_summary);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -552,8 +601,8 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
     // reuses the scan workspace: blk_count / blk_off for the per-block prefix, out_idx as the device queue
     hipLaunchKernelGGL(k_expired_count, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
                        (long long)prev_now, (long long)now, c->d_blk_count);
-    hipLaunchKernelGGL(k_tile_sums, dim3(1), dim3(256), 0, s, c->d_counts, 0, c->d_tile_sum, 0, c->d_blk_count,
-                       c->k1_blocks, c->d_blk_off, c->d_summary);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, c->d_blk_count, c->k1_blocks, c->d_blk_off,
+                       &c->d_summary->m);
     hipLaunchKernelGGL(k_expired_write, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
                        (long long)prev_now, (long long)now, c->d_blk_off, c->d_out_idx, c->cap_rows);
     PIE_HIP(c, hipGetLastError());
