@@ -75,6 +75,10 @@ int pie_ctx_set_stream(pie_ctx *ctx, void *hip_stream);
  * disc = index into DISCIPLINES (server/disciplineConfig.js:35).  Host arrays stay caller-owned. */
 int pie_load_columns(pie_ctx *ctx, const int64_t *start, const int64_t *end, const int32_t *user,
                      const int32_t *disc, size_t n, int32_t n_users);
+/* createSession (server/sessionStore.js:12-19): append k rows behind the resident ones (device capacity grows
+ * geometrically).  n_users may grow, never shrink. */
+int pie_append_rows(pie_ctx *ctx, const int64_t *start, const int64_t *end, const int32_t *user, const int32_t *disc,
+                    size_t k, int32_t n_users);
 /* Fill the table on the device with rows [row0, row0+n) of the deterministic synthetic corpus. */
 int pie_gen_synthetic(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
                       int32_t n_disc, uint32_t flags);
@@ -82,8 +86,10 @@ int pie_gen_synthetic(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0
 int pie_read_columns(pie_ctx *ctx, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, size_t n);
 /* touchSession (server/sessionStore.js:37-45): end[row] = new_end.  deleteSession (:47-53): new_end = PIE_END_NONE. */
 int pie_set_end(pie_ctx *ctx, const int32_t *rows, const int64_t *new_end, size_t k);
-/* deleteSessionsForUser (server/sessionStore.js:55-64): tombstone every row with user == u; *n_deleted out. */
-int pie_delete_user(pie_ctx *ctx, int32_t user, size_t *n_deleted);
+/* deleteSessionsForUser (server/sessionStore.js:55-64): tombstone every live row with user == u (strict match;
+ * unknown ids are a no-op like the falsy-id guard :56-58).  rows_out (may be NULL) receives the tombstoned row
+ * indices in ascending order so the host can drop their token-map entries; *n_deleted their number. */
+int pie_delete_user(pie_ctx *ctx, int32_t user, int32_t *rows_out, size_t cap, size_t *n_deleted);
 
 /* ---- discipline predicate table: replaces findDiscipline() lookups (server/disciplineConfig.js:88-97) -
  * bit d of mask = rows of discipline d are wanted; bits >= n_disc are ignored. n_disc <= 64. */

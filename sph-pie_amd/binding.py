@@ -44,7 +44,8 @@ _SIGS = [
     ("pie_gen_synthetic", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
     ("pie_read_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
     ("pie_set_end", C.c_int, [_P, _P, _P, C.c_size_t]),
-    ("pie_delete_user", C.c_int, [_P, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("pie_delete_user", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_append_rows", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_set_disciplines", C.c_int, [_P, C.c_uint64, C.c_int32]),
     ("pie_scan", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_scan_device", C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
@@ -150,10 +151,19 @@ class PieScan:
         rows, new_end = _col(rows, np.int32), _col(new_end, np.int64)
         self._check(self._lib.pie_set_end(self._ctx, _ptr(rows), _ptr(new_end), rows.shape[0]))
 
+    def append_rows(self, start, end, user, disc, n_users):
+        start, end = _col(start, np.int64), _col(end, np.int64)
+        user, disc = _col(user, np.int32), _col(disc, np.int32)
+        self._check(self._lib.pie_append_rows(self._ctx, _ptr(start), _ptr(end), _ptr(user), _ptr(disc), start.shape[0], int(n_users)))
+        self.n += start.shape[0]
+        self.n_users = int(n_users)
+
     def delete_user(self, user):
+        """-> ascending row indices that were tombstoned."""
         k = C.c_size_t(0)
-        self._check(self._lib.pie_delete_user(self._ctx, int(user), C.byref(k)))
-        return k.value
+        rows = np.empty(max(self.n, 1), np.int32)
+        self._check(self._lib.pie_delete_user(self._ctx, int(user), _ptr(rows), self.n, C.byref(k)))
+        return rows[: k.value].copy()
 
     def set_disciplines(self, mask, n_disc):
         self._check(self._lib.pie_set_disciplines(self._ctx, mask & (2 ** 64 - 1), int(n_disc)))

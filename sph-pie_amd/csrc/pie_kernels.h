@@ -627,21 +627,6 @@ __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, co
     if (t < k && (unsigned)rows[t] < (unsigned long long)n) end[rows[t]] = new_end[t];
 }
 
-// deleteSessionsForUser (/root/reference/server/sessionStore.js:55-64): strict user match, tombstone = never live
-__global__ __launch_bounds__(256) void k_delete_user(const int* __restrict__ user, long long* __restrict__ end, long long n,
-                                                     int target, unsigned long long* __restrict__ n_deleted)
-{
-    unsigned long long local = 0;
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
-        if (user[r] == target && end[r] != INT64_MIN) {
-            end[r] = INT64_MIN;
-            ++local;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_deleted, local);
-}
-
 __global__ __launch_bounds__(256) void k_fetch_rows(const int* __restrict__ idx, long long m, long long n,
                                                     const long long* __restrict__ start, const long long* __restrict__ end,
                                                     const int* __restrict__ user, const int* __restrict__ disc,
@@ -668,28 +653,44 @@ __global__ __launch_bounds__(256) void k_validate_users(const int* __restrict__ 
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
 }
 
-// ------------------------------------------------------------------------------------------------ expired queue ("next" row)
+// ------------------------------------------------------------------------------------------------ ordered row lists
 
-// change predicate prev_now < end <= now, order-preserving compaction in three steps:
-// per-block counts -> prefix (single block) -> ordered write.
-__global__ __launch_bounds__(256) void k_expired_count(const long long* __restrict__ end, long long n, long long rows_per_block,
-                                                       long long prev_now, long long now, int* __restrict__ blk_count)
+// Order-preserving compaction of the rows matching a one-column predicate, in three steps:
+// per-block counts -> prefix (k_block_prefix) -> ordered write.
+//   MODE 0  newly expired: prev_now < end <= now ("next" row of SURVEY.md §8f-1: dead per
+//           /root/reference/server/sessionStore.js:69 at `now`, not yet dead at `prev_now`)
+//   MODE 1  deleteSessionsForUser (/root/reference/server/sessionStore.js:55-64): user == target, strict
+//           match; the write step tombstones the row (end = INT64_MIN: never live again)
+template <int MODE>
+__device__ __forceinline__ bool list_match(const long long* __restrict__ end, const int* __restrict__ user, long long r,
+                                           long long a, long long b)
+{
+    if constexpr (MODE == 0) {
+        const long long e = end[r];
+        return e <= b && e > a;
+    } else {
+        return user[r] == (int)a && end[r] != INT64_MIN;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_list_count(const long long* __restrict__ end, const int* __restrict__ user, long long n,
+                                                    long long rows_per_block, long long a, long long b,
+                                                    int* __restrict__ blk_count)
 {
     __shared__ long long lds4[4];
     const long long c0 = (long long)blockIdx.x * rows_per_block;
     const long long c1 = min(n, c0 + rows_per_block);
     long long local = 0;
-    for (long long r = c0 + threadIdx.x; r < c1; r += blockDim.x) {
-        const long long e = end[r];
-        local += (e <= now && e > prev_now) ? 1 : 0;
-    }
+    for (long long r = c0 + threadIdx.x; r < c1; r += blockDim.x) local += list_match<MODE>(end, user, r, a, b) ? 1 : 0;
     local = block_sum_256(local, lds4);
     if (threadIdx.x == 0) blk_count[blockIdx.x] = (int)local;
 }
 
-__global__ __launch_bounds__(256) void k_expired_write(const long long* __restrict__ end, long long n, long long rows_per_block,
-                                                       long long prev_now, long long now, const long long* __restrict__ blk_off,
-                                                       int* __restrict__ queue, long long cap)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end, const int* __restrict__ user, long long n,
+                                                    long long rows_per_block, long long a, long long b,
+                                                    const long long* __restrict__ blk_off, int* __restrict__ queue, long long cap)
 {
     __shared__ int wcount[4];
     __shared__ long long carry_s;
@@ -700,18 +701,17 @@ __global__ __launch_bounds__(256) void k_expired_write(const long long* __restri
     __syncthreads();
     for (long long r0 = c0; r0 < c1; r0 += blockDim.x) {
         const long long r = r0 + threadIdx.x;
-        bool hit = false;
-        if (r < c1) {
-            const long long e = end[r];
-            hit = (e <= now && e > prev_now);
-        }
-        const unsigned long long b = __ballot(hit);
-        if (lane == 0) wcount[wave] = __popcll(b);
+        const bool hit = r < c1 && list_match<MODE>(end, user, r, a, b);
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(bal);
         __syncthreads();
         long long base = carry_s;
         for (int w = 0; w < wave; ++w) base += wcount[w];
-        const long long pos = base + prefix_in_ballot(b);
+        const long long pos = base + prefix_in_ballot(bal);
         if (hit && pos < cap) queue[pos] = (int)r;
+        if constexpr (MODE == 1) {
+            if (hit) end[r] = INT64_MIN;
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();

@@ -1,0 +1,518 @@
+/*
+ * pie_napi.c — raw N-API (no node-addon-api) shim over the C ABI of include/pie_scan.h.
+ *
+ * The addon holds no logic: it dlopen()s libpie_hip.so and forwards typed-array pointers (zero copy:
+ * BigInt64Array for the int64 columns, Int32Array for ids) to the pie_* entry points.  A non-zero status
+ * becomes a thrown JS Error carrying `.code` (the PIE_E_* value) and the library's error text — the same
+ * shape the route's 500 handler reads (/root/reference/server/index.js:526-536).  All calls are made from
+ * the JS main thread; scanAsync() runs the scan on the libuv pool (napi_create_async_work) so a long scan
+ * does not block the event loop, one in-flight scan per context.
+ *
+ * Build: gcc -shared -fPIC -I/usr/include/node -Iinclude pie_napi.c -ldl -o host/pie_napi.node
+ */
+#define NAPI_VERSION 6
+#include <node_api.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pie_scan.h"
+
+/* ---- the C ABI, resolved at open() ------------------------------------------------------------------ */
+#define PIE_SYMBOLS(X)                                                                                              \
+    X(int, pie_abi_version, (void))                                                                                 \
+    X(int, pie_device_count, (void))                                                                                \
+    X(int, pie_ctx_create, (int, pie_ctx **))                                                                       \
+    X(int, pie_ctx_destroy, (pie_ctx *))                                                                            \
+    X(const char *, pie_last_error, (const pie_ctx *))                                                              \
+    X(int, pie_load_columns, (pie_ctx *, const int64_t *, const int64_t *, const int32_t *, const int32_t *, size_t, int32_t)) \
+    X(int, pie_append_rows, (pie_ctx *, const int64_t *, const int64_t *, const int32_t *, const int32_t *, size_t, int32_t)) \
+    X(int, pie_gen_synthetic, (pie_ctx *, uint64_t, int64_t, int64_t, int64_t, int32_t, int32_t, uint32_t))         \
+    X(int, pie_read_columns, (pie_ctx *, int64_t *, int64_t *, int32_t *, int32_t *, size_t))                       \
+    X(int, pie_set_end, (pie_ctx *, const int32_t *, const int64_t *, size_t))                                      \
+    X(int, pie_delete_user, (pie_ctx *, int32_t, int32_t *, size_t, size_t *))                                      \
+    X(int, pie_set_disciplines, (pie_ctx *, uint64_t, int32_t))                                                     \
+    X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
+    X(int, pie_fetch_rows, (pie_ctx *, const int32_t *, size_t, int64_t *, int64_t *, int32_t *, int32_t *))        \
+    X(int, pie_expired_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
+    X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
+    X(int, pie_stats_get, (pie_ctx *, pie_stats *))                                                                 \
+    X(int, pie_stats_reset, (pie_ctx *))
+
+#define X(ret, name, args) static ret(*p_##name) args;
+PIE_SYMBOLS(X)
+#undef X
+static void *g_lib;
+
+#define CHECK(env, call)                                                 \
+    do {                                                                 \
+        if ((call) != napi_ok) {                                         \
+            napi_throw_error((env), NULL, "N-API call failed: " #call); \
+            return NULL;                                                 \
+        }                                                                \
+    } while (0)
+
+static napi_value throw_pie(napi_env env, pie_ctx *ctx, int rc)
+{
+    napi_value msg, err, code;
+    char buf[640];
+    snprintf(buf, sizeof buf, "pie_scan error %d: %s", rc, p_pie_last_error ? p_pie_last_error(ctx) : "library not open");
+    napi_create_string_utf8(env, buf, NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_create_int32(env, rc, &code);
+    napi_set_named_property(env, err, "code", code);
+    napi_throw(env, err);
+    return NULL;
+}
+
+static int need_lib(napi_env env)
+{
+    if (g_lib) return 1;
+    napi_throw_error(env, NULL, "libpie_hip.so is not open: call open(path) first (there is no CPU fallback)");
+    return 0;
+}
+
+/* Number (integer-valued double, exact to 2^53 — what Date.now() returns) or BigInt -> int64 */
+static int get_i64(napi_env env, napi_value v, int64_t *out)
+{
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_bigint) {
+        bool lossless;
+        return napi_get_value_bigint_int64(env, v, out, &lossless) == napi_ok;
+    }
+    if (t == napi_number) {
+        double d;
+        if (napi_get_value_double(env, v, &d) != napi_ok) return 0;
+        if (!(d == d) || d > 9.2e18 || d < -9.2e18) return 0; /* NaN / out of range: Number.isFinite guard */
+        *out = (int64_t)d;
+        return 1;
+    }
+    return 0;
+}
+
+static void *typed(napi_env env, napi_value v, napi_typedarray_type want, size_t *len)
+{
+    bool is = false;
+    napi_typedarray_type t;
+    void *data = NULL;
+    size_t n = 0;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return NULL;
+    if (napi_get_typedarray_info(env, v, &t, &n, &data, NULL, NULL) != napi_ok || t != want) return NULL;
+    if (len) *len = n;
+    return data ? data : (void *)(uintptr_t)16; /* zero-length arrays may report NULL */
+}
+
+static pie_ctx *get_ctx(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a pie context");
+        return NULL;
+    }
+    return (pie_ctx *)p;
+}
+
+#define ARGS(n)                                                          \
+    size_t argc = (n);                                                   \
+    napi_value argv[(n)];                                                \
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));    \
+    if (argc < (n)) {                                                    \
+        napi_throw_type_error(env, NULL, "too few arguments");           \
+        return NULL;                                                     \
+    }
+
+static napi_value js_int(napi_env env, int64_t v)
+{
+    napi_value out;
+    napi_create_int64(env, v, &out);
+    return out;
+}
+
+/* ---- open(path) -------------------------------------------------------------------------------------- */
+static napi_value fn_open(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    char path[4096];
+    size_t n = 0;
+    CHECK(env, napi_get_value_string_utf8(env, argv[0], path, sizeof path, &n));
+    if (!g_lib) {
+        void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) {
+            char buf[4400];
+            snprintf(buf, sizeof buf, "cannot load %s: %s (build it first; there is no CPU fallback)", path, dlerror());
+            napi_throw_error(env, NULL, buf);
+            return NULL;
+        }
+#define X(ret, name, args)                                                        \
+    p_##name = (ret(*) args)dlsym(lib, #name);                                    \
+    if (!p_##name) {                                                              \
+        napi_throw_error(env, NULL, "libpie_hip.so lacks symbol " #name);         \
+        dlclose(lib);                                                             \
+        return NULL;                                                              \
+    }
+        PIE_SYMBOLS(X)
+#undef X
+        g_lib = lib;
+    }
+    return js_int(env, p_pie_abi_version());
+}
+
+static napi_value fn_device_count(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    if (!need_lib(env)) return NULL;
+    return js_int(env, p_pie_device_count());
+}
+
+static napi_value fn_ctx_create(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    if (!need_lib(env)) return NULL;
+    int32_t dev = 0;
+    CHECK(env, napi_get_value_int32(env, argv[0], &dev));
+    pie_ctx *ctx = NULL;
+    int rc = p_pie_ctx_create(dev, &ctx);
+    if (rc) return throw_pie(env, NULL, rc);
+    napi_value ext;
+    CHECK(env, napi_create_external(env, ctx, NULL, NULL, &ext));
+    return ext;
+}
+
+static napi_value fn_ctx_destroy(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    p_pie_ctx_destroy(ctx);
+    return js_int(env, 0);
+}
+
+/* loadColumns(ctx, start, end, user, disc, nUsers) / appendRows(...) */
+static napi_value load_or_append(napi_env env, napi_callback_info info, int append)
+{
+    ARGS(6)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    size_t n0, n1, n2, n3;
+    int64_t *s = typed(env, argv[1], napi_bigint64_array, &n0), *e = typed(env, argv[2], napi_bigint64_array, &n1);
+    int32_t *u = typed(env, argv[3], napi_int32_array, &n2), *d = typed(env, argv[4], napi_int32_array, &n3);
+    int32_t n_users = 0;
+    if (!s || !e || !u || !d || n0 != n1 || n0 != n2 || n0 != n3) {
+        napi_throw_type_error(env, NULL, "columns must be BigInt64Array, BigInt64Array, Int32Array, Int32Array of equal length");
+        return NULL;
+    }
+    CHECK(env, napi_get_value_int32(env, argv[5], &n_users));
+    int rc = append ? p_pie_append_rows(ctx, s, e, u, d, n0, n_users) : p_pie_load_columns(ctx, s, e, u, d, n0, n_users);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)n0);
+}
+static napi_value fn_load_columns(napi_env env, napi_callback_info info) { return load_or_append(env, info, 0); }
+static napi_value fn_append_rows(napi_env env, napi_callback_info info) { return load_or_append(env, info, 1); }
+
+/* genSynthetic(ctx, seed(BigInt|Number), nTotal, row0, n, nUsers, nDisc, flags) */
+static napi_value fn_gen(napi_env env, napi_callback_info info)
+{
+    ARGS(8)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t seed, n_total, row0, n;
+    int32_t n_users, n_disc, flags;
+    if (!get_i64(env, argv[1], &seed) || !get_i64(env, argv[2], &n_total) || !get_i64(env, argv[3], &row0) ||
+        !get_i64(env, argv[4], &n)) {
+        napi_throw_type_error(env, NULL, "bad integer argument");
+        return NULL;
+    }
+    CHECK(env, napi_get_value_int32(env, argv[5], &n_users));
+    CHECK(env, napi_get_value_int32(env, argv[6], &n_disc));
+    CHECK(env, napi_get_value_int32(env, argv[7], &flags));
+    int rc = p_pie_gen_synthetic(ctx, (uint64_t)seed, n_total, row0, n, n_users, n_disc, (uint32_t)flags);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, n);
+}
+
+/* readColumns(ctx, start, end, user, disc) */
+static napi_value fn_read_columns(napi_env env, napi_callback_info info)
+{
+    ARGS(5)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    size_t n = 0;
+    int64_t *s = typed(env, argv[1], napi_bigint64_array, &n), *e = typed(env, argv[2], napi_bigint64_array, NULL);
+    int32_t *u = typed(env, argv[3], napi_int32_array, NULL), *d = typed(env, argv[4], napi_int32_array, NULL);
+    if (!s || !e || !u || !d) {
+        napi_throw_type_error(env, NULL, "bad output arrays");
+        return NULL;
+    }
+    int rc = p_pie_read_columns(ctx, s, e, u, d, n);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)n);
+}
+
+/* setEnd(ctx, rows Int32Array, newEnd BigInt64Array) */
+static napi_value fn_set_end(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    size_t k = 0, k2 = 0;
+    int32_t *rows = typed(env, argv[1], napi_int32_array, &k);
+    int64_t *ne = typed(env, argv[2], napi_bigint64_array, &k2);
+    if (!rows || !ne || k != k2) {
+        napi_throw_type_error(env, NULL, "setEnd(ctx, Int32Array rows, BigInt64Array newEnd)");
+        return NULL;
+    }
+    int rc = p_pie_set_end(ctx, rows, ne, k);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)k);
+}
+
+/* deleteUser(ctx, user, rowsOut Int32Array) -> number of rows tombstoned (rowsOut holds them, ascending) */
+static napi_value fn_delete_user(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t user = -1;
+    size_t cap = 0, k = 0;
+    CHECK(env, napi_get_value_int32(env, argv[1], &user));
+    int32_t *rows = typed(env, argv[2], napi_int32_array, &cap);
+    if (!rows) {
+        napi_throw_type_error(env, NULL, "deleteUser(ctx, user, Int32Array rowsOut)");
+        return NULL;
+    }
+    int rc = p_pie_delete_user(ctx, user, rows, cap, &k);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)k);
+}
+
+/* setDisciplines(ctx, mask BigInt|Number, nDisc) */
+static napi_value fn_set_disc(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint64_t mask = 0;
+    napi_valuetype t;
+    napi_typeof(env, argv[1], &t);
+    if (t == napi_bigint) {
+        bool lossless;
+        CHECK(env, napi_get_value_bigint_uint64(env, argv[1], &mask, &lossless));
+    } else {
+        int64_t v;
+        if (!get_i64(env, argv[1], &v)) {
+            napi_throw_type_error(env, NULL, "mask must be a BigInt or an integer Number");
+            return NULL;
+        }
+        mask = (uint64_t)v;
+    }
+    int32_t n_disc;
+    CHECK(env, napi_get_value_int32(env, argv[2], &n_disc));
+    int rc = p_pie_set_disciplines(ctx, mask, n_disc);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, 0);
+}
+
+/* scan(ctx, now, cutoff, counts Int32Array[U], offsets BigInt64Array[U+1], idx Int32Array[cap]) -> M */
+static napi_value fn_scan(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t now, cutoff;
+    if (!get_i64(env, argv[1], &now) || !get_i64(env, argv[2], &cutoff)) {
+        napi_throw_type_error(env, NULL, "now / cutoff must be finite integers (Number or BigInt)");
+        return NULL;
+    }
+    size_t cap = 0;
+    int32_t *counts = typed(env, argv[3], napi_int32_array, NULL);
+    int64_t *offsets = typed(env, argv[4], napi_bigint64_array, NULL);
+    int32_t *idx = typed(env, argv[5], napi_int32_array, &cap);
+    if (!counts || !offsets || !idx) {
+        napi_throw_type_error(env, NULL, "scan(ctx, now, cutoff, Int32Array, BigInt64Array, Int32Array)");
+        return NULL;
+    }
+    size_t m = 0;
+    int rc = p_pie_scan(ctx, now, cutoff, counts, offsets, idx, cap, &m);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)m);
+}
+
+/* scanAsync(ctx, now, cutoff, counts, offsets, idx, callback(err, m)) — same scan on the libuv pool */
+typedef struct {
+    napi_async_work work;
+    napi_ref cb, keep[3];
+    pie_ctx *ctx;
+    int64_t now, cutoff;
+    int32_t *counts, *idx;
+    int64_t *offsets;
+    size_t cap, m;
+    int rc;
+    char err[600];
+} scan_job;
+
+static void scan_exec(napi_env env, void *data)
+{
+    (void)env;
+    scan_job *j = (scan_job *)data;
+    j->rc = p_pie_scan(j->ctx, j->now, j->cutoff, j->counts, j->offsets, j->idx, j->cap, &j->m);
+    if (j->rc) snprintf(j->err, sizeof j->err, "pie_scan error %d: %s", j->rc, p_pie_last_error(j->ctx));
+}
+
+static void scan_done(napi_env env, napi_status status, void *data)
+{
+    scan_job *j = (scan_job *)data;
+    napi_value cb, global, args[2], res;
+    napi_get_reference_value(env, j->cb, &cb);
+    napi_get_global(env, &global);
+    if (status != napi_ok || j->rc) {
+        napi_value msg, code;
+        napi_create_string_utf8(env, j->rc ? j->err : "scan cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &args[0]);
+        napi_create_int32(env, j->rc, &code);
+        napi_set_named_property(env, args[0], "code", code);
+        napi_get_undefined(env, &args[1]);
+    } else {
+        napi_get_null(env, &args[0]);
+        napi_create_int64(env, (int64_t)j->m, &args[1]);
+    }
+    napi_call_function(env, global, cb, 2, args, &res);
+    napi_delete_reference(env, j->cb);
+    for (int i = 0; i < 3; ++i) napi_delete_reference(env, j->keep[i]);
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+static napi_value fn_scan_async(napi_env env, napi_callback_info info)
+{
+    ARGS(7)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    scan_job *j = (scan_job *)calloc(1, sizeof *j);
+    if (!j) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    j->ctx = ctx;
+    j->counts = typed(env, argv[3], napi_int32_array, NULL);
+    j->offsets = typed(env, argv[4], napi_bigint64_array, NULL);
+    j->idx = typed(env, argv[5], napi_int32_array, &j->cap);
+    if (!get_i64(env, argv[1], &j->now) || !get_i64(env, argv[2], &j->cutoff) || !j->counts || !j->offsets || !j->idx) {
+        free(j);
+        napi_throw_type_error(env, NULL, "scanAsync(ctx, now, cutoff, Int32Array, BigInt64Array, Int32Array, cb)");
+        return NULL;
+    }
+    napi_value name;
+    napi_create_string_utf8(env, "pie_scan", NAPI_AUTO_LENGTH, &name);
+    napi_create_reference(env, argv[6], 1, &j->cb);
+    for (int i = 0; i < 3; ++i) napi_create_reference(env, argv[3 + i], 1, &j->keep[i]); /* keep buffers alive */
+    if (napi_create_async_work(env, NULL, name, scan_exec, scan_done, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        free(j);
+        napi_throw_error(env, NULL, "cannot queue async work");
+        return NULL;
+    }
+    return js_int(env, 0);
+}
+
+/* fetchRows(ctx, idx Int32Array, m, start, end, user, disc) */
+static napi_value fn_fetch_rows(napi_env env, napi_callback_info info)
+{
+    ARGS(7)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    size_t cap = 0, c1 = 0;
+    int32_t *idx = typed(env, argv[1], napi_int32_array, &cap);
+    int64_t m = 0;
+    if (!idx || !get_i64(env, argv[2], &m) || m < 0 || (size_t)m > cap) {
+        napi_throw_type_error(env, NULL, "fetchRows(ctx, Int32Array idx, m <= idx.length, ...)");
+        return NULL;
+    }
+    int64_t *s = typed(env, argv[3], napi_bigint64_array, &c1), *e = typed(env, argv[4], napi_bigint64_array, NULL);
+    int32_t *u = typed(env, argv[5], napi_int32_array, NULL), *d = typed(env, argv[6], napi_int32_array, NULL);
+    if (!s || !e || !u || !d || c1 < (size_t)m) {
+        napi_throw_type_error(env, NULL, "bad output arrays");
+        return NULL;
+    }
+    int rc = p_pie_fetch_rows(ctx, idx, (size_t)m, s, e, u, d);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, m);
+}
+
+/* expiredQueue(ctx, prevNow, now, queue Int32Array) -> q */
+static napi_value fn_expired_queue(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t prev, now;
+    size_t cap = 0, q = 0;
+    int32_t *queue = typed(env, argv[3], napi_int32_array, &cap);
+    if (!get_i64(env, argv[1], &prev) || !get_i64(env, argv[2], &now) || !queue) {
+        napi_throw_type_error(env, NULL, "expiredQueue(ctx, prevNow, now, Int32Array)");
+        return NULL;
+    }
+    int rc = p_pie_expired_queue(ctx, prev, now, queue, cap, &q);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)q);
+}
+
+/* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
+static napi_value fn_stats(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    pie_stats st;
+    memset(&st, 0, sizeof st);
+    st.struct_size = sizeof st;
+    int rc = p_pie_stats_get(ctx, &st);
+    if (rc) return throw_pie(env, ctx, rc);
+    napi_value o, v;
+    napi_create_object(env, &o);
+#define PUT(name, val)                      \
+    napi_create_double(env, (double)(val), &v); \
+    napi_set_named_property(env, o, name, v);
+    PUT("rows", st.rows) PUT("users", st.users) PUT("selected", st.selected) PUT("algBytes", st.alg_bytes)
+    PUT("k1MsSum", st.k1_ms_sum) PUT("scanMsSum", st.scan_ms_sum) PUT("nProfiled", st.n_profiled)
+    PUT("maxBucket", st.max_bucket)
+#undef PUT
+    return o;
+}
+
+static napi_value fn_set_profiling(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    bool on = false;
+    CHECK(env, napi_get_value_bool(env, argv[1], &on));
+    p_pie_set_profiling(ctx, on ? 1 : 0);
+    if (!on) p_pie_stats_reset(ctx);
+    return js_int(env, 0);
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    static const struct {
+        const char *name;
+        napi_callback fn;
+    } table[] = {
+        {"open", fn_open}, {"deviceCount", fn_device_count}, {"ctxCreate", fn_ctx_create}, {"ctxDestroy", fn_ctx_destroy},
+        {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
+        {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
+        {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
+        {"expiredQueue", fn_expired_queue}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
+        napi_value fn;
+        if (napi_create_function(env, table[i].name, NAPI_AUTO_LENGTH, table[i].fn, NULL, &fn) != napi_ok) return NULL;
+        napi_set_named_property(env, exports, table[i].name, fn);
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

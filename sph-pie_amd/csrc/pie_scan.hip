@@ -137,17 +137,39 @@ void plan_k1(pie_ctx* c)
     if (c->k1_blocks < 1) c->k1_blocks = 1;
 }
 
-int ensure_capacity(pie_ctx* c, long long n, int n_users)
+// Make room for n rows / n_users users.  keep_rows > 0: the first keep_rows rows of the resident columns survive
+// a re-allocation (append path; capacity grows geometrically so appends are amortised O(1) per row).
+int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 0)
 {
     if (n < 0 || n >= (1LL << 31)) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31)", n);
     if (n_users < 1) return fail(c, PIE_E_INVAL, "n_users must be >= 1 (got %d)", n_users);
-    const long long rows = n > 0 ? n : 1;
+    long long rows = n > 0 ? n : 1;
     if (rows > c->cap_rows || n_users > c->cap_users) {
+        int users = n_users;
+        if (keep_rows > 0) { // geometric growth for the append path
+            if (rows > c->cap_rows) rows = rows > 2 * c->cap_rows ? rows : 2 * c->cap_rows;
+            else rows = c->cap_rows;
+            if (n_users > c->cap_users) users = n_users > 2 * c->cap_users ? n_users : 2 * c->cap_users;
+            else users = c->cap_users;
+            if (rows >= (1LL << 31)) rows = (1LL << 31) - 1;
+        }
+        long long *old_s = c->d_start, *old_e = c->d_end;
+        int *old_u = c->d_user, *old_d = c->d_disc;
+        if (keep_rows > 0) { c->d_start = c->d_end = nullptr; c->d_user = c->d_disc = nullptr; }
+        else old_s = old_e = nullptr, old_u = old_d = nullptr;
         free_table(c);
         PIE_HIP(c, hipMalloc(&c->d_start, rows * 8));
         PIE_HIP(c, hipMalloc(&c->d_end, rows * 8));
         PIE_HIP(c, hipMalloc(&c->d_user, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_disc, rows * 4));
+        if (keep_rows > 0 && old_s) {
+            PIE_HIP(c, hipMemcpyAsync(c->d_start, old_s, keep_rows * 8, hipMemcpyDeviceToDevice, c->stream));
+            PIE_HIP(c, hipMemcpyAsync(c->d_end, old_e, keep_rows * 8, hipMemcpyDeviceToDevice, c->stream));
+            PIE_HIP(c, hipMemcpyAsync(c->d_user, old_u, keep_rows * 4, hipMemcpyDeviceToDevice, c->stream));
+            PIE_HIP(c, hipMemcpyAsync(c->d_disc, old_d, keep_rows * 4, hipMemcpyDeviceToDevice, c->stream));
+            PIE_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(old_s); (void)hipFree(old_e); (void)hipFree(old_u); (void)hipFree(old_d);
+        }
         PIE_HIP(c, hipMalloc(&c->d_sel, rows * sizeof(SelRec)));
         PIE_HIP(c, hipMalloc(&c->d_sel_rank, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_bkt_start, rows * 8));
@@ -156,14 +178,14 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users)
         const long long max_blocks = rows / (kUnitRows * 2 * kK1Waves) + 2;
         PIE_HIP(c, hipMalloc(&c->d_blk_count, max_blocks * 4));
         PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks + 1) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_counts2[0], (size_t)n_users * 4 + 32));
-        PIE_HIP(c, hipMalloc(&c->d_counts2[1], (size_t)n_users * 4 + 32));
-        PIE_HIP(c, hipMalloc(&c->d_offsets, ((size_t)n_users + 1) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_tile_sum, ((size_t)n_users / kScanTile + 2) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_seg_list, ((size_t)n_users + rows / kSegMax + 16) * sizeof(Segment)));
-        PIE_HIP(c, hipMalloc(&c->d_big_list, ((size_t)n_users + 16) * 4));
+        PIE_HIP(c, hipMalloc(&c->d_counts2[0], (size_t)users * 4 + 32));
+        PIE_HIP(c, hipMalloc(&c->d_counts2[1], (size_t)users * 4 + 32));
+        PIE_HIP(c, hipMalloc(&c->d_offsets, ((size_t)users + 1) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_tile_sum, ((size_t)users / kScanTile + 2) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
+        PIE_HIP(c, hipMalloc(&c->d_big_list, ((size_t)users + 16) * 4));
         c->cap_rows = rows;
-        c->cap_users = n_users;
+        c->cap_users = users;
     }
     c->n = n;
     c->n_users = n_users;
@@ -172,20 +194,20 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users)
     c->cur = 0;
     c->d_counts = c->d_counts2[0];
     // both ping-pong buffers start clean; afterwards every scan's K2b clears the next scan's buffers
-    PIE_HIP(c, hipMemsetAsync(c->d_counts2[0], 0, (size_t)n_users * 4, c->stream));
-    PIE_HIP(c, hipMemsetAsync(c->d_counts2[1], 0, (size_t)n_users * 4, c->stream));
+    PIE_HIP(c, hipMemsetAsync(c->d_counts2[0], 0, (size_t)c->cap_users * 4, c->stream));
+    PIE_HIP(c, hipMemsetAsync(c->d_counts2[1], 0, (size_t)c->cap_users * 4, c->stream));
     PIE_HIP(c, hipMemsetAsync(c->d_sum2[0], 0, sizeof(Summary), c->stream));
     PIE_HIP(c, hipMemsetAsync(c->d_sum2[1], 0, sizeof(Summary), c->stream));
     plan_k1(c);
     return PIE_OK;
 }
 
-int validate_users(pie_ctx* c)
+int validate_users(pie_ctx* c, long long row0 = 0)
 {
-    if (c->n == 0) return PIE_OK;
+    if (c->n - row0 <= 0) return PIE_OK;
     PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), c->stream));
     const int grid = c->n_cus * 8;
-    hipLaunchKernelGGL(k_validate_users, dim3(grid), dim3(256), 0, c->stream, c->d_user, c->n, c->n_users,
+    hipLaunchKernelGGL(k_validate_users, dim3(grid), dim3(256), 0, c->stream, c->d_user + row0, c->n - row0, c->n_users,
                        &c->d_summary->bad_rows);
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
@@ -321,6 +343,36 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
     return PIE_OK;
 }
 
+// ordered list of the rows matching a one-column predicate (expired queue / user match), through the
+// scan workspace: blk_count + blk_off for the per-block prefix, out_idx as the device-side list
+template <int MODE>
+int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap, size_t* k_out)
+{
+    if (k_out) *k_out = 0;
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n == 0) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(k_list_count<MODE>, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n,
+                       c->rows_per_block, a, b, c->d_blk_count);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, c->d_blk_count, c->k1_blocks, c->d_blk_off,
+                       &c->d_summary->m);
+    hipLaunchKernelGGL(k_list_write<MODE>, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n,
+                       c->rows_per_block, a, b, c->d_blk_off, c->d_out_idx, c->cap_rows);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    c->have_scan = false;
+    const size_t k = (size_t)c->h_summary->m;
+    if (k_out) *k_out = k;
+    if (out && k > cap) return fail(c, PIE_E_CAPACITY, "list cap %zu < %zu", cap, k);
+    if (out && k) {
+        PIE_HIP(c, hipMemcpyAsync(out, c->d_out_idx, k * 4, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    }
+    return PIE_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -418,6 +470,27 @@ int pie_load_columns(pie_ctx* c, const int64_t* start, const int64_t* end, const
     return PIE_OK;
 }
 
+int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const int32_t* user, const int32_t* disc,
+                    size_t k, int32_t n_users)
+{
+    if (!c) return PIE_E_INVAL;
+    if (k > 0 && (!start || !end || !user || !disc)) return fail(c, PIE_E_INVAL, "NULL column pointer");
+    if (n_users < c->n_users) return fail(c, PIE_E_INVAL, "n_users may only grow (%d < %d)", n_users, c->n_users);
+    PIE_HIP(c, hipSetDevice(c->device));
+    const long long old_n = c->n;
+    int rc = ensure_capacity(c, old_n + (long long)k, n_users, old_n > 0 ? old_n : 1);
+    if (rc) return rc;
+    if (k > 0) {
+        PIE_HIP(c, hipMemcpyAsync(c->d_start + old_n, start, k * 8, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_end + old_n, end, k * 8, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_user + old_n, user, k * 4, hipMemcpyHostToDevice, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(c->d_disc + old_n, disc, k * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = validate_users(c, old_n);
+    if (rc) { c->n = old_n; plan_k1(c); return rc; }
+    return PIE_OK;
+}
+
 int pie_gen_synthetic(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
                       int32_t n_disc, uint32_t flags)
 {
@@ -476,21 +549,13 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     return PIE_OK;
 }
 
-int pie_delete_user(pie_ctx* c, int32_t user, size_t* n_deleted)
+int pie_delete_user(pie_ctx* c, int32_t user, int32_t* rows_out, size_t cap, size_t* n_deleted)
 {
     if (!c) return PIE_E_INVAL;
     if (n_deleted) *n_deleted = 0;
     if (c->n == 0 || user < 0 || user >= c->n_users) return PIE_OK; // unknown / falsy id: no-op (sessionStore.js:56-58)
-    PIE_HIP(c, hipSetDevice(c->device));
-    PIE_HIP(c, hipMemsetAsync(c->d_summary, 0, sizeof(Summary), c->stream));
-    hipLaunchKernelGGL(k_delete_user, dim3(c->n_cus * 8), dim3(256), 0, c->stream, c->d_user, c->d_end, c->n, user,
-                       &c->d_summary->q);
-    PIE_HIP(c, hipGetLastError());
-    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, c->stream));
-    PIE_HIP(c, hipStreamSynchronize(c->stream));
-    if (n_deleted) *n_deleted = (size_t)c->h_summary->q;
-    c->have_scan = false;
-    return PIE_OK;
+    // the rows are tombstoned even when rows_out is too small to list them (PIE_E_CAPACITY then tells the count)
+    return run_row_list<1>(c, (long long)user, 0, rows_out, cap, n_deleted);
 }
 
 int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)
@@ -593,30 +658,7 @@ int pie_fetch_rows(pie_ctx* c, const int32_t* idx, size_t m, int64_t* start, int
 int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_out, size_t cap, size_t* q_out)
 {
     if (!c) return PIE_E_INVAL;
-    if (q_out) *q_out = 0;
-    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
-    if (c->n == 0) return PIE_OK;
-    PIE_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    // reuses the scan workspace: blk_count / blk_off for the per-block prefix, out_idx as the device queue
-    hipLaunchKernelGGL(k_expired_count, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
-                       (long long)prev_now, (long long)now, c->d_blk_count);
-    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, c->d_blk_count, c->k1_blocks, c->d_blk_off,
-                       &c->d_summary->m);
-    hipLaunchKernelGGL(k_expired_write, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->n, c->rows_per_block,
-                       (long long)prev_now, (long long)now, c->d_blk_off, c->d_out_idx, c->cap_rows);
-    PIE_HIP(c, hipGetLastError());
-    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
-    PIE_HIP(c, hipStreamSynchronize(s));
-    c->have_scan = false;
-    const size_t q = (size_t)c->h_summary->m;
-    if (q_out) *q_out = q;
-    if (queue_out && q > cap) return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, q);
-    if (queue_out && q) {
-        PIE_HIP(c, hipMemcpyAsync(queue_out, c->d_out_idx, q * 4, hipMemcpyDeviceToHost, s));
-        PIE_HIP(c, hipStreamSynchronize(s));
-    }
-    return PIE_OK;
+    return run_row_list<0>(c, (long long)prev_now, (long long)now, queue_out, cap, q_out);
 }
 
 int pie_set_profiling(pie_ctx* c, int enabled)

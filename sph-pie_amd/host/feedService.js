@@ -1,0 +1,59 @@
+'use strict';
+// Batched feed aggregation: ONE device scan produces the feeds of every user; a request reads its slice.
+// Replaces the reference's per-request chain syncCalendarEvents -> listCalendarEvents
+// (/root/reference/server/storage/sqlProvider.js:274-298) for the session-derived events of this build:
+// the window predicate (:284), the ordering (:276) and the per-user grouping run on the GPU; the host only
+// serialises the selected rows into the event objects of calendarFeed.js:66-79.
+const calendarFeed = require('./calendarFeed');
+const disciplineConfig = require('./disciplineConfig');
+
+function createFeedService(store, options){
+  const opts = options || {};
+  const monthsBack = opts.monthsBack === undefined ? 2 : opts.monthsBack;
+
+  function scan(query){
+    const q = query || {};
+    const now = q.now === undefined ? Date.now() : q.now;
+    const cutoff = q.cutoff === undefined ? calendarFeed.getCalendarCutoffTimestamp(monthsBack, now) : q.cutoff;
+    const res = store.scanFeeds({now, cutoff, disciplines: q.disciplines});
+    return {now, cutoff, res};
+  }
+
+  function eventsFromSlice(res, lo, hi){
+    const idx = res.idx.subarray(lo, hi);
+    const cols = store.fetchRows(idx);
+    const events = [];
+    for(let i = 0; i < idx.length; i++){
+      const d = disciplineConfig.DISCIPLINES[cols.disc[i]];
+      events.push(calendarFeed.eventFromRow(idx[i], cols.start[i], cols.end[i], d ? d.name : 'Session'));
+    }
+    return events;          // already (startTs asc, row asc): the device ordered the bucket
+  }
+
+  // events of one user, from a fresh scan
+  function eventsForUser(userId, query){
+    const u = store.userIndexOf(userId);
+    if(u < 0){
+      return [];
+    }
+    const {res} = scan(query);
+    return eventsFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]));
+  }
+
+  // feeds of every user from ONE scan: Map userId -> events
+  function allFeeds(query){
+    const {res} = scan(query);
+    const feeds = new Map();
+    for(let u = 0; u < res.userIds.length; u++){
+      const lo = Number(res.offsets[u]), hi = Number(res.offsets[u + 1]);
+      if(hi > lo){
+        feeds.set(res.userIds[u], eventsFromSlice(res, lo, hi));
+      }
+    }
+    return feeds;
+  }
+
+  return {scan, eventsForUser, allFeeds};
+}
+
+module.exports = {createFeedService};

@@ -1,0 +1,242 @@
+'use strict';
+// Device-backed session store with the reference module's interface
+// (/root/reference/server/sessionStore.js:75-84: createSession, getSession, touchSession, deleteSession,
+// deleteSessionsForUser, purgeExpiredSessions, SESSION_TTL_MS, SESSION_COOKIE_NAME — synchronous, never
+// throwing on a miss, null for "no session").
+//
+// What moved to the GPU: the session records live as SoA columns in HBM (int64 start/end, int32 user/disc);
+// the two full-table loops of the reference — deleteSessionsForUser (:55-64) and purgeExpiredSessions
+// (:66-73) — are device scans that hand back the affected row indices; the per-user feed aggregation is
+// scanFeeds().  What stays on the host: the token -> row map (O(1) lookups, sha256) and a mirror of each row's
+// {userId, createdAt, expiresAt}, kept exact by the row lists the device scans return, so getSession never
+// touches the device.  Mutations are batched and flushed to the device before any scan.
+const crypto = require('crypto');
+const disciplineConfig = require('./disciplineConfig');
+const pieNative = require('./pieNative');
+
+const SESSION_TTL_MS = 12 * 60 * 60 * 1000;
+const SESSION_COOKIE_NAME = 'mt_session';
+const END_NONE = -(2n ** 63n);          // PIE_END_NONE: tombstone, never live
+
+const sha256hex = text => crypto.createHash('sha256').update(text).digest('hex');
+
+function createStore(options){
+  const opts = options || {};
+  const native = pieNative.load();                 // throws if the addon / HIP library is missing
+  const ctx = native.ctxCreate(opts.device === undefined ? 0 : opts.device);   // throws without a GPU
+
+  const rowOfToken = new Map();                    // tokenHash -> row
+  const rows = [];                                 // row -> {tokenHash|null, userId, createdAt, expiresAt}
+  const userIndex = new Map();                     // userId string -> dense int32
+  const userIds = [];                              // dense int32 -> userId string
+  let uploaded = 0;                                // rows [0, uploaded) are resident on the device
+  let pendingEnd = new Map();                      // row -> BigInt new end (touch / delete of resident rows)
+  let lastPurge = null;
+  let out = null;                                  // scan output arrays, sized lazily
+
+  function denseUser(userId){
+    let u = userIndex.get(userId);
+    if(u === undefined){
+      u = userIds.length;
+      userIndex.set(userId, u);
+      userIds.push(userId);
+    }
+    return u;
+  }
+
+  // push host-side mutations to the device: appended rows first, then end updates, so a row that was created
+  // and touched in the same batch ends with the touched value
+  function flush(){
+    const k = rows.length - uploaded;
+    if(k > 0 || uploaded === 0){
+      const s = new BigInt64Array(k), e = new BigInt64Array(k);
+      const u = new Int32Array(k), d = new Int32Array(k);
+      for(let i = 0; i < k; i++){
+        const r = rows[uploaded + i];
+        s[i] = BigInt(r.createdAt);
+        e[i] = r.tokenHash === null ? END_NONE : BigInt(r.expiresAt);
+        u[i] = r.user;
+        d[i] = r.disc;
+        pendingEnd.delete(uploaded + i);
+      }
+      const nUsers = Math.max(userIds.length, 1);
+      if(uploaded === 0){
+        native.loadColumns(ctx, s, e, u, d, nUsers);
+      }else{
+        native.appendRows(ctx, s, e, u, d, nUsers);
+      }
+      uploaded = rows.length;
+    }
+    if(pendingEnd.size > 0){
+      const r = new Int32Array(pendingEnd.size), v = new BigInt64Array(pendingEnd.size);
+      let i = 0;
+      pendingEnd.forEach((val, row) => { r[i] = row; v[i] = val; i++; });
+      native.setEnd(ctx, r, v);
+      pendingEnd = new Map();
+    }
+  }
+
+  function forget(row){
+    const r = rows[row];
+    if(r.tokenHash !== null){
+      rowOfToken.delete(r.tokenHash);
+      r.tokenHash = null;
+    }
+  }
+
+  function tombstone(row){
+    forget(row);
+    if(row < uploaded){
+      pendingEnd.set(row, END_NONE);
+    }
+  }
+
+  // createSession(userId[, disciplineId]) -> {token, expiresAt}.  The second argument is [DERIVED] (the reference
+  // record has no discipline field): an id of disciplineConfig.DISCIPLINES, default = the default discipline.
+  function createSession(userId, disciplineId){
+    const token = crypto.randomBytes(48).toString('hex');
+    const tokenHash = sha256hex(token);
+    const now = Date.now();
+    const expiresAt = now + SESSION_TTL_MS;
+    let disc = disciplineId === undefined
+      ? (disciplineConfig.DEFAULT_DISCIPLINE ? disciplineConfig.disciplineIndex(disciplineConfig.DEFAULT_DISCIPLINE.id) : 0)
+      : disciplineConfig.disciplineIndex(disciplineId);
+    rows.push({tokenHash, userId, user: denseUser(userId), disc, createdAt: now, expiresAt});
+    rowOfToken.set(tokenHash, rows.length - 1);
+    return {token, expiresAt};
+  }
+
+  function getSession(token){
+    if(!token){
+      return null;
+    }
+    const tokenHash = sha256hex(token);
+    const row = rowOfToken.get(tokenHash);
+    if(row === undefined){
+      return null;
+    }
+    const r = rows[row];
+    if(r.expiresAt <= Date.now()){                  // dead iff expiresAt <= now (:30)
+      tombstone(row);
+      return null;
+    }
+    return {userId: r.userId, createdAt: r.createdAt, expiresAt: r.expiresAt, tokenHash};
+  }
+
+  function touchSession(token){
+    const existing = getSession(token);
+    if(!existing){
+      return null;
+    }
+    const row = rowOfToken.get(existing.tokenHash);
+    const newExpires = Date.now() + SESSION_TTL_MS;
+    rows[row].expiresAt = newExpires;
+    if(row < uploaded){
+      pendingEnd.set(row, BigInt(newExpires));
+    }
+    return {userId: existing.userId, expiresAt: newExpires};
+  }
+
+  function deleteSession(token){
+    if(!token){
+      return;
+    }
+    const row = rowOfToken.get(sha256hex(token));
+    if(row !== undefined){
+      tombstone(row);
+    }
+  }
+
+  // full-table scan on the device (user == x, strict); the returned row list keeps the host map exact
+  function deleteSessionsForUser(userId){
+    if(!userId){
+      return;
+    }
+    const u = userIndex.get(userId);
+    if(u === undefined){
+      return;
+    }
+    flush();
+    const list = new Int32Array(Math.max(rows.length, 1));
+    const k = native.deleteUser(ctx, u, list);
+    for(let i = 0; i < k; i++){
+      forget(list[i]);
+    }
+  }
+
+  // full-table scan on the device; `now` is sampled once (:67).  The device returns the rows that died since the
+  // previous purge (prev < end <= now); rows that died earlier were already dropped from the map.
+  function purgeExpiredSessions(){
+    const now = Date.now();
+    flush();
+    const list = new Int32Array(Math.max(rows.length, 1));
+    const prev = lastPurge === null ? END_NONE : BigInt(lastPurge);
+    const k = native.expiredQueue(ctx, prev, now, list);
+    for(let i = 0; i < k; i++){
+      forget(list[i]);
+    }
+    lastPurge = now;
+    return undefined;
+  }
+
+  // ---- the batched feed scan (replaces the per-request loop) ------------------------------------------
+  // -> {counts Int32Array[U], offsets BigInt64Array[U+1], idx Int32Array[M], m, userIds}
+  function scanFeeds(query){
+    const q = query || {};
+    const now = q.now === undefined ? Date.now() : q.now;
+    const cutoff = q.cutoff === undefined ? END_NONE : q.cutoff;
+    flush();
+    const U = Math.max(userIds.length, 1);
+    if(out === null || out.counts.length !== U || out.idx.length < rows.length){
+      out = {counts: new Int32Array(U), offsets: new BigInt64Array(U + 1), idx: new Int32Array(Math.max(rows.length, 1))};
+    }
+    native.setDisciplines(ctx, disciplineConfig.disciplineMask(q.disciplines), disciplineConfig.DISCIPLINES.length);
+    const m = native.scan(ctx, now, cutoff, out.counts, out.offsets, out.idx);
+    return {counts: out.counts, offsets: out.offsets, idx: out.idx.subarray(0, m), m, userIds};
+  }
+
+  function fetchRows(idx){
+    const m = idx.length;
+    const s = new BigInt64Array(m), e = new BigInt64Array(m), u = new Int32Array(m), d = new Int32Array(m);
+    if(m > 0){
+      native.fetchRows(ctx, idx, m, s, e, u, d);
+    }
+    return {start: s, end: e, user: u, disc: d};
+  }
+
+  function close(){
+    native.ctxDestroy(ctx);
+  }
+
+  return {
+    createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
+    SESSION_TTL_MS, SESSION_COOKIE_NAME,
+    scanFeeds, fetchRows, flush, close,
+    userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
+    size: () => rowOfToken.size,
+    native, ctx
+  };
+}
+
+// module-level singleton with the reference's export names; created on first use so that requiring this file
+// on a machine without a GPU fails at the first call, with the library's own error text.
+let shared = null;
+function store(){
+  if(shared === null){
+    shared = createStore();
+  }
+  return shared;
+}
+
+module.exports = {
+  createSession: (userId, disciplineId) => store().createSession(userId, disciplineId),
+  getSession: token => store().getSession(token),
+  touchSession: token => store().touchSession(token),
+  deleteSession: token => store().deleteSession(token),
+  deleteSessionsForUser: userId => store().deleteSessionsForUser(userId),
+  purgeExpiredSessions: () => store().purgeExpiredSessions(),
+  SESSION_TTL_MS,
+  SESSION_COOKIE_NAME,
+  createStore,
+  sharedStore: store
+};

@@ -1,0 +1,105 @@
+'use strict';
+// CPU checks of the Node host mirror (no GPU): run with TZ=UTC.  Vectors: tests/golden/hand_derived_h1_h5.json.
+process.env.TZ = 'UTC';
+const assert = require('assert');
+const path = require('path');
+const fs = require('fs');
+
+const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', '..', 'tests', 'golden', 'hand_derived_h1_h5.json'), 'utf8'));
+const dc = require('../disciplineConfig');
+const cf = require('../calendarFeed');
+const {readSessionToken} = require('../server');
+let checks = 0;
+const ok = (cond, msg) => { assert.ok(cond, msg); checks++; };
+const eq = (a, b, msg) => { assert.deepStrictEqual(a, b, msg); checks++; };
+
+// ---- H5 discipline table
+const g = golden.disciplines;
+eq(dc.DISCIPLINES.map(d => d.id), g.ids);
+eq(dc.ROLE_LEVELS, g.roles);
+eq(dc.DEFAULT_DISCIPLINE.id, g.default);
+eq(dc.DISCIPLINES.filter(d => d.forms).map(d => d.id), g.forms);
+for(const [id, want] of g.lookups){
+  eq(dc.disciplineIndex(id), want === null ? -1 : want, 'lookup ' + id);
+  eq(dc.findDiscipline(id), want === null ? null : dc.DISCIPLINES[want]);
+}
+eq(dc.findDiscipline(42), null);
+for(const [key, want] of g.role_keys){ eq(dc.parseRoleKey(key), want, 'parseRoleKey ' + key); }
+for(const [role, want] of g.normalize){ eq(dc.normalizeRole(role), want, 'normalizeRole ' + role); }
+eq(dc.normalizeRole(7), null);
+eq(dc.listRoleKeys().length, 21);
+eq(dc.getRoleKey('Drones', 'LEAD'), 'drones.lead');
+eq(dc.getRoleKey('drones', 'boss'), null);
+ok(dc.roleMatchesLevel('drones.lead', 'lead') && !dc.roleMatchesLevel('drones.lead', 'crew'));
+ok(dc.roleMatchesDiscipline('video.crew', 'video') && !dc.roleMatchesDiscipline('video.crew', 'audio'));
+eq(dc.getDisplayName('admin'), 'Admin');
+eq(dc.getDisplayName('show-control.operator'), 'Show Control Operator');
+eq(dc.getDisplayName('bogus'), 'bogus');
+eq(dc.disciplineMask('drones'), 16n);
+eq(dc.disciplineMask('*'), 127n);
+eq(dc.disciplineMask(['audio', 'nope', ' Broadcast ']), 65n);
+
+// ---- cutoff (calendarFeed.js:33-38) under TZ=UTC, incl. month-overflow cases
+for(const c of golden.cutoff_cases_tz_utc){
+  eq(cf.getCalendarCutoffTimestamp(c.months_back, c.now_ms), c.expect_ms, 'cutoff ' + c.now_iso);
+  eq(new Date(cf.getCalendarCutoffTimestamp(c.months_back, c.now_ms)).toISOString().replace('.000Z', 'Z'), c.expect_iso);
+}
+eq(cf.getCalendarCutoffTimestamp(undefined, golden.cutoff_cases_tz_utc[0].now_ms), golden.cutoff_cases_tz_utc[0].expect_ms);
+ok(cf.getCalendarCutoffTimestamp() <= Date.now());
+
+// ---- title metadata (calendarFeed.js:15-31)
+eq(cf.parseCalendarMetadata('Eagles #12 load-in'), {eventName: 'EAGLES', showNumber: 12, color: '#3b82f6'});
+eq(cf.parseCalendarMetadata('woz show 7 rehearsal 9'), {eventName: 'WOZ', showNumber: 7, color: '#22c55e'});
+eq(cf.parseCalendarMetadata('Zac Brown Band: Love and Fear # 3'), {eventName: 'ZAC', showNumber: 3, color: '#ef4444'});
+eq(cf.parseCalendarMetadata('2024 tour'), {eventName: '', showNumber: 2024, color: ''});
+eq(cf.parseCalendarMetadata(''), {eventName: '', showNumber: null, color: ''});
+eq(cf.parseCalendarMetadata(), {eventName: '', showNumber: null, color: ''});
+
+// ---- H2 window + H3 de-dup (sqlProvider.js:284-295)
+const w = golden.window_cases[0];
+const toNum = v => (v === 'NaN' ? NaN : v === 'Infinity' ? Infinity : v);
+const evs = w.startTs.map((s, i) => ({id: 'e' + i, startTs: toNum(s)}));
+eq(cf.windowAndDedup(evs, w.cutoff).map(e => Number(e.id.slice(1))), w.kept_rows);
+const dd = golden.dedup_cases[0];
+eq(cf.windowAndDedup(dd.ids.map((id, i) => ({id, startTs: 10, row: i})), 0).map(e => e.row), dd.kept_rows);
+eq(cf.windowAndDedup(null, 0), []);
+
+// ---- ordering (sqlProvider.js:276), ties keep input order
+eq(cf.orderEvents([{startTs: 5, k: 0}, {startTs: 1, k: 1}, {startTs: 5, k: 2}, {startTs: 1, k: 3}]).map(e => e.k), [1, 3, 0, 2]);
+
+// ---- event object shape (calendarFeed.js:66-79)
+const ev = cf.eventFromRow(42, 1700000000000n, 1700043200000n, 'Drones');
+eq(Object.keys(ev), ['id', 'title', 'description', 'location', 'start', 'end', 'startTs', 'endTs', 'allDay', 'eventName', 'showNumber', 'color']);
+eq(ev.start, '2023-11-14T22:13:20.000Z');
+eq([ev.startTs, ev.endTs, ev.allDay, ev.eventName, ev.showNumber, ev.id], [1700000000000, 1700043200000, false, 'DRONES', 42, 'session-42']);
+const noEnd = cf.eventFromRow(1, 1699920000000n, cf.END_NONE, 'Audio');
+eq([noEnd.end, noEnd.endTs, noEnd.allDay], ['', null, true]);
+
+// ---- fetchCalendarFeed never rejects
+(async () => {
+  eq(await cf.fetchCalendarFeed(''), []);
+  eq(await cf.fetchCalendarFeed(42), []);
+  eq(await cf.fetchCalendarFeed('https://example.invalid/feed.ics'), []);
+  eq(await cf.fetchCalendarFeed({events: async () => [{id: 'x'}]}), [{id: 'x'}]);
+  const quiet = console.error; console.error = () => {};
+  eq(await cf.fetchCalendarFeed({events: async () => { throw new Error('boom'); }}), []);
+  console.error = quiet;
+
+  // ---- cookie parsing (index.js:594-610)
+  eq(readSessionToken({headers: {cookie: 'a=b; mt_session=abc%20d; z=1'}}, 'mt_session'), 'abc d');
+  eq(readSessionToken({headers: {cookie: 'xmt_session=1'}}, 'mt_session'), null);
+  eq(readSessionToken({headers: {}}, 'mt_session'), null);
+
+  // ---- the addon loads and refuses to work without a GPU (no CPU fallback)
+  const pieNative = require('../pieNative');
+  if(fs.existsSync(pieNative.ADDON) && fs.existsSync(pieNative.LIB)){
+    const native = pieNative.load();
+    ok(typeof native.scan === 'function' && typeof native.scanAsync === 'function');
+    if(native.deviceCount() === 0){
+      assert.throws(() => native.ctxCreate(0), e => e.code === -2 && /no CPU path/.test(e.message));
+      assert.throws(() => require('../sessionStore').createSession('u1'), /no CPU path/);
+      checks += 2;
+    }
+  }
+  console.log('host cpu_test ok: ' + checks + ' checks');
+})().catch(err => { console.error(err); process.exit(1); });

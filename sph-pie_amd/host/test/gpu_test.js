@@ -1,0 +1,183 @@
+'use strict';
+// GPU checks of the Node host over the N-API addon: run on an MI355X box with TZ=UTC.
+//  1. sessionStore (device-backed) replays the G1-G4 fixture recorded from the real reference module
+//     (tests/golden/sessionstore_g1_g4.json) and must answer exactly as the reference did.
+//  2. scanFeeds() on the synthetic corpus equals the reference-faithful JS restatement (oracle/ref_faithful.js).
+//  3. GET /api/calendar end to end: cookie auth, 401 / 403 / 423, {events} sorted by startTs.
+process.env.TZ = 'UTC';
+const assert = require('assert');
+const fs = require('fs');
+const http = require('http');
+const path = require('path');
+
+const REPO = path.join(__dirname, '..', '..', '..');
+const golden = JSON.parse(fs.readFileSync(path.join(REPO, 'tests', 'golden', 'sessionstore_g1_g4.json'), 'utf8'));
+const refJs = require(path.join(REPO, 'oracle', 'ref_faithful.js'));     // the checker, never the product
+const {createStore} = require('../sessionStore');
+const {createFeedService} = require('../feedService');
+const {createServer} = require('../server');
+const dc = require('../disciplineConfig');
+
+let checks = 0;
+const eq = (a, b, msg) => { assert.deepStrictEqual(a, b, msg); checks++; };
+const realNow = Date.now;
+let fakeNow = 0;
+Date.now = () => fakeNow;
+
+function replayCorpus(){
+  const store = createStore();
+  const tokens = golden.sessions.map(r => {
+    fakeNow = r.createdAt;
+    const made = store.createSession(r.user);
+    assert.strictEqual(made.expiresAt, r.expiresAt);
+    return made.token;
+  });
+  return {store, tokens};
+}
+
+function get(port, cookie){
+  return new Promise((resolve, reject) => {
+    const req = http.request({host: '127.0.0.1', port, path: '/api/calendar', method: 'GET', headers: cookie ? {cookie} : {}}, res => {
+      let body = '';
+      res.on('data', c => { body += c; });
+      res.on('end', () => resolve({status: res.statusCode, body: JSON.parse(body)}));
+    });
+    req.on('error', reject);
+    req.end();
+  });
+}
+
+(async () => {
+  // ---- 1. G1 liveness
+  for(const c of golden.G1){
+    const {store, tokens} = replayCorpus();
+    fakeNow = c.now;
+    eq(tokens.map(t => (store.getSession(t) !== null ? 1 : 0)), c.live, 'G1 now=' + c.now);
+    // and the same answer from the device: live rows == rows selected by a scan with no window
+    const res = store.scanFeeds({now: c.now});
+    const live = new Array(tokens.length).fill(0);
+    res.idx.forEach(i => { live[i] = 1; });
+    eq(live, c.live, 'G1 device now=' + c.now);
+    store.close();
+  }
+  { const {store} = replayCorpus(); eq([store.getSession(''), store.getSession(null), store.getSession(undefined)], [null, null, null]); store.close(); }
+  // ---- G2 purge (device expired-queue scan keeps the host map exact)
+  for(const c of golden.G2){
+    const {store, tokens} = replayCorpus();
+    fakeNow = c.now;
+    eq(store.purgeExpiredSessions(), undefined);
+    eq(store.size(), c.survivors.length);
+    eq(tokens.map((t, i) => (store.getSession(t) !== null ? i : -1)).filter(i => i >= 0), c.survivors, 'G2');
+    store.close();
+  }
+  // ---- G3 deleteSessionsForUser (device user-match scan), incl. unknown and falsy ids
+  for(const c of golden.G3){
+    const {store, tokens} = replayCorpus();
+    fakeNow = c.observe_now;
+    eq(store.deleteSessionsForUser(c.user), undefined);
+    eq(tokens.map((t, i) => (store.getSession(t) !== null ? i : -1)).filter(i => i >= 0), c.survivors, 'G3 ' + c.user);
+    const res = store.scanFeeds({now: c.observe_now});
+    eq(Array.from(res.idx).sort((a, b) => a - b), c.survivors, 'G3 device ' + c.user);
+    store.close();
+  }
+  // ---- G4 touch
+  {
+    const {store, tokens} = replayCorpus();
+    for(const t of golden.G4){
+      fakeNow = t.now;
+      const got = store.touchSession(tokens[t.row]);
+      eq(got, t.returned, 'G4 row ' + t.row);
+      if(t.after){
+        const s = store.getSession(tokens[t.row]);
+        eq({userId: s.userId, createdAt: s.createdAt, expiresAt: s.expiresAt}, t.after);
+        store.flush();
+        eq(Number(store.fetchRows(Int32Array.of(t.row)).end[0]), t.after.expiresAt, 'device end after touch');
+      }
+    }
+    store.close();
+  }
+
+  // ---- 2. scanFeeds == reference-faithful JS on the synthetic corpus (config 1 shape: 1k sessions / 10 users / 3 disciplines)
+  {
+    const n = 1000, U = 10, D = 3, T0 = 1700000000000;
+    const rows = refJs.genCorpus(0x5EED5EEDn, n, U, D);
+    const store = createStore();
+    const native = store.native;
+    native.genSynthetic(store.ctx, 0x5EED5EEDn, n, 0, n, U, D, 0);
+    const s = new BigInt64Array(n), e = new BigInt64Array(n), u = new Int32Array(n), d = new Int32Array(n);
+    native.readColumns(store.ctx, s, e, u, d);
+    eq(Array.from(s, Number), rows.map(r => r.start)); eq(Array.from(e, Number), rows.map(r => r.end));
+    eq(Array.from(u), rows.map(r => r.user)); eq(Array.from(d), rows.map(r => r.disc));
+    const sessions = refJs.buildMap(rows);
+    for(const [now, cutoff, mask] of [[T0 - 6 * 3600 * 1000, T0 - 61 * 86400 * 1000, 5n], [T0 - 200 * 86400 * 1000, T0 - 61 * 86400 * 1000, 7n], [0, 0, 2n]]){
+      native.setDisciplines(store.ctx, mask, D);
+      const counts = new Int32Array(U), offsets = new BigInt64Array(U + 1), idx = new Int32Array(n);
+      const m = native.scan(store.ctx, now, cutoff, counts, offsets, idx);
+      const want = refJs.scanFeeds(sessions, U, now, cutoff, x => x >= 0 && x < D && ((mask >> BigInt(x)) & 1n) === 1n);
+      eq(Array.from(counts), want.map(f => f.length));
+      eq(Array.from(idx.subarray(0, m)), [].concat.apply([], want.map(f => f.map(x => x.row))));
+      eq(Number(offsets[U]), m);
+      // async variant gives the same bytes without blocking the event loop
+      const c2 = new Int32Array(U), o2 = new BigInt64Array(U + 1), i2 = new Int32Array(n);
+      const m2 = await new Promise((res, rej) => native.scanAsync(store.ctx, now, cutoff, c2, o2, i2, (err, mm) => (err ? rej(err) : res(mm))));
+      eq([m2, Array.from(c2), Array.from(i2.subarray(0, m2))], [m, Array.from(counts), Array.from(idx.subarray(0, m))]);
+    }
+    assert.throws(() => native.scan(store.ctx, NaN, 0, new Int32Array(U), new BigInt64Array(U + 1), new Int32Array(n)), /finite integers/);
+    checks++;
+    store.close();
+  }
+
+  // ---- 3. HTTP seam
+  {
+    const store = createStore();
+    const users = new Map([
+      ['u-lead', {id: 'u-lead', roles: ['drones.lead']}], ['u-crew', {id: 'u-crew', roles: [' Drones.Crew ']}],
+      ['u-audio', {id: 'u-audio', roles: ['audio.lead']}], ['u-admin', {id: 'u-admin', roles: ['admin']}],
+      ['u-reset', {id: 'u-reset', roles: ['drones.lead'], needsPasswordReset: true}]
+    ]);
+    const base = 1750000000000;
+    const cookies = {};
+    let t = base;
+    const mk = (uid, disc) => { fakeNow = t; t += 1000; return store.createSession(uid, disc).token; };
+    cookies['u-lead'] = mk('u-lead', 'drones');
+    mk('u-lead', 'audio'); mk('u-lead', 'drones'); mk('u-crew', 'video');
+    fakeNow = t - 1000; mk('u-lead', 'lighting'); t += 1000;                 // equal createdAt as the previous u-lead row? no: distinct rows, tie test below
+    cookies['u-crew'] = mk('u-crew', 'drones'); cookies['u-audio'] = mk('u-audio', 'audio');
+    cookies['u-admin'] = mk('u-admin', 'drones'); cookies['u-reset'] = mk('u-reset', 'drones');
+    const ghost = mk('u-ghost', 'drones');
+    fakeNow = t + 5000;
+    const feeds = createFeedService(store);
+    const server = createServer({store, feeds, findUserById: id => users.get(id) || null});
+    await new Promise(r => server.listen(0, '127.0.0.1', r));
+    const port = server.address().port;
+    const ck = tok => 'theme=dark; ' + store.SESSION_COOKIE_NAME + '=' + tok;
+    eq(await get(port, null), {status: 401, body: {error: 'Authentication required'}});
+    eq(await get(port, ck('deadbeef')), {status: 401, body: {error: 'Authentication required'}});
+    eq(await get(port, ck(ghost)), {status: 401, body: {error: 'Authentication required'}});
+    eq(await get(port, ck(cookies['u-audio'])), {status: 403, body: {error: 'Insufficient permissions'}});
+    eq(await get(port, ck(cookies['u-reset'])), {status: 423, body: {error: 'Password reset required'}});
+    const lead = await get(port, ck(cookies['u-lead']));
+    eq(lead.status, 200);
+    eq(lead.body.events.length, 4);
+    eq(lead.body.events.map(e => e.startTs), lead.body.events.map(e => e.startTs).slice().sort((a, b) => a - b));
+    eq(Object.keys(lead.body.events[0]), ['id', 'title', 'description', 'location', 'start', 'end', 'startTs', 'endTs', 'allDay', 'eventName', 'showNumber', 'color']);
+    eq(lead.body.events.map(e => e.eventName), ['DRONES', 'AUDIO', 'DRONES', 'LIGHTING']);
+    eq(lead.body.events[0].endTs - lead.body.events[0].startTs, store.SESSION_TTL_MS);
+    eq((await get(port, ck(cookies['u-crew']))).body.events.length, 2);
+    eq((await get(port, ck(cookies['u-admin']))).body.events.length, 1);
+    // expiry: 12 h later every session is dead -> 401; the device agrees (no live rows)
+    fakeNow = t + store.SESSION_TTL_MS + 10000;
+    eq((await get(port, ck(cookies['u-lead']))).status, 401);
+    eq(store.scanFeeds({now: fakeNow}).m, 0);
+    // a device failure surfaces as the reference's 500 shape
+    const quiet = console.error; console.error = () => {};
+    const broken = createServer({store: Object.assign({}, store, {getSession: () => ({userId: 'u-lead'})}),
+      feeds: {eventsForUser: () => { throw new Error('device lost'); }}, findUserById: id => users.get(id)});
+    await new Promise(r => broken.listen(0, '127.0.0.1', r));
+    eq(await get(broken.address().port, ck('x')), {status: 500, body: {error: 'Internal server error', detail: 'device lost'}});
+    console.error = quiet;
+    server.close(); broken.close(); store.close();
+  }
+  Date.now = realNow;
+  console.log('host gpu_test ok: ' + checks + ' checks');
+})().catch(err => { console.error(err); process.exit(1); });

@@ -56,52 +56,56 @@ class HipShardBackend:
 
 
 class ShardedFeeds:
-    """Per-rank driver: scan the local shard, all-gather counts and row lists, build global offsets."""
+    """Per-rank driver: scan the local shard, all-gather counts and row lists, build global offsets.
+
+    `backend.scan(now, cutoff, cap)` -> (counts[U_local] int32, payload[1+cap] int32 with payload[0] = M, M) as
+    tensors on `backend.device` (the GPU for nccl/RCCL, the CPU for gloo)."""
 
     def __init__(self, backend, rank, world, n_users_local, group=None, cap=None):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
         self.n_users_local = int(n_users_local)
-        self.u_pad = None  # counts are padded to the largest shard's user count (fixed-size gather)
+        self.device = torch.device(getattr(backend, "device", "cpu"))
+        # counts are padded to the largest shard's user count so the gather has one fixed size
+        self.u_pad = self._all_max(self.n_users_local)
         self.cap = cap  # capacity of one rank's row list in the payload gather; negotiated on first use
 
-    def _negotiate_cap(self, m, device):
-        t = torch.tensor([m], dtype=torch.int64, device=device)
+    def _all_max(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        need = int(t.item())
+        return int(t.item())
+
+    @staticmethod
+    def _grow(need):
         return max(1024, int(need * 1.25) + 64)
 
     def scan_and_gather(self, now, cutoff):
-        """-> dict(counts [world, U_pad] int32, lengths [world] , rows [world, cap] int32, offsets [world*U_pad+1] int64).
-        Feed of local user u of rank r = rows[r, off[r,u] : off[r,u+1]] with off = per-rank exclusive prefix."""
+        """-> dict(counts [world, U_pad] int32, lengths [world] int32, rows [world, cap] int32,
+        offsets [world*U_pad+1] int64).  Feed of local user u of rank r = rows[r, off[u] : off[u+1]] with
+        off = exclusive prefix of counts[r]."""
         if self.cap is None:
-            counts, payload, m = self.backend.scan(now, cutoff, 1024)
-            self.cap = self._negotiate_cap(m, counts.device)
-        if self.u_pad is None:
-            t = torch.tensor([self.n_users_local], dtype=torch.int64, device=self.backend.scan(now, cutoff, self.cap)[0].device)
-            if self.world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            self.u_pad = int(t.item())
+            _, _, m = self.backend.scan(now, cutoff, 0)
+            self.cap = self._grow(self._all_max(m))
         while True:
             counts, payload, m = self.backend.scan(now, cutoff, self.cap)
             if counts.numel() < self.u_pad:
                 counts = torch.cat([counts, counts.new_zeros(self.u_pad - counts.numel())])
             if self.world == 1:
-                g_counts, g_payload = counts.unsqueeze(0), payload.unsqueeze(0)
+                g_counts, g_payload = counts, payload
             else:
-                g_counts = torch.empty((self.world, counts.numel()), dtype=counts.dtype, device=counts.device)
-                g_payload = torch.empty((self.world, payload.numel()), dtype=payload.dtype, device=payload.device)
+                g_counts = torch.empty(self.world * counts.numel(), dtype=counts.dtype, device=counts.device)
+                g_payload = torch.empty(self.world * payload.numel(), dtype=payload.dtype, device=payload.device)
                 dist.all_gather_into_tensor(g_counts, counts, group=self.group)
                 dist.all_gather_into_tensor(g_payload, payload, group=self.group)
+            g_counts = g_counts.view(self.world, -1)
+            g_payload = g_payload.view(self.world, -1)
             lengths = g_payload[:, 0]
-            if self._fits(lengths):
+            # one tiny D2H per step (world ints); every rank sees the same gathered lengths, so every rank
+            # takes the same branch
+            need = int(lengths.max().item())
+            if need <= self.cap:
                 break
-            # every rank sees the same gathered lengths, so every rank takes this branch together
-            self.cap = max(1024, int(int(lengths.max().item()) * 1.25) + 64)
+            self.cap = self._grow(need)
         offsets = torch.zeros(g_counts.numel() + 1, dtype=torch.int64, device=g_counts.device)
         torch.cumsum(g_counts.reshape(-1), 0, out=offsets[1:])
         return {"counts": g_counts, "lengths": lengths, "rows": g_payload[:, 1:], "offsets": offsets}
-
-    def _fits(self, lengths):
-        # one tiny D2H per step (world ints); it is the step's completion point anyway
-        return bool((lengths <= self.cap).all().item())

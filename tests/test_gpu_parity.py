@@ -63,7 +63,8 @@ def test_golden_sessionstore_vectors(gpu_ctx, oracle):
         deleted = gpu_ctx.delete_user(k)
         _, _, idx = gpu_ctx.scan(case["observe_now"], INT64_MIN)
         assert sorted(idx.tolist()) == case["survivors"]
-        assert deleted == len(s) - len(case["survivors"])
+        assert deleted.tolist() == sorted(set(range(len(s))) - set(case["survivors"]))
+        assert gpu_ctx.delete_user(k).size == 0   # second call finds nothing left
     gpu_ctx.load_columns(s, e, u, d, len(users))
     for t in g["G4"]:
         if t["returned"] is None:
@@ -157,6 +158,24 @@ def test_idx_capacity_error(gpu_ctx, pie, oracle):
     with pytest.raises(pie.PieError) as ei:
         gpu_ctx.scan(INT64_MIN, INT64_MIN, idx_cap=10)
     assert ei.value.code == pie.binding.PIE_E_CAPACITY
+
+
+def test_append_rows_equals_bulk_load(gpu_ctx, oracle):
+    """createSession path: appending in ragged batches gives the same table (and feeds) as one bulk load."""
+    n, U = 50000, 300
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    now, cutoff, mask = spec_query(oracle)
+    cuts = [0, 1, 2, 65, 4096, 4097, 20000, n]
+    gpu_ctx.load_columns(s[:0], e[:0], u[:0], d[:0], 1)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        gpu_ctx.append_rows(s[a:b], e[a:b], u[a:b], d[a:b], max(int(u[:b].max()) + 1, 1))
+    assert gpu_ctx.n == n
+    for a, b in zip(gpu_ctx.read_columns(), (s, e, u, d)):
+        assert np.array_equal(a, b)
+    gpu_ctx.set_disciplines(mask, 32)
+    got = gpu_ctx.scan(INT64_MIN, INT64_MIN)
+    want = oracle.scan(s, e, u, d, gpu_ctx.n_users, INT64_MIN, INT64_MIN, mask & 0xFFFFFFFF)
+    assert_same(got, want)
 
 
 def test_expired_queue_parity(gpu_ctx, oracle):

@@ -1,0 +1,95 @@
+"""CPU, world_size 2, gloo: the multi-GPU path (user-hash partition -> per-rank scan -> all-gather of counts and
+row lists -> global feeds).  The per-rank scan is injected here (the CPU oracle stands in for the GPU, as the
+checker the tests are allowed to use); on a GPU box the same ShardedFeeds code runs over HipShardBackend."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+T0, DAY = 1700000000000, 86400 * 1000
+INT64_MIN = -(2 ** 63)
+
+
+class OracleBackend:
+    """Test stand-in for HipShardBackend: same contract, CPU tensors."""
+
+    device = "cpu"
+
+    def __init__(self, oracle, shard, mask):
+        self.o, self.sh, self.mask = oracle, shard, mask
+
+    def scan(self, now, cutoff, cap):
+        c, off, idx = self.o.scan(self.sh["start"], self.sh["end"], self.sh["user"], self.sh["disc"], self.sh["n_users"],
+                                  now, cutoff, self.mask)
+        payload = torch.zeros(cap + 1, dtype=torch.int32)
+        m = idx.size
+        payload[0] = m
+        k = min(m, cap)
+        payload[1:1 + k] = torch.from_numpy(idx[:k])
+        return torch.from_numpy(c), payload, m
+
+
+def _worker(rank, world, port, tmp, n, U):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_py
+    import sph_pie_amd  # noqa: F401
+    from sph_pie_amd.shard import ShardedFeeds, partition_by_user_hash
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cols = oracle_py.gen(0x5EED5EED, n, 0, n, U, 32, 1)
+        shards = partition_by_user_hash(*cols, U, world)
+        sh = shards[rank]
+        mask = 0x55555555
+        feeds = ShardedFeeds(OracleBackend(oracle_py, sh, mask), rank, world, sh["n_users"])
+        for now, cutoff in [(T0 - 6 * 3600 * 1000, T0 - 61 * DAY), (INT64_MIN, INT64_MIN), (T0 - 100 * DAY, T0 - 61 * DAY)]:
+            out = feeds.scan_and_gather(now, cutoff)
+            # rebuild global feeds from the gathered buffers and compare with the oracle on the WHOLE table
+            wc, wo, wi = oracle_py.scan(*cols, U, now, cutoff, mask)
+            got_counts = np.zeros(U, np.int32)
+            got_feeds = {}
+            for r in range(world):
+                cnt = out["counts"][r].numpy()
+                rows = out["rows"][r].numpy()[: int(out["lengths"][r])]
+                off = np.concatenate([[0], np.cumsum(cnt)])
+                for lu, gu in enumerate(shards[r]["users"]):
+                    got_counts[gu] = cnt[lu]
+                    got_feeds[int(gu)] = shards[r]["rows"][rows[off[lu]:off[lu + 1]]]
+                assert cnt[len(shards[r]["users"]):].sum() == 0   # padding users stay empty
+            assert np.array_equal(got_counts, wc)
+            for gu in range(U):
+                assert np.array_equal(got_feeds.get(gu, np.zeros(0, np.int64)), wi[wo[gu]:wo[gu + 1]]), (rank, gu)
+            assert int(out["offsets"][-1]) == wi.size
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,U", [(20000, 37), (3000, 5)])
+def test_sharded_feeds_world2_gloo(tmp_path, oracle, n, U):
+    port = 29500 + (os.getpid() % 2000) + (n % 7)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), n, U), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_partition_is_a_partition(pie, oracle):
+    from sph_pie_amd.shard import partition_by_user_hash
+    n, U = 5000, 41
+    cols = oracle.gen(0x5EED5EED, n, 0, n, U, 7, 0)
+    for world in (1, 2, 4, 8):
+        shards = partition_by_user_hash(*cols, U, world)
+        rows = np.concatenate([s["rows"] for s in shards])
+        assert np.array_equal(np.sort(rows), np.arange(n))
+        users = np.concatenate([s["users"] for s in shards])
+        assert np.array_equal(np.sort(users), np.arange(U))
+        for r, s in enumerate(shards):
+            assert all(pie.shard_of(int(g), world) == r for g in s["users"])
+            assert np.array_equal(s["users"][s["user"]], cols[2][s["rows"]])  # local -> global user round trip
