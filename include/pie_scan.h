@@ -57,6 +57,9 @@ typedef struct pie_stats {
     uint32_t n_segments;   /* block-sorted segments of the last scan */
     uint32_t n_big;        /* buckets that needed the multi-pass merge in the last scan */
     uint32_t k1_blocks;    /* grid of the scan kernel */
+    uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first) */
+    uint32_t reserved;
+    uint64_t live;         /* rows with end > now seen by the last scan */
 } pie_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------- */

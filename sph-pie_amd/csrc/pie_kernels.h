@@ -40,6 +40,7 @@ struct Summary {
     unsigned int max_count;     // largest bucket
     unsigned int bad_rows;      // rows whose user id fell outside [0, U): never selected, reported
     unsigned long long q;       // expired-queue length (pie_expired_queue)
+    unsigned long long live;    // rows with end > now seen by K1 (drives the choice of K1 variant for the next scan)
 };
 
 constexpr int kWave = 64;
@@ -178,15 +179,18 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, unsigned int* __restrict__ bad_rows)
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
     __shared__ int blk_cursor;
+    __shared__ int blk_live;
     constexpr int kTile = kUnitRows * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) blk_cursor = 0;
+    unsigned int* bad_rows = &summary->bad_rows;
+    int nlive = 0; // wave-uniform count of rows with end > now
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; }
     __syncthreads();
 
     const long long c0 = (long long)blockIdx.x * rows_per_block;
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
             for (int j = 0; j < UNROLL; ++j) {
                 p[2 * j] = row_selected(s[j].x, e[j].x, d[j].x, now, cutoff, mask);
                 p[2 * j + 1] = row_selected(s[j].y, e[j].y, d[j].y, now, cutoff, mask);
+                nlive += __popcll(__ballot(e[j].x > now)) + __popcll(__ballot(e[j].y > now));
                 if constexpr (LATE_U) {
                     const long long r = t + j * kUnitRows + 2 * lane;
                     u[j].x = 0;
@@ -254,9 +259,11 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
                 bool sel_row = false;
                 long long sv = 0;
                 int uv = 0, rk = 0;
+                const long long ev = r < t1 ? end[r] : INT64_MIN;
+                nlive += __popcll(__ballot(ev > now));
                 if (r < t1) {
                     sv = start[r];
-                    sel_row = row_selected(sv, end[r], disc[r], now, cutoff, mask);
+                    sel_row = row_selected(sv, ev, disc[r], now, cutoff, mask);
                     if (sel_row) {
                         uv = user[r];
                         if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[uv], 1);
@@ -268,8 +275,113 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
         }
     }
     if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
     __syncthreads();
-    if (threadIdx.x == 0) blk_count[blockIdx.x] = blk_cursor;
+    if (threadIdx.x == 0) {
+        blk_count[blockIdx.x] = blk_cursor;
+        if (blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+    }
+}
+
+// K1, liveness-first form.  In a session store almost every row is expired (12 h TTL, months of history), so
+// `end > now` is by far the most selective conjunct.  This form streams ONLY the `end` column (8 B/row), keeps
+// the indices of live rows in a per-wave LDS ring, and whenever 64 of them are queued evaluates the rest of the
+// predicate for those rows with all 64 lanes busy: start/disc/user are gathered for live rows only (late
+// materialisation of three columns).  Output is identical to k_scan_compact; the host picks the form from the
+// live fraction the previous scan observed.
+constexpr int kLiveRing = 128;
+
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
+    const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
+    const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
+    unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
+{
+    __shared__ SelRec stage[kK1Waves][kStage];
+    __shared__ int stage_rank[kK1Waves][kStage];
+    __shared__ int live_ring[kK1Waves][kLiveRing];
+    __shared__ int blk_cursor;
+    __shared__ int blk_live;
+    constexpr int kTile = kUnitRows * UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; }
+    __syncthreads();
+
+    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    long long c1 = c0 + rows_per_block;
+    if (c1 > n) c1 = n;
+    SelRec* out = sel + c0;
+    int* out_rank = sel_rank + c0;
+    WaveStage st;
+    st.ring = stage[wave];
+    st.ring_rank = stage_rank[wave];
+    st.head = 0;
+    st.fill = 0;
+    int* lring = live_ring[wave];
+    int lhead = 0, lfill = 0, nlive = 0; // wave-uniform
+
+    // evaluate the rest of the predicate for `cnt` queued live rows (cnt <= 64), one row per lane
+    auto drain = [&](int cnt) {
+        bool p = false;
+        long long sv = 0;
+        int row = 0, uv = 0, rk = 0;
+        if (lane < cnt) {
+            row = lring[(lhead + lane) & (kLiveRing - 1)];
+            sv = start[row];
+            const int dv = disc[row];
+            p = (sv >= cutoff) & ((unsigned)dv < 64u) & (((mask >> (dv & 63)) & 1ull) != 0);
+            if (p) {
+                uv = user[row];
+                if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[uv], 1);
+                else { atomicAdd(&summary->bad_rows, 1u); p = false; }
+            }
+        }
+        lhead = (lhead + cnt) & (kLiveRing - 1);
+        lfill -= cnt;
+        stage_rows(p, sv, row, uv, rk, st, out, out_rank, &blk_cursor, lane);
+    };
+    auto push_live = [&](bool live, int row) {
+        const unsigned long long b = __ballot(live);
+        if (b == 0) return;
+        if (live) lring[(lhead + lfill + prefix_in_ballot(b)) & (kLiveRing - 1)] = row;
+        const int c = __popcll(b);
+        lfill += c;
+        nlive += c;
+        __builtin_amdgcn_wave_barrier();
+        if (lfill >= kWave) drain(kWave);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
+        if (t + kTile <= c1) {
+            ll2_t e[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                e[j] = stream_load<NT>(reinterpret_cast<const ll2_t*>(end + t + j * kUnitRows + 2 * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int r = (int)(t + j * kUnitRows + 2 * lane);
+                push_live(e[j].x > now, r);
+                push_live(e[j].y > now, r + 1);
+            }
+        } else {
+            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
+            for (long long r0 = t; r0 < t1; r0 += kWave) {
+                const long long r = r0 + lane;
+                push_live(r < t1 && end[r] > now, (int)r);
+            }
+        }
+    }
+    if (lfill > 0) drain(lfill);
+    if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_count[blockIdx.x] = blk_cursor;
+        if (blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K2 offsets
@@ -432,6 +544,7 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
         summary_next->max_count = 0;
         summary_next->bad_rows = 0;
         summary_next->q = 0;
+        summary_next->live = 0;
     }
 }
 

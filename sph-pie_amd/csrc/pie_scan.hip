@@ -45,14 +45,20 @@ struct pie_ctx {
     int n_disc = 64;
 
     // scan workspace
-    int k1_blocks = 0;
+    int k1_blocks = 0;            // plan in use by the last / current scan
     long long rows_per_block = 0;
+    int plan_blocks[2] = {0, 0};  // [0] streaming form, [1] liveness-first form
+    long long plan_rows[2] = {0, 0};
     int n_tiles = 0;
     int* d_counts2[2] = {nullptr, nullptr}; // ping-pong: K2b of scan i clears the buffer of scan i+1
     int* d_counts = nullptr;                 // buffer holding the last scan's counts
     int cur = 0;
     int* d_sel_rank = nullptr;
-    int k1_variant = 0x03; // nontemporal loads + late user materialisation (measured best, profiles/)
+    int k1_variant = 0x03;    // streaming form: nontemporal loads + late user materialisation
+    int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
+    bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
+    int last_variant = 0;
+    double live_frac = -1;    // live fraction seen by the previous scan of this table (-1: none yet)
     long long* d_offsets = nullptr;
     long long* d_tile_sum = nullptr;
     SelRec* d_sel = nullptr;
@@ -115,26 +121,38 @@ void free_table(pie_ctx* c)
     c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0; c->have_scan = false;
 }
 
-int k1_unroll(int variant) { return (variant >> 4) == 2 ? 2 : (variant >> 4) == 8 ? 8 : 4; }
-
-// Grid of the scan kernel: every block owns a contiguous, kBlockTileRows-aligned row range.  Default is a
-// few blocks per CU slot so the tail of the launch is short; PIE_K1_BLOCKS overrides for tuning.
-void plan_k1(pie_ctx* c)
+// Grid of the scan kernel: every block owns a contiguous, tile-aligned row range.  Two plans, measured on
+// cfg3 (profiles/r01_c_*): the streaming form likes many short blocks (short tail), the liveness-first form likes
+// fewer, longer blocks (each wave ends with one partial drain of its live-row ring, amortised over more rows).
+// PIE_K1_BLOCKS / PIE_K1_BLOCKS_LIVE override for tuning.
+void plan_one(pie_ctx* c, int which, long long want, const char* env)
 {
-    long long want = (long long)c->n_cus * 48;
-    if (const char* e = getenv("PIE_K1_BLOCKS")) {
+    if (const char* e = getenv(env)) {
         long long v = atoll(e);
         if (v > 0) want = v;
     }
-    const long long kBlockTileRows = (long long)kUnitRows * k1_unroll(c->k1_variant) * kK1Waves;
+    const long long kBlockTileRows = (long long)kUnitRows * 8 * kK1Waves; // a whole number of wave-tiles for every unroll
     long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
     if (tiles < 1) tiles = 1;
     if (want > tiles) want = tiles;
     if (want < 1) want = 1;
     const long long tiles_per_block = (tiles + want - 1) / want;
-    c->rows_per_block = tiles_per_block * kBlockTileRows;
-    c->k1_blocks = (int)((c->n + c->rows_per_block - 1) / c->rows_per_block);
-    if (c->k1_blocks < 1) c->k1_blocks = 1;
+    c->plan_rows[which] = tiles_per_block * kBlockTileRows;
+    c->plan_blocks[which] = (int)((c->n + c->plan_rows[which] - 1) / c->plan_rows[which]);
+    if (c->plan_blocks[which] < 1) c->plan_blocks[which] = 1;
+}
+
+void use_plan(pie_ctx* c, int which)
+{
+    c->k1_blocks = c->plan_blocks[which];
+    c->rows_per_block = c->plan_rows[which];
+}
+
+void plan_k1(pie_ctx* c)
+{
+    plan_one(c, 0, (long long)c->n_cus * 48, "PIE_K1_BLOCKS");
+    plan_one(c, 1, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_LIVE");
+    use_plan(c, 0);
 }
 
 // Make room for n rows / n_users users.  keep_rows > 0: the first keep_rows rows of the resident columns survive
@@ -191,6 +209,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     c->n_users = n_users;
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
     c->have_scan = false;
+    c->live_frac = -1;
     c->cur = 0;
     c->d_counts = c->d_counts2[0];
     // both ping-pong buffers start clean; afterwards every scan's K2b clears the next scan's buffers
@@ -233,20 +252,34 @@ int resolve_events(pie_ctx* c)
     return PIE_OK;
 }
 
-// K1 variants (PIE_K1_VARIANT selects one for tuning runs; the default is the measured best).
-//   bit0: nontemporal loads   bit1: late materialisation of user[]   bits 4..: unroll (0 -> 4)
-void launch_k1(pie_ctx* c, hipStream_t s, long long now, long long cutoff, unsigned long long mask, int* counts,
-               Summary* sum)
+// K1 forms.  Variant code: bit0 nontemporal loads, bit1 late user materialisation, bit2 liveness-first form
+// (streams only `end`, gathers the other columns for live rows); bits 4.. = unroll (0 -> 4).
+// PIE_K1_VARIANT pins one form (tuning / A-B runs); otherwise the form follows the live fraction that the
+// previous scan on this table observed: liveness-first below kLiveFirstBelow, the streaming form above.
+constexpr double kLiveFirstBelow = 0.10; // measured crossover ~0.16 live (profiles/r01_c_live_fraction_crossover.txt)
+
+void launch_k1(pie_ctx* c, hipStream_t s, int variant, long long now, long long cutoff, unsigned long long mask,
+               int* counts, Summary* sum)
 {
 #define PIE_K1(UN, NT, LU)                                                                                          \
     hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, counts, c->d_sel, \
-                       c->d_sel_rank, c->d_blk_count, &sum->bad_rows)
-    switch (c->k1_variant) {
+                       c->d_sel_rank, c->d_blk_count, sum)
+#define PIE_K1L(UN, NT)                                                                                             \
+    hipLaunchKernelGGL((k_scan_live_first<UN, NT>), dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+                       c->d_user, c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, counts, c->d_sel, \
+                       c->d_sel_rank, c->d_blk_count, sum)
+    switch (variant) {
     case 0x00: PIE_K1(4, false, false); break;
     case 0x01: PIE_K1(4, true, false); break;
     case 0x02: PIE_K1(4, false, true); break;
     case 0x03: PIE_K1(4, true, true); break;
+    case 0x04: PIE_K1L(4, false); break;
+    case 0x05: PIE_K1L(4, true); break;
+    case 0x24: PIE_K1L(2, false); break;
+    case 0x25: PIE_K1L(2, true); break;
+    case 0x84: PIE_K1L(8, false); break;
+    case 0x85: PIE_K1L(8, true); break;
     case 0x20: PIE_K1(2, false, false); break;
     case 0x21: PIE_K1(2, true, false); break;
     case 0x22: PIE_K1(2, false, true); break;
@@ -255,9 +288,10 @@ void launch_k1(pie_ctx* c, hipStream_t s, long long now, long long cutoff, unsig
     case 0x81: PIE_K1(8, true, false); break;
     case 0x82: PIE_K1(8, false, true); break;
     case 0x83: PIE_K1(8, true, true); break;
-    default: PIE_K1(4, false, false); break;
+    default: PIE_K1(4, true, true); break;
     }
 #undef PIE_K1
+#undef PIE_K1L
 }
 
 // The whole scan, results left on the device.  One host wait in the middle of the queue (for the 32-byte
@@ -288,7 +322,12 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
     Summary* sum = c->d_sum2[c->cur];
     Summary* sum_next = c->d_sum2[c->cur ^ 1];
     if (ev) PIE_HIP(c, hipEventRecord(ev->e0, s));
-    launch_k1(c, s, now, cutoff, mask, counts, sum);
+    int variant = c->k1_variant;
+    c->last_variant = 0;
+    if (!c->k1_pinned && c->live_frac >= 0) variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+    use_plan(c, (variant & 4) ? 1 : 0);
+    launch_k1(c, s, variant, now, cutoff, mask, counts, sum);
+    c->last_variant = variant;
     if (ev) PIE_HIP(c, hipEventRecord(ev->e1, s));
     hipLaunchKernelGGL(k_tile_sums, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum);
     hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum, c->d_offsets,
@@ -311,6 +350,7 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
 
     PIE_HIP(c, hipEventSynchronize(summary_ready));
     c->last = *c->h_summary;
+    c->live_frac = c->n > 0 ? (double)c->last.live / (double)c->n : 0.0;
     if (c->last.n_big > 0) {
         // big buckets: tiles of kSegMax are sorted in place by K4b; merge passes ping-pong between the bucket
         // arrays and scratch carved out of the (now consumed) record staging; the last pass lands in out_idx.
@@ -419,7 +459,8 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
         return PIE_E_NODEVICE;
     }
     c->stream = c->own_stream;
-    if (const char* v = getenv("PIE_K1_VARIANT")) c->k1_variant = (int)strtol(v, nullptr, 0);
+    if (const char* v = getenv("PIE_K1_VARIANT")) { c->k1_variant = (int)strtol(v, nullptr, 0); c->k1_pinned = true; }
+    if (const char* v = getenv("PIE_K1_LIVE_FIRST")) c->k1_live_first = (int)strtol(v, nullptr, 0);
     *ctx_out = c;
     return PIE_OK;
 }
@@ -686,6 +727,9 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
     out->n_segments = c->last.n_seg;
     out->n_big = c->last.n_big;
     out->k1_blocks = (uint32_t)c->k1_blocks;
+    out->k1_variant = (uint32_t)c->last_variant;
+    out->reserved = 0;
+    out->live = c->last.live;
     return PIE_OK;
 }
 

@@ -103,6 +103,43 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
     run_both(gpu_ctx, oracle, cols, U, D, oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)
 
 
+@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85])
+def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
+    """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
+    through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
+    monkeypatch.setenv("PIE_K1_VARIANT", hex(variant))
+    with pie.PieScan(0) as ctx:
+        for n, U, D, flags in [(1, 1, 1, 0), (4097, 9, 7, 1), (70001, 333, 32, 0), (1 << 20, 5000, 32, 3)]:
+            cols = oracle.gen(SEED, n, 0, n, U, D, flags)
+            now, cutoff, mask = spec_query(oracle)
+            for q in [(now, cutoff, mask), (INT64_MIN, INT64_MIN, ALL), (2 ** 62, INT64_MIN, ALL),
+                      (oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)]:
+                run_both(ctx, oracle, cols, U, D, *q)
+            assert ctx.stats()["k1_variant"] == variant
+
+
+def test_k1_form_follows_live_fraction(pie, oracle):
+    """Unpinned: the first scan of a table streams every predicate column; once a scan has seen that few rows are
+    live the liveness-first form takes over, and it falls back when most rows are live.  Same bytes either way."""
+    with pie.PieScan(0) as ctx:
+        n, U, D = 400000, 1000, 32
+        s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
+        now, cutoff, mask = spec_query(oracle)
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(mask, D)
+        want_spec = oracle.scan(s, e, u, d, U, now, cutoff, mask & 0xFFFFFFFF)
+        want_all = oracle.scan(s, e, u, d, U, INT64_MIN, INT64_MIN, mask & 0xFFFFFFFF)
+        assert_same(ctx.scan(now, cutoff), want_spec)
+        st = ctx.stats()
+        assert st["k1_variant"] == 0x03 and abs(st["live"] / n - 18 / (120 * 24)) < 2e-3
+        assert_same(ctx.scan(now, cutoff), want_spec)
+        assert ctx.stats()["k1_variant"] == 0x85
+        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # still liveness-first (decided from the last scan) ...
+        assert ctx.stats()["k1_variant"] == 0x85 and ctx.stats()["live"] == n
+        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and back to streaming once everything is live
+        assert ctx.stats()["k1_variant"] == 0x03
+
+
 def test_generator_parity(gpu_ctx, oracle):
     for n, U, D, flags in [(1000, 10, 3, 0), (70001, 333, 32, 1), (70001, 333, 32, 2), (4096, 4096, 64, 3)]:
         gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, flags)

@@ -24,10 +24,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--query", default="spec")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--live-days", type=float, default=None, help="now = T0 - X days + 12 h, no window: live fraction ~ X/120")
     a = ap.parse_args()
     now, cutoff = (T0 - 6 * 3600 * 1000, T0 - 61 * DAY) if a.query == "spec" else (T0 - 100 * DAY, T0 - 61 * DAY)
+    if a.query == "none":
+        now, cutoff = 2 ** 62, -(2 ** 63)
     if a.query == "all":
         now, cutoff = -(2 ** 63), -(2 ** 63)
+    if a.live_days is not None:
+        now, cutoff = T0 - int(a.live_days * DAY) - 12 * 3600 * 1000, -(2 ** 63)
     mask = 0x55555555
     ref = None
     results = {}
@@ -36,6 +41,7 @@ def main():
         for v, b in configs:
             os.environ["PIE_K1_VARIANT"] = hex(v)
             os.environ["PIE_K1_BLOCKS"] = str(b)
+            os.environ["PIE_K1_BLOCKS_LIVE"] = str(b)
             with pie.PieScan(0) as ctx:
                 ctx.gen_synthetic(0x5EED5EED, a.rows, 0, a.rows, a.users, 32, a.flags)
                 ctx.set_disciplines(mask, 32)
