@@ -70,6 +70,11 @@ def cpu_baseline(args, U, D, now, cutoff, mask, flags):
 
 
 def main():
+    # exactly ONE JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1, so fd 1 is
+    # pointed at stderr for the whole run and the result line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -102,8 +107,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the scan path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PIE_BENCH_FORCE_GATHER=1 exercises the RCCL exchange step with a single rank (rehearsal on a 1-GPU box)
+    gather = world > 1 or os.environ.get("PIE_BENCH_FORCE_GATHER") == "1"
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     N, U, D = args.rows, args.users, args.disc
@@ -122,38 +130,44 @@ def main():
     ctx.set_disciplines(mask, D)
     log("rank %d: generated %d rows in %.2f s" % (rank, N, time.perf_counter() - t_gen))
 
-    backend = HipShardBackend(ctx, dev) if world > 1 else None
-    feeds = ShardedFeeds(backend, rank, world, U) if world > 1 else None
+    backend = HipShardBackend(ctx, dev) if gather else None
+    feeds = ShardedFeeds(backend, rank, world, U, always_collective=gather) if gather else None
 
-    def step():
-        if world == 1:
-            return ctx.scan_device(now, cutoff)
-        return feeds.scan_and_gather(now, cutoff)
+    def run_steps(k):
+        """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1 (depth-1 pipeline,
+        every gather is collected inside the same call)."""
+        last = None
+        if not gather:
+            for _ in range(k):
+                last = ctx.scan_device(now, cutoff)
+            return last
+        last = feeds.run_steps(k, now, cutoff)
+        if last is None:  # a row list outgrew the message: capacity was raised, redo synchronously once
+            last = feeds.scan_and_gather(now, cutoff)
+        return last
 
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if gather:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, 1))
     fence()
     ctx.stats_reset()
     ctx.set_profiling(True)  # HIP events around the scan kernels, on the stream they are launched on
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
+    last = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     ctx.set_profiling(False)
-    if world > 1:
+    if gather:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = ctx.stats()
-    m = last if world == 1 else int(last["lengths"][rank].item())
+    m = last if not gather else int(last["lengths"][rank])
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -196,8 +210,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, U, D, now, cutoff, mask, flags)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    if gather:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -106,11 +106,19 @@ int pie_scan(pie_ctx *ctx, int64_t now, int64_t cutoff, int32_t *counts_out, int
              int32_t *idx_out, size_t idx_cap, size_t *m_out);
 /* Same scan, results left in device memory (for the multi-GPU gather and for benchmarking). */
 int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
+/* The same scan in two halves for callers that overlap host work with it: begin enqueues every kernel and returns
+ * at once; finish waits for the scan's summary (M), runs the rare big-bucket merge passes and returns M.  Exactly
+ * one scan may be in flight per context. */
+int pie_scan_begin(pie_ctx *ctx, int64_t now, int64_t cutoff);
+int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
 /* Device pointers of the last scan's results (valid until the next load/scan on this ctx). */
 int pie_result_device_ptrs(pie_ctx *ctx, void **counts_dev, void **offsets_dev, void **idx_dev);
 /* Copy the last scan's results into caller-owned DEVICE buffers (e.g. torch tensors that feed an RCCL
  * all-gather), asynchronously on the context's stream.  Any pointer may be NULL; idx copies min(M, idx_cap). */
 int pie_copy_results_device(pie_ctx *ctx, void *counts_dst, void *offsets_dst, void *idx_dst, size_t idx_cap);
+/* Pack the last scan's results into ONE int32 message in caller-owned device memory, one launch on the context's
+ * stream: [counts[0..U) | zeros up to u_pad | M | idx[0 .. min(M, idx_cap))] — the unit of the multi-GPU all-gather. */
+int pie_pack_results_device(pie_ctx *ctx, void *dst_i32, size_t u_pad, size_t idx_cap);
 /* Gather the rows named by idx (host array of m row indices) for host-side serialisation
  * (the event object of server/calendarFeed.js:66-79).  Output pointers may be NULL. */
 int pie_fetch_rows(pie_ctx *ctx, const int32_t *idx, size_t m, int64_t *start, int64_t *end, int32_t *user,

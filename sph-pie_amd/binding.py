@@ -50,8 +50,11 @@ _SIGS = [
     ("pie_set_disciplines", C.c_int, [_P, C.c_uint64, C.c_int32]),
     ("pie_scan", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_scan_device", C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
+    ("pie_scan_begin", C.c_int, [_P, C.c_int64, C.c_int64]),
+    ("pie_scan_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_copy_results_device", C.c_int, [_P, _P, _P, _P, C.c_size_t]),
+    ("pie_pack_results_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_fetch_rows", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("pie_expired_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_set_profiling", C.c_int, [_P, C.c_int]),
@@ -185,6 +188,14 @@ class PieScan:
         self._check(self._lib.pie_scan_device(self._ctx, int(now), int(cutoff), C.byref(m)))
         return m.value
 
+    def scan_begin(self, now, cutoff):
+        self._check(self._lib.pie_scan_begin(self._ctx, int(now), int(cutoff)))
+
+    def scan_finish(self):
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_scan_finish(self._ctx, C.byref(m)))
+        return m.value
+
     def result_device_ptrs(self):
         a, b, c = _P(), _P(), _P()
         self._check(self._lib.pie_result_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
@@ -193,6 +204,10 @@ class PieScan:
     def copy_results_device(self, counts_ptr=None, offsets_ptr=None, idx_ptr=None, idx_cap=0):
         """D2D copy into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr()), on the ctx stream."""
         self._check(self._lib.pie_copy_results_device(self._ctx, counts_ptr, offsets_ptr, idx_ptr, int(idx_cap)))
+
+    def pack_results_device(self, dst_ptr, u_pad, idx_cap):
+        """[counts | 0-pad to u_pad | M | idx[:min(M, cap)]] as int32 into caller-owned device memory (one launch)."""
+        self._check(self._lib.pie_pack_results_device(self._ctx, dst_ptr, int(u_pad), int(idx_cap)))
 
     def fetch_rows(self, idx):
         idx = _col(idx, np.int32)

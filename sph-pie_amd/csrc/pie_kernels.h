@@ -731,6 +731,27 @@ __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ result packing
+
+// One contiguous int32 message for the multi-GPU exchange: [counts[0..U) | 0 .. u_pad) | M | idx[0..min(M,cap))].
+// One launch instead of three D2D copies; the message feeds a single RCCL all-gather.
+__global__ __launch_bounds__(256) void k_pack_results(const int* __restrict__ counts, int n_users, int u_pad,
+                                                      const Summary* __restrict__ summary, const int* __restrict__ out_idx,
+                                                      long long cap, int* __restrict__ dst)
+{
+    const long long m = (long long)summary->m;
+    const long long k = m < cap ? m : cap;
+    const long long total = (long long)u_pad + 1 + k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int v;
+        if (i < n_users) v = counts[i];
+        else if (i < u_pad) v = 0;
+        else if (i == u_pad) v = (int)m;
+        else v = out_idx[i - u_pad - 1];
+        dst[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ table maintenance
 
 __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, const int* __restrict__ rows,

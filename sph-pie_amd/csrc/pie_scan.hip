@@ -74,6 +74,8 @@ struct pie_ctx {
     Summary* h_summary = nullptr; // pinned
     hipEvent_t ev_summary = nullptr;
     bool have_scan = false;
+    bool in_flight = false;        // between pie_scan_begin and pie_scan_finish
+    ScanEvents* flight_ev = nullptr;
     Summary last{};
 
     // profiling
@@ -294,11 +296,14 @@ void launch_k1(pie_ctx* c, hipStream_t s, int variant, long long now, long long 
 #undef PIE_K1L
 }
 
-// The whole scan, results left on the device.  One host wait in the middle of the queue (for the 32-byte
-// summary) overlaps with K3/K4a/K4b, which are already enqueued behind it.
-int run_scan(pie_ctx* c, long long now, long long cutoff)
+// The scan in two halves.  scan_begin enqueues every kernel of the common path (K1..K4) and returns at once;
+// scan_finish waits for the 40-byte summary that K2b produced (K3/K4 are already queued behind it, so the GPU
+// never waits for the host), runs the rare big-bucket merge passes, and closes the timing events.  A caller
+// that has host work to do per step (the multi-GPU exchange) does it between the two halves.
+int scan_begin(pie_ctx* c, long long now, long long cutoff)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->in_flight) return fail(c, PIE_E_STATE, "pie_scan_begin while a scan is in flight");
     hipStream_t s = c->stream;
     ScanEvents* ev = nullptr;
     if (c->profiling) {
@@ -334,8 +339,7 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
                        c->d_seg_list, c->d_big_list, sum, counts_next, sum_next);
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, sum, sizeof(Summary), hipMemcpyDeviceToHost, s));
     if (!c->ev_summary) PIE_HIP(c, hipEventCreateWithFlags(&c->ev_summary, hipEventDisableTiming));
-    hipEvent_t summary_ready = c->ev_summary;
-    PIE_HIP(c, hipEventRecord(summary_ready, s));
+    PIE_HIP(c, hipEventRecord(c->ev_summary, s));
 
     int scat_blocks = (c->k1_blocks + 3) / 4;
     if (scat_blocks > c->n_cus * 8) scat_blocks = c->n_cus * 8;
@@ -347,8 +351,19 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
     c->d_counts = counts;
     c->cur ^= 1;
     PIE_HIP(c, hipGetLastError());
+    c->in_flight = true;
+    c->have_scan = false;
+    c->flight_ev = ev;
+    return PIE_OK;
+}
 
-    PIE_HIP(c, hipEventSynchronize(summary_ready));
+int scan_finish(pie_ctx* c)
+{
+    if (!c->in_flight) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
+    hipStream_t s = c->stream;
+    ScanEvents* ev = c->flight_ev;
+    c->in_flight = false;
+    PIE_HIP(c, hipEventSynchronize(c->ev_summary));
     c->last = *c->h_summary;
     c->live_frac = c->n > 0 ? (double)c->last.live / (double)c->n : 0.0;
     if (c->last.n_big > 0) {
@@ -381,6 +396,13 @@ int run_scan(pie_ctx* c, long long now, long long cutoff)
     if (c->last.bad_rows)
         return fail(c, PIE_E_INVAL, "%u selected rows carry a user id outside [0, %d)", c->last.bad_rows, c->n_users);
     return PIE_OK;
+}
+
+int run_scan(pie_ctx* c, long long now, long long cutoff)
+{
+    int rc = scan_begin(c, now, cutoff);
+    if (rc) return rc;
+    return scan_finish(c);
 }
 
 // ordered list of the rows matching a one-column predicate (expired queue / user match), through the
@@ -617,6 +639,22 @@ int pie_scan_device(pie_ctx* c, int64_t now, int64_t cutoff, size_t* m_out)
     return rc;
 }
 
+int pie_scan_begin(pie_ctx* c, int64_t now, int64_t cutoff)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    return scan_begin(c, now, cutoff);
+}
+
+int pie_scan_finish(pie_ctx* c, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = scan_finish(c);
+    if (m_out) *m_out = (size_t)c->last.m;
+    return rc;
+}
+
 int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out,
              size_t idx_cap, size_t* m_out)
 {
@@ -660,6 +698,21 @@ int pie_copy_results_device(pie_ctx* c, void* counts_dst, void* offsets_dst, voi
     size_t m = (size_t)c->last.m;
     if (m > idx_cap) m = idx_cap;
     if (idx_dst && m) PIE_HIP(c, hipMemcpyAsync(idx_dst, c->d_out_idx, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    return PIE_OK;
+}
+
+int pie_pack_results_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t idx_cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
+    if (!dst_i32 || u_pad < (size_t)c->n_users) return fail(c, PIE_E_INVAL, "bad pack destination / u_pad < n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    const size_t total = u_pad + 1 + ((size_t)c->last.m < idx_cap ? (size_t)c->last.m : idx_cap);
+    size_t grid = (total + 255) / 256;
+    if (grid > (size_t)c->n_cus * 8) grid = (size_t)c->n_cus * 8;
+    hipLaunchKernelGGL(k_pack_results, dim3((unsigned)grid), dim3(256), 0, c->stream, c->d_counts, c->n_users, (int)u_pad,
+                       c->d_sum2[c->cur ^ 1], c->d_out_idx, (long long)idx_cap, (int*)dst_i32);
+    PIE_HIP(c, hipGetLastError());
     return PIE_OK;
 }
 

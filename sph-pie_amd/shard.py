@@ -2,10 +2,11 @@
 cross-user feeds.  One process per GPU; torch.distributed is the transport (backend "nccl"
 is RCCL over xGMI on ROCm, "gloo" on CPU for the world_size-2 tests).
 
-Rows of different users are independent, so each rank scans its shard with no communication; the only
-exchange step is the gather of per-user counts (fixed size) and of the selected-row lists (variable size,
-sent as a fixed-capacity buffer whose first word is the length).  xGMI is point-to-point: an all-gather of
-small buffers is latency-bound, so both gathers carry one contiguous buffer each.
+Rows of different users are independent, so each rank scans its shard with no communication.  The one exchange
+step gathers, per rank, ONE contiguous int32 message  [counts[0..U_pad) | M | rows[0..cap)]  (packed by a single
+kernel launch, `pie_pack_results_device`).  xGMI is point-to-point and these messages are small (≈2 MB), so the
+gather is latency-bound: it is issued on a side stream and overlaps the next scan; the host never waits on the
+scan stream for it (submit / collect, depth-1 pipeline).
 """
 import numpy as np
 import torch
@@ -35,43 +36,57 @@ def partition_by_user_hash(start, end, user, disc, n_users, world):
 
 
 class HipShardBackend:
-    """Scans the local shard with the HIP library and hands back torch tensors on this rank's GPU."""
+    """Scans the local shard with the HIP library and packs the result message on this rank's GPU."""
 
     def __init__(self, ctx: PieScan, device):
         self.ctx = ctx
         self.device = torch.device(device)
-        # run the scan on torch's current stream so the D2D copies and the collectives order naturally
+        # the scan runs on torch's current stream, so packing, events and collectives order with it naturally
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        self.counts = torch.empty(ctx.n_users, dtype=torch.int32, device=self.device)
-        self.payload = None
 
-    def scan(self, now, cutoff, cap):
-        """-> (counts[U] int32, payload[1+cap] int32 with payload[0] = M)."""
-        m = self.ctx.scan_device(now, cutoff)
-        if self.payload is None or self.payload.numel() != cap + 1:
-            self.payload = torch.empty(cap + 1, dtype=torch.int32, device=self.device)
-        self.ctx.copy_results_device(self.counts.data_ptr(), None, self.payload.data_ptr() + 4, cap)
-        self.payload[0] = m
-        return self.counts, self.payload, m
+    def scan_begin(self, now, cutoff):
+        """Enqueue the scan kernels; returns immediately."""
+        self.ctx.scan_begin(now, cutoff)
+
+    def scan_finish_packed(self, dst, u_pad, cap):
+        """Wait for the scan's summary, then write [counts | 0-pad | M | rows[:min(M, cap)]] into dst (int32, device)
+        with one kernel launch.  -> M (host int)."""
+        m = self.ctx.scan_finish()
+        self.ctx.pack_results_device(dst.data_ptr(), u_pad, cap)
+        return m
+
+
+class _Ticket:
+    __slots__ = ("parity", "work", "m", "done", "cap", "u_pad", "packed")
 
 
 class ShardedFeeds:
-    """Per-rank driver: scan the local shard, all-gather counts and row lists, build global offsets.
+    """Per-rank driver: scan the local shard, all-gather the packed messages, build global offsets.
 
-    `backend.scan(now, cutoff, cap)` -> (counts[U_local] int32, payload[1+cap] int32 with payload[0] = M, M) as
-    tensors on `backend.device` (the GPU for nccl/RCCL, the CPU for gloo)."""
+    `backend.scan_packed(now, cutoff, dst, u_pad, cap) -> M` fills an int32 tensor on `backend.device` (the GPU for
+    nccl/RCCL, the CPU for gloo).  submit() enqueues scan + pack + asynchronous all-gather and returns a ticket;
+    collect(ticket) returns the gathered views.  Two message / result buffers alternate, so step i+1 may be
+    submitted before step i is collected."""
 
-    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None):
+    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self.collective = world > 1 or always_collective  # world 1 + always_collective: rehearsal of the exchange step
         self.n_users_local = int(n_users_local)
         self.device = torch.device(getattr(backend, "device", "cpu"))
+        self.cuda = self.device.type == "cuda"
         # counts are padded to the largest shard's user count so the gather has one fixed size
         self.u_pad = self._all_max(self.n_users_local)
-        self.cap = cap  # capacity of one rank's row list in the payload gather; negotiated on first use
+        self.cap = cap  # capacity of one rank's row list in the message; negotiated on first use
+        self.parity = 0
+        self.msg = self.out = None
+        self.comm_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.gather_done = [None, None]   # event after the gather that last read msg[p] / wrote out[p]
+        self.len_host = None
 
+    # ---- helpers
     def _all_max(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
@@ -79,33 +94,118 @@ class ShardedFeeds:
     def _grow(need):
         return max(1024, int(need * 1.25) + 64)
 
-    def scan_and_gather(self, now, cutoff):
-        """-> dict(counts [world, U_pad] int32, lengths [world] int32, rows [world, cap] int32,
-        offsets [world*U_pad+1] int64).  Feed of local user u of rank r = rows[r, off[u] : off[u+1]] with
-        off = exclusive prefix of counts[r]."""
+    def _alloc(self):
+        L = self.u_pad + 1 + self.cap
+        self.msg = [torch.zeros(L, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.out = [torch.zeros(self.world * L, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.len_host = [torch.zeros(self.world, dtype=torch.int32, pin_memory=self.cuda) for _ in range(2)]
+        self.offsets = [torch.zeros(self.world * self.u_pad + 1, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.gather_done = [None, None]
+
+    # ---- pipeline stages -------------------------------------------------------------------------------
+    #   begin            enqueue the scan (no host wait)
+    #   finish_and_pack  wait for its summary, enqueue the pack launch, mark the message ready       -> ticket
+    #   exchange         issue the all-gather of that message on the side stream (host-heavy, GPU-async)
+    #   collect          wait for the side stream only; hand out the gathered views
+    # run_steps() interleaves them so that the host work of exchange(i-1) happens while the GPU scans step i.
+    def begin(self, now, cutoff):
+        self._query = (now, cutoff)
+        self.backend.scan_begin(now, cutoff)
+
+    def finish_and_pack(self):
         if self.cap is None:
-            _, _, m = self.backend.scan(now, cutoff, 0)
-            self.cap = self._grow(self._all_max(m))
+            # first use: learn M, agree on a capacity, and redo this scan with real buffers
+            probe = torch.zeros(self.u_pad + 1, dtype=torch.int32, device=self.device)
+            self.cap = self._grow(self._all_max(self.backend.scan_finish_packed(probe, self.u_pad, 0)))
+            self.backend.scan_begin(*self._query)
+        if self.msg is None or self.msg[0].numel() != self.u_pad + 1 + self.cap:
+            self._alloc()
+        p = self.parity
+        self.parity ^= 1
+        if self.cuda and self.gather_done[p] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.gather_done[p])  # msg[p] is free again
+        t = _Ticket()
+        t.parity, t.cap, t.u_pad, t.work, t.done = p, self.cap, self.u_pad, None, None
+        t.m = self.backend.scan_finish_packed(self.msg[p], self.u_pad, self.cap)
+        if self.cuda:
+            t.packed = torch.cuda.Event()
+            t.packed.record(torch.cuda.current_stream(self.device))
+        return t
+
+    def exchange(self, t):
+        p = t.parity
+        L = t.u_pad + 1 + t.cap
+        if not self.collective:
+            self.out[p].copy_(self.msg[p])
+        elif self.cuda:
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(t.packed)
+                t.work = dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group, async_op=True)
+                t.work.wait()  # orders the side stream behind the collective; the host does not block here
+                g = self.out[p].view(self.world, L)
+                self.len_host[p].copy_(g[:, t.u_pad], non_blocking=True)
+                torch.cumsum(g[:, : t.u_pad].reshape(-1), 0, out=self.offsets[p][1:])
+                t.done = torch.cuda.Event()
+                t.done.record(self.comm_stream)
+            self.gather_done[p] = t.done
+        else:
+            t.work = dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group, async_op=True)
+
+    def collect(self, t):
+        """-> dict(counts [world, U_pad], lengths [world], rows [world, cap], offsets [world*U_pad+1]) or None when a
+        rank's row list outgrew the message capacity (every rank sees the same lengths, so every rank gets None,
+        the capacity has been raised, and the caller resubmits)."""
+        p = t.parity
+        L = t.u_pad + 1 + t.cap
+        if t.done is not None:
+            t.done.synchronize()            # waits for the side stream only, never for the scan stream
+        else:
+            if t.work is not None:
+                t.work.wait()
+            g0 = self.out[p].view(self.world, L)
+            self.len_host[p].copy_(g0[:, t.u_pad])
+            torch.cumsum(g0[:, : t.u_pad].reshape(-1), 0, out=self.offsets[p][1:])
+        g = self.out[p].view(self.world, L)
+        need = int(self.len_host[p].max())
+        if need > t.cap:
+            self.cap = max(self.cap, self._grow(need))
+            return None
+        return {"counts": g[:, : t.u_pad], "lengths": self.len_host[p].clone(), "rows": g[:, t.u_pad + 1:],
+                "offsets": self.offsets[p]}
+
+    def submit(self, now, cutoff):
+        """One whole step without overlap: scan, pack, issue the gather.  -> ticket for collect()."""
+        self.begin(now, cutoff)
+        t = self.finish_and_pack()
+        self.exchange(t)
+        return t
+
+    def scan_and_gather(self, now, cutoff):
+        """Synchronous form: one scan, one gather, retried with a larger message if a row list did not fit."""
         while True:
-            counts, payload, m = self.backend.scan(now, cutoff, self.cap)
-            if counts.numel() < self.u_pad:
-                counts = torch.cat([counts, counts.new_zeros(self.u_pad - counts.numel())])
-            if self.world == 1:
-                g_counts, g_payload = counts, payload
-            else:
-                g_counts = torch.empty(self.world * counts.numel(), dtype=counts.dtype, device=counts.device)
-                g_payload = torch.empty(self.world * payload.numel(), dtype=payload.dtype, device=payload.device)
-                dist.all_gather_into_tensor(g_counts, counts, group=self.group)
-                dist.all_gather_into_tensor(g_payload, payload, group=self.group)
-            g_counts = g_counts.view(self.world, -1)
-            g_payload = g_payload.view(self.world, -1)
-            lengths = g_payload[:, 0]
-            # one tiny D2H per step (world ints); every rank sees the same gathered lengths, so every rank
-            # takes the same branch
-            need = int(lengths.max().item())
-            if need <= self.cap:
-                break
-            self.cap = self._grow(need)
-        offsets = torch.zeros(g_counts.numel() + 1, dtype=torch.int64, device=g_counts.device)
-        torch.cumsum(g_counts.reshape(-1), 0, out=offsets[1:])
-        return {"counts": g_counts, "lengths": lengths, "rows": g_payload[:, 1:], "offsets": offsets}
+            res = self.collect(self.submit(now, cutoff))
+            if res is not None:
+                return res
+
+    def run_steps(self, k, now, cutoff):
+        """k steps of the same query, software-pipelined: while the GPU scans step i the host issues the gather of
+        step i-1 and collects step i-2.  Every gather is collected before returning.  -> last collected result
+        (None if a message overflowed: the capacity has been raised, call again)."""
+        last, packed, flying = None, None, None
+        if k <= 0:
+            return None
+        self.begin(now, cutoff)
+        for i in range(k):
+            if packed is not None:
+                self.exchange(packed)
+                if flying is not None:
+                    last = self.collect(flying)
+                flying, packed = packed, None
+            t = self.finish_and_pack()
+            if i + 1 < k:
+                self.begin(now, cutoff)
+            packed = t
+        self.exchange(packed)
+        if flying is not None:
+            last = self.collect(flying)
+        return self.collect(packed)

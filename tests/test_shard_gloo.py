@@ -18,21 +18,25 @@ INT64_MIN = -(2 ** 63)
 
 class OracleBackend:
     """Test stand-in for HipShardBackend: same contract, CPU tensors."""
-
     device = "cpu"
 
     def __init__(self, oracle, shard, mask):
         self.o, self.sh, self.mask = oracle, shard, mask
 
-    def scan(self, now, cutoff, cap):
+    def scan_begin(self, now, cutoff):
+        self.q = (now, cutoff)
+
+    def scan_finish_packed(self, dst, u_pad, cap):
+        now, cutoff = self.q
         c, off, idx = self.o.scan(self.sh["start"], self.sh["end"], self.sh["user"], self.sh["disc"], self.sh["n_users"],
                                   now, cutoff, self.mask)
-        payload = torch.zeros(cap + 1, dtype=torch.int32)
         m = idx.size
-        payload[0] = m
         k = min(m, cap)
-        payload[1:1 + k] = torch.from_numpy(idx[:k])
-        return torch.from_numpy(c), payload, m
+        dst[: c.size] = torch.from_numpy(c)
+        dst[c.size:u_pad] = 0
+        dst[u_pad] = m
+        dst[u_pad + 1:u_pad + 1 + k] = torch.from_numpy(idx[:k])
+        return m
 
 
 def _worker(rank, world, port, tmp, n, U):
@@ -50,7 +54,15 @@ def _worker(rank, world, port, tmp, n, U):
         sh = shards[rank]
         mask = 0x55555555
         feeds = ShardedFeeds(OracleBackend(oracle_py, sh, mask), rank, world, sh["n_users"])
-        for now, cutoff in [(T0 - 6 * 3600 * 1000, T0 - 61 * DAY), (INT64_MIN, INT64_MIN), (T0 - 100 * DAY, T0 - 61 * DAY)]:
+        queries = [(T0 - 6 * 3600 * 1000, T0 - 61 * DAY), (INT64_MIN, INT64_MIN), (T0 - 100 * DAY, T0 - 61 * DAY)]
+        # pipelined use: submit step i+1 before collecting step i (the second query outgrows the negotiated
+        # capacity on purpose, so the resubmit path runs too)
+        tickets = [feeds.submit(*queries[0]), feeds.submit(*queries[0])]
+        first = [feeds.collect(t) for t in tickets]
+        assert first[0] is not None and torch.equal(first[0]["rows"], first[1]["rows"])
+        piped = feeds.run_steps(5, *queries[0])
+        assert torch.equal(piped["rows"], first[0]["rows"]) and torch.equal(piped["counts"], first[0]["counts"])
+        for now, cutoff in queries:
             out = feeds.scan_and_gather(now, cutoff)
             # rebuild global feeds from the gathered buffers and compare with the oracle on the WHOLE table
             wc, wo, wi = oracle_py.scan(*cols, U, now, cutoff, mask)
