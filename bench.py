@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--js-rows", type=int, default=10 ** 6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
+                    help="scans in flight: 2 = the table pass of step i+1 overlaps the scatter/order tail of step i")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,9 +141,11 @@ def main():
         every gather is collected inside the same call)."""
         last = None
         if not gather:
-            for _ in range(k):
-                last = ctx.scan_device(now, cutoff)
-            return last
+            if args.depth == 1:
+                for _ in range(k):
+                    last = ctx.scan_device(now, cutoff)
+                return last
+            return ctx.scan_pipelined(k, now, cutoff)
         last = feeds.run_steps(k, now, cutoff)
         if last is None:  # a row list outgrew the message: capacity was raised, redo synchronously once
             last = feeds.scan_and_gather(now, cutoff)
@@ -156,12 +161,14 @@ def main():
     run_steps(max(args.warmup, 1))
     fence()
     ctx.stats_reset()
-    ctx.set_profiling(True)  # HIP events around the scan kernels, on the stream they are launched on
+    # HIP events around the scan kernels, on the stream they are launched on; every 4th step carries them (an event
+    # between two kernels drains the pipeline for a few microseconds, which would inflate ms_per_step)
+    ctx.set_profiling(args.profile_every)
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    ctx.set_profiling(False)
+    ctx.set_profiling(0)
     if gather:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,7 +201,7 @@ def main():
                 "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
                             "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s variant, %s query" % (N, U, D, args.order, args.variant, args.query),
                 "sessions_per_gpu": N, "users_per_gpu": U, "disciplines": D, "selected_rows_rank0": int(m),
-                "parallelism": "user-hash shards x%d, RCCL all-gather of counts + row lists" % world if world > 1 else "single GPU",
+                "parallelism": "user-hash shards x%d, RCCL all-gather of per-user offsets + row lists, overlapped with the next scan" % world if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant), "achieved": achieved, "peak": HBM_PEAK_GBS,

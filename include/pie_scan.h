@@ -70,8 +70,13 @@ int pie_ctx_create(int device_id, pie_ctx **ctx_out);
 int pie_ctx_destroy(pie_ctx *ctx);
 /* ctx may be NULL: returns the last error of a failed pie_ctx_create on this thread. */
 const char *pie_last_error(const pie_ctx *ctx);
-/* Run every kernel on a caller stream (a hipStream_t, e.g. torch's current stream).  NULL = ctx-owned stream. */
+/* Run the scan's main-stream kernels (K1, K2) on a caller stream (a hipStream_t, e.g. torch's current stream).
+ * NULL = ctx-owned stream. */
 int pie_ctx_set_stream(pie_ctx *ctx, void *hip_stream);
+/* The stream on which scan results are produced and on which every result copy / pack is enqueued (today the
+ * context's one stream).  A caller that consumes results on another stream records an event here
+ * (e.g. torch.cuda.ExternalStream(ptr)). */
+int pie_ctx_aux_stream(pie_ctx *ctx, void **hip_stream_out);
 
 /* ---- session table: replaces the in-process `sessions` Map (server/sessionStore.js:6,17) -------------
  * Columns are SoA: start = createdAt, end = expiresAt (int64 ms), user = dense index of the userId string,
@@ -106,18 +111,20 @@ int pie_scan(pie_ctx *ctx, int64_t now, int64_t cutoff, int32_t *counts_out, int
              int32_t *idx_out, size_t idx_cap, size_t *m_out);
 /* Same scan, results left in device memory (for the multi-GPU gather and for benchmarking). */
 int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
-/* The same scan in two halves for callers that overlap host work with it: begin enqueues every kernel and returns
- * at once; finish waits for the scan's summary (M), runs the rare big-bucket merge passes and returns M.  Exactly
- * one scan may be in flight per context. */
+/* The same scan in two halves for callers that overlap host work with it: begin enqueues the table pass and the
+ * offsets kernel and returns at once; finish waits for the scan's summary (M), enqueues scatter + per-bucket order
+ * (and the rare big-bucket merge passes) and returns M.  Results of a finished scan end at the next begin. */
 int pie_scan_begin(pie_ctx *ctx, int64_t now, int64_t cutoff);
 int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
-/* Device pointers of the last scan's results (valid until the next load/scan on this ctx). */
+/* Device pointers of the last finished scan's results: complete in stream order (pie_ctx_aux_stream) or after
+ * pie_synchronize; valid until the next pie_scan_begin. */
 int pie_result_device_ptrs(pie_ctx *ctx, void **counts_dev, void **offsets_dev, void **idx_dev);
 /* Copy the last scan's results into caller-owned DEVICE buffers (e.g. torch tensors that feed an RCCL
  * all-gather), asynchronously on the context's stream.  Any pointer may be NULL; idx copies min(M, idx_cap). */
 int pie_copy_results_device(pie_ctx *ctx, void *counts_dst, void *offsets_dst, void *idx_dst, size_t idx_cap);
 /* Pack the last scan's results into ONE int32 message in caller-owned device memory, one launch on the context's
- * stream: [counts[0..U) | zeros up to u_pad | M | idx[0 .. min(M, idx_cap))] — the unit of the multi-GPU all-gather. */
+ * stream: [off[0..u_pad] (exclusive offsets, = M past the last user) | M | idx[0 .. min(M, idx_cap))], u_pad+2+cap
+ * words — the unit of the multi-GPU all-gather; Feed(u) = idx[off[u] : off[u+1]]. */
 int pie_pack_results_device(pie_ctx *ctx, void *dst_i32, size_t u_pad, size_t idx_cap);
 /* Gather the rows named by idx (host array of m row indices) for host-side serialisation
  * (the event object of server/calendarFeed.js:66-79).  Output pointers may be NULL. */
@@ -130,7 +137,9 @@ int pie_fetch_rows(pie_ctx *ctx, const int32_t *idx, size_t m, int64_t *start, i
 int pie_expired_queue(pie_ctx *ctx, int64_t prev_now, int64_t now, int32_t *queue_out, size_t cap, size_t *q_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
-int pie_set_profiling(pie_ctx *ctx, int enabled); /* record HIP events around the scan kernels */
+/* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
+ * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */
+int pie_set_profiling(pie_ctx *ctx, int enabled);
 int pie_stats_get(pie_ctx *ctx, pie_stats *out);  /* resolves pending events (synchronises the stream) */
 int pie_stats_reset(pie_ctx *ctx);
 int pie_synchronize(pie_ctx *ctx);

@@ -41,6 +41,7 @@ _SIGS = [
     ("pie_ctx_destroy", C.c_int, [_P]),
     ("pie_last_error", C.c_char_p, [_P]),
     ("pie_ctx_set_stream", C.c_int, [_P, _P]),
+    ("pie_ctx_aux_stream", C.c_int, [_P, C.POINTER(_P)]),
     ("pie_load_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_gen_synthetic", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
     ("pie_read_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
@@ -196,6 +197,19 @@ class PieScan:
         self._check(self._lib.pie_scan_finish(self._ctx, C.byref(m)))
         return m.value
 
+    def scan_pipelined(self, k, now, cutoff):
+        """k scans of the same query with two in flight: the table pass of scan i+1 overlaps the tail (scatter,
+        per-bucket order) of scan i.  -> M of the last scan; results on the device as after scan_device()."""
+        m = 0
+        if k <= 0:
+            return m
+        self.scan_begin(now, cutoff)
+        for i in range(k):
+            if i + 1 < k:
+                self.scan_begin(now, cutoff)
+            m = self.scan_finish()
+        return m
+
     def result_device_ptrs(self):
         a, b, c = _P(), _P(), _P()
         self._check(self._lib.pie_result_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
@@ -206,7 +220,7 @@ class PieScan:
         self._check(self._lib.pie_copy_results_device(self._ctx, counts_ptr, offsets_ptr, idx_ptr, int(idx_cap)))
 
     def pack_results_device(self, dst_ptr, u_pad, idx_cap):
-        """[counts | 0-pad to u_pad | M | idx[:min(M, cap)]] as int32 into caller-owned device memory (one launch)."""
+        """[off[0..u_pad] | M | idx[:min(M, cap)]] as int32 (u_pad+2+cap words) into caller-owned device memory."""
         self._check(self._lib.pie_pack_results_device(self._ctx, dst_ptr, int(u_pad), int(idx_cap)))
 
     def fetch_rows(self, idx):
@@ -227,8 +241,15 @@ class PieScan:
     def set_stream(self, hip_stream):
         self._check(self._lib.pie_ctx_set_stream(self._ctx, hip_stream))
 
-    def set_profiling(self, on=True):
-        self._check(self._lib.pie_set_profiling(self._ctx, 1 if on else 0))
+    def aux_stream(self):
+        """hipStream_t (as int) on which scan tails and result copies / packs run."""
+        p = _P()
+        self._check(self._lib.pie_ctx_aux_stream(self._ctx, C.byref(p)))
+        return p.value
+
+    def set_profiling(self, every=1):
+        """0/False: off; n: every n-th scan carries timing events."""
+        self._check(self._lib.pie_set_profiling(self._ctx, int(every)))
 
     def stats(self):
         st = PieStats()

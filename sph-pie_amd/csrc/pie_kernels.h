@@ -4,8 +4,9 @@
 //
 // Pipeline of one scan (all on one stream):
 //   K1  k_scan_compact   read 4 columns once, predicate, histogram counts[user], compact selected rows
-//   K2a k_tile_sums      per-tile sums of counts[U]  (+ prefix of K1's per-block record counts)
-//   K2b k_offsets        exclusive scan -> offsets[U+1], work lists for the sort kernels, summary
+//   K2  k_offsets        one launch: exclusive scan of counts -> offsets[U+1] (tile sums published with
+//                        agent-scope granules, tiles claimed by ticket), work lists for K4, summary to the
+//                        host through mapped memory, and the zeroing of the other slot's histogram
 //   K3  k_scatter        selected records -> per-user buckets (slot = offsets[u] + atomic rank)
 //   K4  k_sort_buckets  one launch: buckets of <= 16 rows in registers (one thread each, sorting network);
 //                       larger buckets (or 4096-row tiles of big buckets) one block each, LDS bitonic
@@ -41,6 +42,19 @@ struct Summary {
     unsigned int bad_rows;      // rows whose user id fell outside [0, U): never selected, reported
     unsigned long long q;       // expired-queue length (pie_expired_queue)
     unsigned long long live;    // rows with end > now seen by K1 (drives the choice of K1 variant for the next scan)
+};
+
+// K2's inter-block state, zeroed together with the histogram it belongs to
+struct ScanCtl {
+    unsigned int ticket; // next tile to claim
+    unsigned int done;   // tiles finished
+    unsigned int pad[2];
+};
+
+// what the host reads after K2: written by the last K2 block into mapped pinned memory, seq last
+struct HostSummary {
+    Summary s;
+    unsigned long long seq;
 };
 
 constexpr int kWave = 64;
@@ -408,26 +422,6 @@ __device__ __forceinline__ long long block_sum_256(long long v, long long* lds4)
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-// K2a: tile_sum[b] = sum of counts over tile b (2048 users per block).
-__global__ __launch_bounds__(256) void k_tile_sums(const int* __restrict__ counts, int n_users,
-                                                   long long* __restrict__ tile_sum)
-{
-    __shared__ long long lds4[4];
-    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
-    long long v = 0;
-    if (base + 8 <= n_users) {
-        const int4 a = *reinterpret_cast<const int4*>(counts + base);
-        const int4 b = *reinterpret_cast<const int4*>(counts + base + 4);
-        v = (long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (base + k < n_users) v += counts[base + k];
-    }
-    v = block_sum_256(v, lds4);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = v;
-}
-
 // exclusive prefix over blk[0..nb) by ONE block -> off[nb+1]; total also stored to *total_out (may be null)
 __global__ __launch_bounds__(256) void k_block_prefix(const int* __restrict__ blk, int nb, long long* __restrict__ off,
                                                       unsigned long long* __restrict__ total_out)
@@ -457,45 +451,66 @@ __global__ __launch_bounds__(256) void k_block_prefix(const int* __restrict__ bl
     }
 }
 
-// K2b: offsets[u] = exclusive prefix of counts; sort work lists; max bucket; M.  Also clears the OTHER
-// counts / summary buffers, so the next scan starts from zero without a memset on its critical path.
+// K2: offsets[u] = exclusive prefix of counts; sort work lists; max bucket; M — in ONE launch.
+// Tiles of 2048 users are claimed by ticket (so a block only ever waits for tiles that are already running,
+// whatever the dispatch order); a tile publishes its sum as one 8-byte {flag, value} granule with an agent-scope
+// store and reads its predecessors' granules with agent-scope loads (no fence needed for a single granule:
+// /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  The last block to finish copies the
+// summary to mapped host memory (seq last, system scope): the host spins on it instead of paying a D2H copy
+// node plus an event wait.  Every block also zeroes its slice of the OTHER slot's histogram span, so the next
+// scan needs no memset.
+constexpr unsigned long long kTileReady = 1ull << 62;
+
 __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts, int n_users,
-                                                 const long long* __restrict__ tile_sum,
+                                                 unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
                                                  Segment* __restrict__ seg_list, int* __restrict__ big_list,
-                                                 Summary* __restrict__ summary, int* __restrict__ counts_next,
-                                                 Summary* __restrict__ summary_next)
+                                                 Summary* __restrict__ summary, HostSummary* __restrict__ host,
+                                                 unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16)
 {
     __shared__ long long lds4[4];
     __shared__ long long wsum[4];
+    __shared__ unsigned int tile_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // base = sum of the tile sums in front of this tile (n_tiles is small: U / 2048)
-    long long part = 0;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_sum[t];
-    const long long base = block_sum_256(part, lds4);
+    if (zero_span) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_vec16; i += (long long)gridDim.x * 256) zero_span[i] = z;
+    }
+    if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int tile = (int)tile_s;
 
-    const int u0 = blockIdx.x * kScanTile + threadIdx.x * 8;
+    const int u0 = tile * kScanTile + threadIdx.x * 8;
     int c[8];
     long long tsum = 0;
     if (u0 + 8 <= n_users) {
         const int4 a = *reinterpret_cast<const int4*>(counts + u0);
         const int4 b = *reinterpret_cast<const int4*>(counts + u0 + 4);
         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-        const int4 z = make_int4(0, 0, 0, 0);
-        *reinterpret_cast<int4*>(counts_next + u0) = z;
-        *reinterpret_cast<int4*>(counts_next + u0 + 4) = z;
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
-            if (u0 + k < n_users) counts_next[u0 + k] = 0;
-        }
+        for (int k = 0; k < 8; ++k) c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) tsum += c[k];
     const long long incl = wave_incl_scan(tsum, lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
+    const long long tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&tile_pub[tile], kTileReady | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // base = sum of the tiles in front of this one
+    long long part = 0;
+    for (int t = threadIdx.x; t < tile; t += 256) {
+        unsigned long long v;
+        do {
+            v = __hip_atomic_load(&tile_pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(v & kTileReady)) __builtin_amdgcn_s_sleep(1);
+        } while (!(v & kTileReady));
+        part += (long long)(v & (kTileReady - 1));
+    }
+    const long long base = block_sum_256(part, lds4);
+
     long long run = base + incl - tsum;
     for (int w = 0; w < wave; ++w) run += wsum[w];
     unsigned int local_max = 0;
@@ -532,59 +547,61 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
     }
     if (u0 + 8 >= n_users && u0 < n_users) { // thread holding the last user
         offsets[n_users] = run;
-        summary->m = (unsigned long long)run;
+        __hip_atomic_store(&summary->m, (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local_max = max(local_max, (unsigned)__shfl_xor((int)local_max, o, kWave));
     if (lane == 0 && local_max > 0) atomicMax(&summary->max_count, local_max);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        summary_next->m = 0;
-        summary_next->n_seg = 0;
-        summary_next->n_big = 0;
-        summary_next->max_count = 0;
-        summary_next->bad_rows = 0;
-        summary_next->q = 0;
-        summary_next->live = 0;
+
+    // completion: the last block hands the summary to the host.  Every field was written by device-scope atomics
+    // (or the agent-scope store above), each writer's operations are complete before its block's `done` increment
+    // (vmcnt drain + barrier), and the reader uses agent-scope loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned d = atomicAdd(&ctl->done, 1u);
+        if (d == gridDim.x - 1 && host) {
+            Summary out;
+            out.m = __hip_atomic_load(&summary->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.n_seg = __hip_atomic_load(&summary->n_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.n_big = __hip_atomic_load(&summary->n_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.max_count = __hip_atomic_load(&summary->max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.bad_rows = __hip_atomic_load(&summary->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.q = 0;
+            out.live = __hip_atomic_load(&summary->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host->s = out;
+            __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ K3 scatter
 
 // Records of K1 block b (blk_count[b] of them, in that block's private region) -> bucket slot
-// offsets[user] + rank.  No atomics: the rank came back from K1's histogram atomic.
-// Phase 1: one WAVE per region for the common small regions (one dependent chain per wave, all regions in
-// flight at once).  Phase 2: regions with more than kScatterWaveMax records (a time-ordered table selects
-// whole regions) are walked by a whole block each.
-constexpr int kScatterWaveMax = 1024;
-
-__device__ __forceinline__ void scatter_one(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank, long long at,
-                                            const long long* __restrict__ offsets, long long* __restrict__ bkt_start,
-                                            int* __restrict__ bkt_idx)
-{
-    const SelRec rec = sel[at];
-    const long long pos = offsets[rec.user] + sel_rank[at];
-    bkt_start[pos] = rec.start;
-    bkt_idx[pos] = rec.idx;
-}
-
+// offsets[user] + rank.  No atomics: the rank came back from K1's histogram atomic.  One block per region
+// (grid-stride when there are more regions than blocks): the 256 threads take the region's records in one step
+// in the common case, so the kernel is one dependent chain (count -> record -> offset -> store) deep.
 __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank,
                                                  const int* __restrict__ blk_count, int nb, long long rows_per_block,
                                                  const long long* __restrict__ offsets,
                                                  long long* __restrict__ bkt_start, int* __restrict__ bkt_idx)
 {
-    const int lane = threadIdx.x & 63;
-    const int n_waves = gridDim.x * 4;
-    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nb; b += n_waves) {
-        const int cnt = blk_count[b];
-        if (cnt > kScatterWaveMax) continue;
-        const long long base = (long long)b * rows_per_block;
-        for (int i = lane; i < cnt; i += 64) scatter_one(sel, sel_rank, base + i, offsets, bkt_start, bkt_idx);
-    }
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
-        const int cnt = blk_count[b];
-        if (cnt <= kScatterWaveMax) continue;
         const long long base = (long long)b * rows_per_block;
-        for (int i = threadIdx.x; i < cnt; i += 256) scatter_one(sel, sel_rank, base + i, offsets, bkt_start, bkt_idx);
+        // the first 256 records are fetched without waiting for the count (the region is at least one block tile
+        // long, so the addresses are valid; entries past the count are simply not used)
+        const int cnt = blk_count[b];
+        SelRec rec = sel[base + threadIdx.x];
+        int rank = sel_rank[base + threadIdx.x];
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            if (i >= 256) {
+                rec = sel[base + i];
+                rank = sel_rank[base + i];
+            }
+            const long long pos = offsets[rec.user] + rank;
+            bkt_start[pos] = rec.start;
+            bkt_idx[pos] = rec.idx;
+        }
     }
 }
 
@@ -733,21 +750,24 @@ __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_
 
 // ------------------------------------------------------------------------------------------------ result packing
 
-// One contiguous int32 message for the multi-GPU exchange: [counts[0..U) | 0 .. u_pad) | M | idx[0..min(M,cap))].
-// One launch instead of three D2D copies; the message feeds a single RCCL all-gather.
-__global__ __launch_bounds__(256) void k_pack_results(const int* __restrict__ counts, int n_users, int u_pad,
+// One contiguous int32 message for the multi-GPU exchange:
+//   [ off[0..u_pad] (u_pad+1 entries: exclusive offsets, off[u] = M for u >= U) | M | rows[0..min(M,cap)) ]
+// Offsets instead of counts: the receiver slices Feed(rank, u) = rows[off[u] : off[u+1]] with no prefix sum of its
+// own.  One launch instead of three D2D copies; the message feeds a single RCCL all-gather.
+__global__ __launch_bounds__(256) void k_pack_results(const long long* __restrict__ offsets, int n_users, int u_pad,
                                                       const Summary* __restrict__ summary, const int* __restrict__ out_idx,
                                                       long long cap, int* __restrict__ dst)
 {
     const long long m = (long long)summary->m;
     const long long k = m < cap ? m : cap;
-    const long long total = (long long)u_pad + 1 + k;
+    const long long head = (long long)u_pad + 2;
+    const long long total = head + k;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int v;
-        if (i < n_users) v = counts[i];
-        else if (i < u_pad) v = 0;
-        else if (i == u_pad) v = (int)m;
-        else v = out_idx[i - u_pad - 1];
+        if (i <= n_users) v = (int)offsets[i];
+        else if (i <= u_pad) v = (int)m;
+        else if (i == u_pad + 1) v = (int)m;
+        else v = out_idx[i - head];
         dst[i] = v;
     }
 }

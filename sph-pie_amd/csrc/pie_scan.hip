@@ -1,5 +1,17 @@
 // pie_scan.hip — C ABI (include/pie_scan.h) over the HIP kernels of pie_kernels.h.  gfx950 only.
 // There is no CPU path in this library: every entry point either runs on the GPU or returns an error.
+//
+// One stream, two slots.  A scan is one bandwidth-bound kernel (K1, the table pass) followed by a chain of short
+// latency-bound kernels (K2 offsets, K3 scatter, K4 per-bucket order), all on ONE stream: co-running the chain
+// with the next table pass on other streams was measured and rejected (the chain's dependent loads crawl under
+// a saturated HBM and every cross-queue dependency costs ~15 us: profiles/r01_d_two_stream_timeline.txt).
+// The big per-scan buffers exist twice (two SLOTS) and the small histogram "spans" three times, rotating: K2 of
+// every scan zeroes the span the NEXT scan will use (whose consumers are two scans old), so no memset and no
+// event sits between kernels — a marker packet between two kernels costs ~6 us here, a plain kernel boundary ~0.
+// pie_scan_begin enqueues K1+K2 and returns; pie_scan_finish spins on the summary that K2's last block writes to
+// mapped host memory, then enqueues K3/K4 sized from it.  With begin(i+1) called before finish(i) the stream
+// always holds the next table pass, so the host's round trip (summary -> K3/K4 launch) is off the critical path:
+//   stream:  K1(i) K2(i) | K1(i+1) K2(i+1) | K3(i) K4(i) consumers(i) | K1(i+2) K2(i+2) | K3(i+1) ...
 #include "../../include/pie_scan.h"
 #include "pie_kernels.h"
 
@@ -18,10 +30,38 @@ namespace {
 thread_local char g_create_error[256] = "";
 
 struct ScanEvents {
-    hipEvent_t e0, e1, e2; // before first kernel, after K1, after last kernel
+    hipEvent_t e0, e1, e2; // before K1, after K1, after the last kernel of the tail
 };
 
 constexpr int kEventRing = 2048;
+
+// everything one scan owns
+struct Slot {
+    int* counts = nullptr;         // the span this scan uses: counts[cap_users] | tile_pub[] | ScanCtl | Summary
+    unsigned long long* tile_pub = nullptr;
+    ScanCtl* ctl = nullptr;
+    Summary* sum = nullptr;
+    HostSummary* h_sum = nullptr;     // mapped pinned memory: written by K2's last block
+    HostSummary* h_sum_dev = nullptr; // the same memory as the device sees it
+    unsigned long long seq = 0;       // value h_sum->seq takes when this slot's scan has its summary
+    long long* offsets = nullptr;
+    SelRec* sel = nullptr;
+    int* sel_rank = nullptr;
+    int* blk_count = nullptr;
+    long long* bkt_start = nullptr;
+    int* bkt_idx = nullptr;
+    int* out_idx = nullptr;
+    Segment* seg_list = nullptr;
+    int* big_list = nullptr;
+    // per-scan host state
+    bool in_flight = false;
+    bool have_result = false;
+    Summary last{};
+    int k1_blocks = 0;
+    long long rows_per_block = 0;
+    int variant = 0;
+    int ev_index = -1; // index into the event ring, -1 = not profiled
+};
 
 } // namespace
 
@@ -29,7 +69,8 @@ struct pie_ctx {
     int device = -1;
     int n_cus = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // main stream (own_stream or the caller's)
+    unsigned long long seq_counter = 0;
     char err[512] = "";
 
     // resident table
@@ -44,39 +85,28 @@ struct pie_ctx {
     unsigned long long disc_mask = ~0ull;
     int n_disc = 64;
 
-    // scan workspace
-    int k1_blocks = 0;            // plan in use by the last / current scan
-    long long rows_per_block = 0;
-    int plan_blocks[2] = {0, 0};  // [0] streaming form, [1] liveness-first form
+    // scan plans: [0] streaming form, [1] liveness-first form
+    int plan_blocks[2] = {0, 0};
     long long plan_rows[2] = {0, 0};
     int n_tiles = 0;
-    int* d_counts2[2] = {nullptr, nullptr}; // ping-pong: K2b of scan i clears the buffer of scan i+1
-    int* d_counts = nullptr;                 // buffer holding the last scan's counts
-    int cur = 0;
-    int* d_sel_rank = nullptr;
     int k1_variant = 0x03;    // streaming form: nontemporal loads + late user materialisation
     int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
     bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
-    int last_variant = 0;
-    double live_frac = -1;    // live fraction seen by the previous scan of this table (-1: none yet)
-    long long* d_offsets = nullptr;
-    long long* d_tile_sum = nullptr;
-    SelRec* d_sel = nullptr;
-    int* d_blk_count = nullptr;
+    double live_frac = -1;    // live fraction seen by the last finished scan of this table (-1: none yet)
+
+    Slot slot[2];
+    char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
+    int span_next = 0;
+    int profile_every = 1;   // with profiling on, every n-th scan carries timing events
+    unsigned long long scans_begun = 0;
+    int next_slot = 0;   // slot the next pie_scan_begin uses
+    int n_flight = 0;    // scans begun and not finished (0..2)
+    Slot* res = nullptr; // last finished scan (results)
+
+    // shared scratch
     long long* d_blk_off = nullptr;
-    long long* d_bkt_start = nullptr;
-    int* d_bkt_idx = nullptr;
-    int* d_out_idx = nullptr;
-    Segment* d_seg_list = nullptr;
-    int* d_big_list = nullptr;
-    Summary* d_summary = nullptr;            // scratch for table maintenance calls
-    Summary* d_sum2[2] = {nullptr, nullptr}; // per-scan summaries, ping-pong like counts
+    Summary* d_summary = nullptr; // table-maintenance calls
     Summary* h_summary = nullptr; // pinned
-    hipEvent_t ev_summary = nullptr;
-    bool have_scan = false;
-    bool in_flight = false;        // between pie_scan_begin and pie_scan_finish
-    ScanEvents* flight_ev = nullptr;
-    Summary last{};
 
     // profiling
     bool profiling = false;
@@ -113,14 +143,41 @@ void dfree(T*& p)
     p = nullptr;
 }
 
+// scans in flight are the last n_flight slots handed out; this is the older one
+Slot* oldest_in_flight(pie_ctx* c)
+{
+    if (c->n_flight == 0) return nullptr;
+    return &c->slot[c->n_flight == 2 ? c->next_slot : (c->next_slot ^ 1)];
+}
+
+void free_slots(pie_ctx* c)
+{
+    for (Slot& s : c->slot) {
+        s.counts = nullptr; s.sum = nullptr;
+        s.tile_pub = nullptr; s.ctl = nullptr;
+        dfree(s.offsets); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
+        dfree(s.bkt_start); dfree(s.bkt_idx); dfree(s.out_idx); dfree(s.seg_list); dfree(s.big_list);
+        s.in_flight = s.have_result = false;
+    }
+    for (char*& sp : c->span) dfree(sp);
+    c->span_next = 0;
+    c->res = nullptr;
+    c->n_flight = 0;
+    c->next_slot = 0;
+}
+
 void free_table(pie_ctx* c)
 {
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc);
-    dfree(c->d_counts2[0]); dfree(c->d_counts2[1]); c->d_counts = nullptr; dfree(c->d_offsets); dfree(c->d_tile_sum);
-    dfree(c->d_sel); dfree(c->d_sel_rank); dfree(c->d_blk_count); dfree(c->d_blk_off);
-    dfree(c->d_bkt_start); dfree(c->d_bkt_idx); dfree(c->d_out_idx);
-    dfree(c->d_seg_list); dfree(c->d_big_list);
-    c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0; c->have_scan = false;
+    dfree(c->d_blk_off);
+    free_slots(c);
+    c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0;
+}
+
+int sync_all(pie_ctx* c)
+{
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
 }
 
 // Grid of the scan kernel: every block owns a contiguous, tile-aligned row range.  Two plans, measured on
@@ -144,18 +201,16 @@ void plan_one(pie_ctx* c, int which, long long want, const char* env)
     if (c->plan_blocks[which] < 1) c->plan_blocks[which] = 1;
 }
 
-void use_plan(pie_ctx* c, int which)
-{
-    c->k1_blocks = c->plan_blocks[which];
-    c->rows_per_block = c->plan_rows[which];
-}
-
 void plan_k1(pie_ctx* c)
 {
     plan_one(c, 0, (long long)c->n_cus * 48, "PIE_K1_BLOCKS");
     plan_one(c, 1, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_LIVE");
-    use_plan(c, 0);
 }
+
+// layout of a slot's span (all parts 64-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
+size_t span_counts_bytes(const pie_ctx* c) { return (((size_t)c->cap_users * 4 + 63) / 64) * 64; }
+size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / kScanTile + 2) * 8 + 63) / 64) * 64; }
+size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_bytes(c) + 64 + ((sizeof(Summary) + 63) / 64) * 64; }
 
 // Make room for n rows / n_users users.  keep_rows > 0: the first keep_rows rows of the resident columns survive
 // a re-allocation (append path; capacity grows geometrically so appends are amortised O(1) per row).
@@ -163,6 +218,9 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
 {
     if (n < 0 || n >= (1LL << 31)) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31)", n);
     if (n_users < 1) return fail(c, PIE_E_INVAL, "n_users must be >= 1 (got %d)", n_users);
+    if (c->n_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
+    int rc = sync_all(c);
+    if (rc) return rc;
     long long rows = n > 0 ? n : 1;
     if (rows > c->cap_rows || n_users > c->cap_users) {
         int users = n_users;
@@ -190,35 +248,33 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             PIE_HIP(c, hipStreamSynchronize(c->stream));
             (void)hipFree(old_s); (void)hipFree(old_e); (void)hipFree(old_u); (void)hipFree(old_d);
         }
-        PIE_HIP(c, hipMalloc(&c->d_sel, rows * sizeof(SelRec)));
-        PIE_HIP(c, hipMalloc(&c->d_sel_rank, rows * 4));
-        PIE_HIP(c, hipMalloc(&c->d_bkt_start, rows * 8));
-        PIE_HIP(c, hipMalloc(&c->d_bkt_idx, rows * 4));
-        PIE_HIP(c, hipMalloc(&c->d_out_idx, rows * 4));
-        const long long max_blocks = rows / (kUnitRows * 2 * kK1Waves) + 2;
-        PIE_HIP(c, hipMalloc(&c->d_blk_count, max_blocks * 4));
+        const long long max_blocks = rows / (kUnitRows * 8 * kK1Waves) + 2;
         PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks + 1) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_counts2[0], (size_t)users * 4 + 32));
-        PIE_HIP(c, hipMalloc(&c->d_counts2[1], (size_t)users * 4 + 32));
-        PIE_HIP(c, hipMalloc(&c->d_offsets, ((size_t)users + 1) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_tile_sum, ((size_t)users / kScanTile + 2) * 8));
-        PIE_HIP(c, hipMalloc(&c->d_seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
-        PIE_HIP(c, hipMalloc(&c->d_big_list, ((size_t)users + 16) * 4));
+        c->cap_users = users; // counts_span() below reads it
+        for (Slot& s : c->slot) {
+            PIE_HIP(c, hipMalloc(&s.offsets, ((size_t)users + 1) * 8));
+            // +256: K3 fetches a region's first 256 records before it knows the count
+            PIE_HIP(c, hipMalloc(&s.sel, (rows + 256) * sizeof(SelRec)));
+            PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
+            PIE_HIP(c, hipMalloc(&s.blk_count, max_blocks * 4));
+            PIE_HIP(c, hipMalloc(&s.bkt_start, rows * 8));
+            PIE_HIP(c, hipMalloc(&s.bkt_idx, rows * 4));
+            PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
+            PIE_HIP(c, hipMalloc(&s.seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
+            PIE_HIP(c, hipMalloc(&s.big_list, ((size_t)users + 16) * 4));
+        }
+        for (char*& sp : c->span) PIE_HIP(c, hipMalloc(&sp, counts_span(c)));
         c->cap_rows = rows;
-        c->cap_users = users;
     }
     c->n = n;
     c->n_users = n_users;
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
-    c->have_scan = false;
     c->live_frac = -1;
-    c->cur = 0;
-    c->d_counts = c->d_counts2[0];
-    // both ping-pong buffers start clean; afterwards every scan's K2b clears the next scan's buffers
-    PIE_HIP(c, hipMemsetAsync(c->d_counts2[0], 0, (size_t)c->cap_users * 4, c->stream));
-    PIE_HIP(c, hipMemsetAsync(c->d_counts2[1], 0, (size_t)c->cap_users * 4, c->stream));
-    PIE_HIP(c, hipMemsetAsync(c->d_sum2[0], 0, sizeof(Summary), c->stream));
-    PIE_HIP(c, hipMemsetAsync(c->d_sum2[1], 0, sizeof(Summary), c->stream));
+    c->res = nullptr;
+    for (Slot& s : c->slot) s.have_result = false;
+    // all three spans start clean; from here on every K2 zeroes the span of the scan after it
+    for (char* sp : c->span) PIE_HIP(c, hipMemsetAsync(sp, 0, counts_span(c), c->stream));
+    c->span_next = 0;
     plan_k1(c);
     return PIE_OK;
 }
@@ -241,7 +297,9 @@ int validate_users(pie_ctx* c, long long row0 = 0)
 int resolve_events(pie_ctx* c)
 {
     if (c->ring_used == 0) return PIE_OK;
-    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->n_flight) return PIE_OK; // events of scans in flight are not closed yet; resolved on a later call
+    int rc = sync_all(c);
+    if (rc) return rc;
     for (int i = 0; i < c->ring_used; ++i) {
         float k1 = 0, all = 0;
         PIE_HIP(c, hipEventElapsedTime(&k1, c->ring[i].e0, c->ring[i].e1));
@@ -260,18 +318,17 @@ int resolve_events(pie_ctx* c)
 // previous scan on this table observed: liveness-first below kLiveFirstBelow, the streaming form above.
 constexpr double kLiveFirstBelow = 0.10; // measured crossover ~0.16 live (profiles/r01_c_live_fraction_crossover.txt)
 
-void launch_k1(pie_ctx* c, hipStream_t s, int variant, long long now, long long cutoff, unsigned long long mask,
-               int* counts, Summary* sum)
+void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cutoff, unsigned long long mask)
 {
 #define PIE_K1(UN, NT, LU)                                                                                          \
-    hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
-                       c->d_user, c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, counts, c->d_sel, \
-                       c->d_sel_rank, c->d_blk_count, sum)
+    hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+                       c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
+                       sl.sel_rank, sl.blk_count, sl.sum)
 #define PIE_K1L(UN, NT)                                                                                             \
-    hipLaunchKernelGGL((k_scan_live_first<UN, NT>), dim3(c->k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
-                       c->d_user, c->d_disc, c->n, c->rows_per_block, now, cutoff, mask, c->n_users, counts, c->d_sel, \
-                       c->d_sel_rank, c->d_blk_count, sum)
-    switch (variant) {
+    hipLaunchKernelGGL((k_scan_live_first<UN, NT>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+                       c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
+                       sl.sel_rank, sl.blk_count, sl.sum)
+    switch (sl.variant) {
     case 0x00: PIE_K1(4, false, false); break;
     case 0x01: PIE_K1(4, true, false); break;
     case 0x02: PIE_K1(4, false, true); break;
@@ -290,146 +347,179 @@ void launch_k1(pie_ctx* c, hipStream_t s, int variant, long long now, long long 
     case 0x81: PIE_K1(8, true, false); break;
     case 0x82: PIE_K1(8, false, true); break;
     case 0x83: PIE_K1(8, true, true); break;
-    default: PIE_K1(4, true, true); break;
+    default: sl.variant = 0x03; PIE_K1(4, true, true); break;
     }
 #undef PIE_K1
 #undef PIE_K1L
 }
 
-// The scan in two halves.  scan_begin enqueues every kernel of the common path (K1..K4) and returns at once;
-// scan_finish waits for the 40-byte summary that K2b produced (K3/K4 are already queued behind it, so the GPU
-// never waits for the host), runs the rare big-bucket merge passes, and closes the timing events.  A caller
-// that has host work to do per step (the multi-GPU exchange) does it between the two halves.
+// Head of a scan: K1 and K2 on the stream.  No host wait.
 int scan_begin(pie_ctx* c, long long now, long long cutoff)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
-    if (c->in_flight) return fail(c, PIE_E_STATE, "pie_scan_begin while a scan is in flight");
+    if (c->n_flight >= 2) return fail(c, PIE_E_STATE, "two scans are already in flight: call pie_scan_finish first");
+    Slot& sl = c->slot[c->next_slot];
     hipStream_t s = c->stream;
-    ScanEvents* ev = nullptr;
-    if (c->profiling) {
+    sl.ev_index = -1;
+    if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
         if (c->ring_used == kEventRing) {
             int rc = resolve_events(c);
             if (rc) return rc;
         }
-        if ((int)c->ring.size() <= c->ring_used) {
-            ScanEvents e{};
-            PIE_HIP(c, hipEventCreate(&e.e0));
-            PIE_HIP(c, hipEventCreate(&e.e1));
-            PIE_HIP(c, hipEventCreate(&e.e2));
-            c->ring.push_back(e);
+        if (c->ring_used < kEventRing) {
+            if ((int)c->ring.size() <= c->ring_used) {
+                ScanEvents e{};
+                PIE_HIP(c, hipEventCreate(&e.e0));
+                PIE_HIP(c, hipEventCreate(&e.e1));
+                PIE_HIP(c, hipEventCreate(&e.e2));
+                c->ring.push_back(e);
+            }
+            sl.ev_index = c->ring_used++;
         }
-        ev = &c->ring[c->ring_used];
     }
     const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
+    sl.variant = c->k1_variant;
+    if (!c->k1_pinned && c->live_frac >= 0) sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+    const int plan = (sl.variant & 4) ? 1 : 0;
+    sl.k1_blocks = c->plan_blocks[plan];
+    sl.rows_per_block = c->plan_rows[plan];
+    sl.have_result = false;
+    if (c->res == &sl) c->res = nullptr;
 
-    int* counts = c->d_counts2[c->cur];
-    int* counts_next = c->d_counts2[c->cur ^ 1];
-    Summary* sum = c->d_sum2[c->cur];
-    Summary* sum_next = c->d_sum2[c->cur ^ 1];
-    if (ev) PIE_HIP(c, hipEventRecord(ev->e0, s));
-    int variant = c->k1_variant;
-    c->last_variant = 0;
-    if (!c->k1_pinned && c->live_frac >= 0) variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
-    use_plan(c, (variant & 4) ? 1 : 0);
-    launch_k1(c, s, variant, now, cutoff, mask, counts, sum);
-    c->last_variant = variant;
-    if (ev) PIE_HIP(c, hipEventRecord(ev->e1, s));
-    hipLaunchKernelGGL(k_tile_sums, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum);
-    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, counts, c->n_users, c->d_tile_sum, c->d_offsets,
-                       c->d_seg_list, c->d_big_list, sum, counts_next, sum_next);
-    PIE_HIP(c, hipMemcpyAsync(c->h_summary, sum, sizeof(Summary), hipMemcpyDeviceToHost, s));
-    if (!c->ev_summary) PIE_HIP(c, hipEventCreateWithFlags(&c->ev_summary, hipEventDisableTiming));
-    PIE_HIP(c, hipEventRecord(c->ev_summary, s));
-
-    int scat_blocks = (c->k1_blocks + 3) / 4;
-    if (scat_blocks > c->n_cus * 8) scat_blocks = c->n_cus * 8;
-    hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, s, c->d_sel, c->d_sel_rank, c->d_blk_count,
-                       c->k1_blocks, c->rows_per_block, c->d_offsets, c->d_bkt_start, c->d_bkt_idx);
-    const int tiny_blocks = (c->n_users + 255) / 256;
-    hipLaunchKernelGGL(k_sort_buckets, dim3(tiny_blocks + c->n_cus * 3), dim3(256), 0, s, counts, c->d_offsets,
-                       c->n_users, tiny_blocks, c->d_seg_list, sum, c->d_bkt_start, c->d_bkt_idx, c->d_out_idx);
-    c->d_counts = counts;
-    c->cur ^= 1;
+    // this scan's histogram span (zeroed by the previous scan's K2, or by the load) and the one K2 will zero
+    {
+        char* base = c->span[c->span_next];
+        sl.counts = reinterpret_cast<int*>(base);
+        sl.tile_pub = reinterpret_cast<unsigned long long*>(base + span_counts_bytes(c));
+        sl.ctl = reinterpret_cast<ScanCtl*>(base + span_counts_bytes(c) + span_tiles_bytes(c));
+        sl.sum = reinterpret_cast<Summary*>(base + span_counts_bytes(c) + span_tiles_bytes(c) + 64);
+        c->span_next = (c->span_next + 1) % 3;
+    }
+    int4* zero_span = reinterpret_cast<int4*>(c->span[c->span_next]);
+    c->scans_begun++;
+    if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e0, s));
+    launch_k1(c, sl, s, now, cutoff, mask);
+    if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e1, s));
+    sl.seq = ++c->seq_counter;
+    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl, sl.offsets,
+                       sl.seg_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, (long long)(counts_span(c) / 16));
     PIE_HIP(c, hipGetLastError());
-    c->in_flight = true;
-    c->have_scan = false;
-    c->flight_ev = ev;
+    sl.in_flight = true;
+    c->n_flight++;
+    c->next_slot ^= 1;
     return PIE_OK;
 }
 
+// Tail of the oldest scan in flight: wait for its summary, then scatter + per-bucket order
+// (plus the merge passes of big buckets, sized from the summary).
 int scan_finish(pie_ctx* c)
 {
-    if (!c->in_flight) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
-    hipStream_t s = c->stream;
-    ScanEvents* ev = c->flight_ev;
-    c->in_flight = false;
-    PIE_HIP(c, hipEventSynchronize(c->ev_summary));
-    c->last = *c->h_summary;
-    c->live_frac = c->n > 0 ? (double)c->last.live / (double)c->n : 0.0;
-    if (c->last.n_big > 0) {
-        // big buckets: tiles of kSegMax are sorted in place by K4b; merge passes ping-pong between the bucket
-        // arrays and scratch carved out of the (now consumed) record staging; the last pass lands in out_idx.
-        long long* tmp_s = reinterpret_cast<long long*>(c->d_sel);
+    Slot* slp = oldest_in_flight(c);
+    if (!slp) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
+    Slot& sl = *slp;
+    hipStream_t a = c->stream;
+    sl.in_flight = false;
+    c->n_flight--;
+    // wait for K2's last block to publish the summary in mapped host memory (no copy node, no event wait);
+    // the event is only the fallback if the mapped write is not observed
+    {
+        volatile unsigned long long* seq = &sl.h_sum->seq;
+        unsigned long long spins = 0;
+        while (*seq != sl.seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0) { // ~every few ms: make sure the stream is still healthy
+                hipError_t q = hipStreamQuery(c->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(c, PIE_E_HIP, "scan failed: %s", hipGetErrorString(q));
+                if (q == hipSuccess && *seq != sl.seq) {
+                    // the stream drained but the mapped write is not visible: read the device copy instead
+                    PIE_HIP(c, hipMemcpy(&sl.h_sum->s, sl.sum, sizeof(Summary), hipMemcpyDeviceToHost));
+                    break;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    sl.last = sl.h_sum->s;
+    c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
+
+    if (sl.last.m > 0) {
+        int scat_blocks = sl.k1_blocks;
+        if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
+        hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
+                           sl.rows_per_block, sl.offsets, sl.bkt_start, sl.bkt_idx);
+        const int tiny_blocks = (c->n_users + 255) / 256;
+        const int seg_blocks = sl.last.n_seg < (unsigned)(c->n_cus * 3) ? (int)sl.last.n_seg : c->n_cus * 3;
+        hipLaunchKernelGGL(k_sort_buckets, dim3(tiny_blocks + seg_blocks), dim3(256), 0, a, sl.counts, sl.offsets,
+                           c->n_users, tiny_blocks, sl.seg_list, sl.sum, sl.bkt_start, sl.bkt_idx, sl.out_idx);
+    }
+    if (sl.last.n_big > 0) {
+        // big buckets: tiles of kSegMax were sorted in place by K4; merge passes ping-pong between the bucket
+        // arrays and scratch carved out of this slot's (now consumed) record staging; the last pass lands in out_idx.
+        long long* tmp_s = reinterpret_cast<long long*>(sl.sel);
         int* tmp_i = reinterpret_cast<int*>(tmp_s + c->cap_rows);
         int passes = 0;
-        for (long long w = kSegMax; w < (long long)c->last.max_count; w <<= 1) ++passes;
+        for (long long w = kSegMax; w < (long long)sl.last.max_count; w <<= 1) ++passes;
         bool in_bkt = true; // which buffer pair holds the current runs
         long long w = kSegMax;
         for (int p = 0; p < passes; ++p, w <<= 1) {
-            const long long* src_s = in_bkt ? c->d_bkt_start : tmp_s;
-            const int* src_i = in_bkt ? c->d_bkt_idx : tmp_i;
-            long long* dst_s = in_bkt ? tmp_s : c->d_bkt_start;
-            int* dst_i = (p == passes - 1) ? c->d_out_idx : (in_bkt ? tmp_i : c->d_bkt_idx);
-            const unsigned gx = (unsigned)((c->last.max_count + 255u) / 256u);
-            const unsigned gy = c->last.n_big < 65535u ? c->last.n_big : 65535u;
-            hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, s, c->d_big_list,
-                               (int)c->last.n_big, c->d_counts, c->d_offsets, w, src_s, src_i, dst_s, dst_i);
+            const long long* src_s = in_bkt ? sl.bkt_start : tmp_s;
+            const int* src_i = in_bkt ? sl.bkt_idx : tmp_i;
+            long long* dst_s = in_bkt ? tmp_s : sl.bkt_start;
+            int* dst_i = (p == passes - 1) ? sl.out_idx : (in_bkt ? tmp_i : sl.bkt_idx);
+            const unsigned gx = (unsigned)((sl.last.max_count + 255u) / 256u);
+            const unsigned gy = sl.last.n_big < 65535u ? sl.last.n_big : 65535u;
+            hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, a, sl.big_list,
+                               (int)sl.last.n_big, sl.counts, sl.offsets, w, src_s, src_i, dst_s, dst_i);
             in_bkt = !in_bkt;
         }
-        PIE_HIP(c, hipGetLastError());
     }
-    if (ev) {
-        PIE_HIP(c, hipEventRecord(ev->e2, s));
-        c->ring_used++;
-    }
-    c->have_scan = true;
-    if (c->last.bad_rows)
-        return fail(c, PIE_E_INVAL, "%u selected rows carry a user id outside [0, %d)", c->last.bad_rows, c->n_users);
+    PIE_HIP(c, hipGetLastError());
+    if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, a));
+    sl.have_result = true;
+    c->res = &sl;
+    if (sl.last.bad_rows)
+        return fail(c, PIE_E_INVAL, "%u selected rows carry a user id outside [0, %d)", sl.last.bad_rows, c->n_users);
     return PIE_OK;
 }
 
 int run_scan(pie_ctx* c, long long now, long long cutoff)
 {
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight: finish it first");
     int rc = scan_begin(c, now, cutoff);
     if (rc) return rc;
     return scan_finish(c);
 }
 
-// ordered list of the rows matching a one-column predicate (expired queue / user match), through the
-// scan workspace: blk_count + blk_off for the per-block prefix, out_idx as the device-side list
+// ordered list of the rows matching a one-column predicate (expired queue / user match), through slot 0's
+// workspace: blk_count + blk_off for the per-block prefix, out_idx as the device-side list
 template <int MODE>
 int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap, size_t* k_out)
 {
     if (k_out) *k_out = 0;
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n == 0) return PIE_OK;
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     PIE_HIP(c, hipSetDevice(c->device));
+    int rc = sync_all(c); // the workspace below is shared with the scans' tails
+    if (rc) return rc;
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(k_list_count<MODE>, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n,
-                       c->rows_per_block, a, b, c->d_blk_count);
-    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, c->d_blk_count, c->k1_blocks, c->d_blk_off,
-                       &c->d_summary->m);
-    hipLaunchKernelGGL(k_list_write<MODE>, dim3(c->k1_blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n,
-                       c->rows_per_block, a, b, c->d_blk_off, c->d_out_idx, c->cap_rows);
+    Slot& sl = c->slot[0];
+    sl.have_result = false;
+    if (c->res == &sl) c->res = nullptr;
+    const int blocks = c->plan_blocks[0];
+    const long long rpb = c->plan_rows[0];
+    hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, a, b, sl.blk_count);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
+    hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, a, b,
+                       c->d_blk_off, sl.out_idx, c->cap_rows);
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
     PIE_HIP(c, hipStreamSynchronize(s));
-    c->have_scan = false;
     const size_t k = (size_t)c->h_summary->m;
     if (k_out) *k_out = k;
     if (out && k > cap) return fail(c, PIE_E_CAPACITY, "list cap %zu < %zu", cap, k);
     if (out && k) {
-        PIE_HIP(c, hipMemcpyAsync(out, c->d_out_idx, k * 4, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipMemcpyAsync(out, sl.out_idx, k * 4, hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
     }
     return PIE_OK;
@@ -471,13 +561,17 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
         return fail(nullptr, PIE_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&c->d_summary, sizeof(Summary))) != hipSuccess ||
-        (e = hipMalloc(&c->d_sum2[0], sizeof(Summary))) != hipSuccess ||
-        (e = hipMalloc(&c->d_sum2[1], sizeof(Summary))) != hipSuccess ||
-        (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) != hipSuccess) {
+    bool ok = (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) == hipSuccess &&
+              (e = hipMalloc(&c->d_summary, sizeof(Summary))) == hipSuccess &&
+              (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) == hipSuccess;
+    for (Slot& s : c->slot) {
+        ok = ok && (e = hipHostMalloc(&s.h_sum, sizeof(HostSummary), hipHostMallocMapped)) == hipSuccess &&
+             (e = hipHostGetDevicePointer((void**)&s.h_sum_dev, s.h_sum, 0)) == hipSuccess;
+        if (ok) memset(s.h_sum, 0, sizeof(HostSummary));
+    }
+    if (!ok) {
         fail(nullptr, PIE_E_NODEVICE, "context setup: %s", hipGetErrorString(e));
-        delete c;
+        delete c; // the few handles created so far go with the process: it has no usable GPU anyway
         return PIE_E_NODEVICE;
     }
     c->stream = c->own_stream;
@@ -496,10 +590,10 @@ int pie_ctx_destroy(pie_ctx* c)
     for (auto& e : c->ring) {
         (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2);
     }
-    if (c->ev_summary) (void)hipEventDestroy(c->ev_summary);
+    for (Slot& s : c->slot) {
+        if (s.h_sum) (void)hipHostFree(s.h_sum);
+    }
     if (c->d_summary) (void)hipFree(c->d_summary);
-    if (c->d_sum2[0]) (void)hipFree(c->d_sum2[0]);
-    if (c->d_sum2[1]) (void)hipFree(c->d_sum2[1]);
     if (c->h_summary) (void)hipHostFree(c->h_summary);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -509,8 +603,17 @@ int pie_ctx_destroy(pie_ctx* c)
 int pie_ctx_set_stream(pie_ctx* c, void* hip_stream)
 {
     if (!c) return PIE_E_INVAL;
-    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    int rc = sync_all(c);
+    if (rc) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PIE_OK;
+}
+
+int pie_ctx_aux_stream(pie_ctx* c, void** hip_stream_out)
+{
+    if (!c || !hip_stream_out) return PIE_E_INVAL;
+    *hip_stream_out = (void*)c->stream;
     return PIE_OK;
 }
 
@@ -529,7 +632,7 @@ int pie_load_columns(pie_ctx* c, const int64_t* start, const int64_t* end, const
         PIE_HIP(c, hipMemcpyAsync(c->d_disc, disc, n * 4, hipMemcpyHostToDevice, c->stream));
     }
     rc = validate_users(c);
-    if (rc) { c->n = 0; return rc; }
+    if (rc) { c->n = 0; plan_k1(c); return rc; }
     return PIE_OK;
 }
 
@@ -592,6 +695,7 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     if (!c) return PIE_E_INVAL;
     if (k == 0) return PIE_OK;
     if (!rows || !new_end) return fail(c, PIE_E_INVAL, "NULL pointer");
+    if (c->n_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     for (size_t i = 0; i < k; ++i)
         if (rows[i] < 0 || rows[i] >= c->n) return fail(c, PIE_E_INVAL, "row %d outside the table", rows[i]);
     PIE_HIP(c, hipSetDevice(c->device));
@@ -608,7 +712,6 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     (void)hipFree(d_rows);
     (void)hipFree(d_new);
     if (e != hipSuccess) return fail(c, PIE_E_HIP, "pie_set_end: %s", hipGetErrorString(e));
-    c->have_scan = false;
     return PIE_OK;
 }
 
@@ -635,7 +738,7 @@ int pie_scan_device(pie_ctx* c, int64_t now, int64_t cutoff, size_t* m_out)
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = run_scan(c, now, cutoff);
-    if (m_out) *m_out = (size_t)c->last.m;
+    if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
     return rc;
 }
 
@@ -651,7 +754,7 @@ int pie_scan_finish(pie_ctx* c, size_t* m_out)
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = scan_finish(c);
-    if (m_out) *m_out = (size_t)c->last.m;
+    if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
     return rc;
 }
 
@@ -661,57 +764,60 @@ int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = run_scan(c, now, cutoff);
-    const size_t m = (size_t)c->last.m;
+    const size_t m = c->res ? (size_t)c->res->last.m : 0;
     if (m_out) *m_out = m;
     if (rc) return rc;
-    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, c->d_counts, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, c->stream));
-    if (offsets_out)
-        PIE_HIP(c, hipMemcpyAsync(offsets_out, c->d_offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    Slot& sl = *c->res;
+    hipStream_t a = c->stream;
+    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, sl.counts, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, a));
+    if (offsets_out) PIE_HIP(c, hipMemcpyAsync(offsets_out, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, a));
     if (idx_out && m > idx_cap) {
-        PIE_HIP(c, hipStreamSynchronize(c->stream));
+        PIE_HIP(c, hipStreamSynchronize(a));
         return fail(c, PIE_E_CAPACITY, "idx_cap %zu < selected rows %zu", idx_cap, m);
     }
-    if (idx_out && m) PIE_HIP(c, hipMemcpyAsync(idx_out, c->d_out_idx, m * 4, hipMemcpyDeviceToHost, c->stream));
-    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (idx_out && m) PIE_HIP(c, hipMemcpyAsync(idx_out, sl.out_idx, m * 4, hipMemcpyDeviceToHost, a));
+    PIE_HIP(c, hipStreamSynchronize(a));
     return PIE_OK;
 }
 
 int pie_result_device_ptrs(pie_ctx* c, void** counts_dev, void** offsets_dev, void** idx_dev)
 {
     if (!c) return PIE_E_INVAL;
-    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
-    if (counts_dev) *counts_dev = c->d_counts;
-    if (offsets_dev) *offsets_dev = c->d_offsets;
-    if (idx_dev) *idx_dev = c->d_out_idx;
+    if (!c->res || !c->res->have_result) return fail(c, PIE_E_STATE, "no scan result on this context");
+    if (counts_dev) *counts_dev = c->res->counts;
+    if (offsets_dev) *offsets_dev = c->res->offsets;
+    if (idx_dev) *idx_dev = c->res->out_idx;
     return PIE_OK;
 }
 
 int pie_copy_results_device(pie_ctx* c, void* counts_dst, void* offsets_dst, void* idx_dst, size_t idx_cap)
 {
     if (!c) return PIE_E_INVAL;
-    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
+    if (!c->res || !c->res->have_result) return fail(c, PIE_E_STATE, "no scan result on this context");
     PIE_HIP(c, hipSetDevice(c->device));
-    if (counts_dst)
-        PIE_HIP(c, hipMemcpyAsync(counts_dst, c->d_counts, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, c->stream));
+    Slot& sl = *c->res;
+    hipStream_t a = c->stream;
+    if (counts_dst) PIE_HIP(c, hipMemcpyAsync(counts_dst, sl.counts, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, a));
     if (offsets_dst)
-        PIE_HIP(c, hipMemcpyAsync(offsets_dst, c->d_offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
-    size_t m = (size_t)c->last.m;
+        PIE_HIP(c, hipMemcpyAsync(offsets_dst, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, a));
+    size_t m = (size_t)sl.last.m;
     if (m > idx_cap) m = idx_cap;
-    if (idx_dst && m) PIE_HIP(c, hipMemcpyAsync(idx_dst, c->d_out_idx, m * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (idx_dst && m) PIE_HIP(c, hipMemcpyAsync(idx_dst, sl.out_idx, m * 4, hipMemcpyDeviceToDevice, a));
     return PIE_OK;
 }
 
 int pie_pack_results_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t idx_cap)
 {
     if (!c) return PIE_E_INVAL;
-    if (!c->have_scan) return fail(c, PIE_E_STATE, "no scan result on this context");
+    if (!c->res || !c->res->have_result) return fail(c, PIE_E_STATE, "no scan result on this context");
     if (!dst_i32 || u_pad < (size_t)c->n_users) return fail(c, PIE_E_INVAL, "bad pack destination / u_pad < n_users");
     PIE_HIP(c, hipSetDevice(c->device));
-    const size_t total = u_pad + 1 + ((size_t)c->last.m < idx_cap ? (size_t)c->last.m : idx_cap);
+    Slot& sl = *c->res;
+    const size_t total = u_pad + 2 + ((size_t)sl.last.m < idx_cap ? (size_t)sl.last.m : idx_cap);
     size_t grid = (total + 255) / 256;
     if (grid > (size_t)c->n_cus * 8) grid = (size_t)c->n_cus * 8;
-    hipLaunchKernelGGL(k_pack_results, dim3((unsigned)grid), dim3(256), 0, c->stream, c->d_counts, c->n_users, (int)u_pad,
-                       c->d_sum2[c->cur ^ 1], c->d_out_idx, (long long)idx_cap, (int*)dst_i32);
+    hipLaunchKernelGGL(k_pack_results, dim3((unsigned)grid), dim3(256), 0, c->stream, sl.offsets, c->n_users, (int)u_pad,
+                       sl.sum, sl.out_idx, (long long)idx_cap, (int*)dst_i32);
     PIE_HIP(c, hipGetLastError());
     return PIE_OK;
 }
@@ -723,7 +829,7 @@ int pie_fetch_rows(pie_ctx* c, const int32_t* idx, size_t m, int64_t* start, int
     if (!idx) return fail(c, PIE_E_INVAL, "idx is NULL");
     if (c->n == 0) return fail(c, PIE_E_STATE, "no table loaded");
     PIE_HIP(c, hipSetDevice(c->device));
-    // device scratch: [idx m*4][start m*8][end m*8][user m*4][disc m*4]
+    // device scratch: [start m*8][end m*8][user m*4][disc m*4][idx m*4]
     char* d = nullptr;
     const size_t bytes = m * 28 + 64;
     PIE_HIP(c, hipMalloc(&d, bytes));
@@ -759,6 +865,7 @@ int pie_set_profiling(pie_ctx* c, int enabled)
 {
     if (!c) return PIE_E_INVAL;
     c->profiling = enabled != 0;
+    c->profile_every = enabled > 1 ? enabled : 1;
     return PIE_OK;
 }
 
@@ -769,20 +876,21 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = resolve_events(c);
     if (rc) return rc;
+    const Slot* sl = c->res;
     out->n_profiled = c->n_profiled;
     out->rows = (uint64_t)c->n;
     out->users = (uint64_t)c->n_users;
-    out->selected = c->last.m;
+    out->selected = sl ? sl->last.m : 0;
     out->alg_bytes = 24ull * (uint64_t)c->n;
     out->k1_ms_sum = c->k1_ms_sum;
     out->scan_ms_sum = c->scan_ms_sum;
-    out->max_bucket = c->last.max_count;
-    out->n_segments = c->last.n_seg;
-    out->n_big = c->last.n_big;
-    out->k1_blocks = (uint32_t)c->k1_blocks;
-    out->k1_variant = (uint32_t)c->last_variant;
+    out->max_bucket = sl ? sl->last.max_count : 0;
+    out->n_segments = sl ? sl->last.n_seg : 0;
+    out->n_big = sl ? sl->last.n_big : 0;
+    out->k1_blocks = sl ? (uint32_t)sl->k1_blocks : 0;
+    out->k1_variant = sl ? (uint32_t)sl->variant : 0;
     out->reserved = 0;
-    out->live = c->last.live;
+    out->live = sl ? sl->last.live : 0;
     return PIE_OK;
 }
 
@@ -799,8 +907,7 @@ int pie_synchronize(pie_ctx* c)
 {
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
-    PIE_HIP(c, hipStreamSynchronize(c->stream));
-    return PIE_OK;
+    return sync_all(c);
 }
 
 int32_t pie_shard_of(int32_t user, int32_t n_shards)

@@ -3,10 +3,12 @@ cross-user feeds.  One process per GPU; torch.distributed is th
 is RCCL over xGMI on ROCm, "gloo" on CPU for the world_size-2 tests).
 
 Rows of different users are independent, so each rank scans its shard with no communication.  The one exchange
-step gathers, per rank, ONE contiguous int32 message  [counts[0..U_pad) | M | rows[0..cap)]  (packed by a single
-kernel launch, `pie_pack_results_device`).  xGMI is point-to-point and these messages are small (≈2 MB), so the
-gather is latency-bound: it is issued on a side stream and overlaps the next scan; the host never waits on the
-scan stream for it (submit / collect, depth-1 pipeline).
+step gathers, per rank, ONE contiguous int32 message
+    [ off[0..U_pad] (exclusive offsets, = M past the shard's last user) | M | rows[0..cap) ]
+packed by a single kernel launch (`pie_pack_results_device`); Feed(rank r, local user u) =
+rows[r, off[r,u] : off[r,u+1]] with no further arithmetic on the receiving side.  xGMI is point-to-point and these
+messages are small (≈2 MB), so the gather is latency-bound: it is issued on a side stream and overlaps the next
+scan; the host never waits on the scan stream for it, and the per-step host work is a handful of calls.
 """
 import numpy as np
 import torch
@@ -41,32 +43,36 @@ class HipShardBackend:
     def __init__(self, ctx: PieScan, device):
         self.ctx = ctx
         self.device = torch.device(device)
-        # the scan runs on torch's current stream, so packing, events and collectives order with it naturally
-        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # the scan runs on the library's own stream; it is wrapped here so torch events can be recorded on it
+        self.result_stream = torch.cuda.ExternalStream(self.ctx.aux_stream(), device=self.device)
 
     def scan_begin(self, now, cutoff):
-        """Enqueue the scan kernels; returns immediately."""
+        """Enqueue the table pass + offsets kernel; returns immediately."""
         self.ctx.scan_begin(now, cutoff)
 
     def scan_finish_packed(self, dst, u_pad, cap):
-        """Wait for the scan's summary, then write [counts | 0-pad | M | rows[:min(M, cap)]] into dst (int32, device)
-        with one kernel launch.  -> M (host int)."""
+        """Wait for the scan's summary, enqueue its tail, then write the message into dst (int32, device) with one
+        kernel launch.  -> M (host int)."""
         m = self.ctx.scan_finish()
         self.ctx.pack_results_device(dst.data_ptr(), u_pad, cap)
         return m
 
 
 class _Ticket:
-    __slots__ = ("parity", "work", "m", "done", "cap", "u_pad", "packed")
+    __slots__ = ("parity", "m", "cap", "u_pad", "issued")
 
 
 class ShardedFeeds:
-    """Per-rank driver: scan the local shard, all-gather the packed messages, build global offsets.
+    """Per-rank driver: scan the local shard, all-gather the packed messages.
 
-    `backend.scan_packed(now, cutoff, dst, u_pad, cap) -> M` fills an int32 tensor on `backend.device` (the GPU for
-    nccl/RCCL, the CPU for gloo).  submit() enqueues scan + pack + asynchronous all-gather and returns a ticket;
-    collect(ticket) returns the gathered views.  Two message / result buffers alternate, so step i+1 may be
-    submitted before step i is collected."""
+    `backend.scan_begin(now, cutoff)` / `backend.scan_finish_packed(dst, u_pad, cap) -> M` fill an int32 tensor on
+    `backend.device` (the GPU for nccl/RCCL, the CPU for gloo).  Pipeline stages:
+        begin            enqueue the scan (no host wait)
+        finish_and_pack  wait for its summary, enqueue tail + pack, mark the message ready          -> ticket
+        exchange         issue the all-gather of that message on the side stream (GPU-async)
+        collect          wait for the side stream only; hand out the gathered views
+    run_steps() interleaves them so that the host work of exchange(i) happens while the GPU scans step i+1.
+    Two message / result buffers alternate."""
 
     def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
@@ -74,14 +80,17 @@ class ShardedFeeds:
         self.n_users_local = int(n_users_local)
         self.device = torch.device(getattr(backend, "device", "cpu"))
         self.cuda = self.device.type == "cuda"
-        # counts are padded to the largest shard's user count so the gather has one fixed size
+        # offsets are padded to the largest shard's user count so the gather has one fixed size
         self.u_pad = self._all_max(self.n_users_local)
         self.cap = cap  # capacity of one rank's row list in the message; negotiated on first use
         self.parity = 0
         self.msg = self.out = None
-        self.comm_stream = torch.cuda.Stream(self.device) if self.cuda else None
-        self.gather_done = [None, None]   # event after the gather that last read msg[p] / wrote out[p]
-        self.len_host = None
+        if self.cuda:
+            self.comm_stream = torch.cuda.Stream(self.device)
+            self.rs = getattr(backend, "result_stream", None) or torch.cuda.current_stream(self.device)
+            self.ev_packed = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.busy = [False, False]   # a gather that reads msg[p] / writes out[p] has been issued and not collected
 
     # ---- helpers
     def _all_max(self, value):
@@ -95,19 +104,15 @@ class ShardedFeeds:
         return max(1024, int(need * 1.25) + 64)
 
     def _alloc(self):
-        L = self.u_pad + 1 + self.cap
+        L = self.u_pad + 2 + self.cap
         self.msg = [torch.zeros(L, dtype=torch.int32, device=self.device) for _ in range(2)]
         self.out = [torch.zeros(self.world * L, dtype=torch.int32, device=self.device) for _ in range(2)]
         self.len_host = [torch.zeros(self.world, dtype=torch.int32, pin_memory=self.cuda) for _ in range(2)]
-        self.offsets = [torch.zeros(self.world * self.u_pad + 1, dtype=torch.int64, device=self.device) for _ in range(2)]
-        self.gather_done = [None, None]
+        # strided view of the M word of every rank's message, made once
+        self.len_dev = [o.view(self.world, L)[:, self.u_pad + 1] for o in self.out]
+        self.busy = [False, False]
 
-    # ---- pipeline stages -------------------------------------------------------------------------------
-    #   begin            enqueue the scan (no host wait)
-    #   finish_and_pack  wait for its summary, enqueue the pack launch, mark the message ready       -> ticket
-    #   exchange         issue the all-gather of that message on the side stream (host-heavy, GPU-async)
-    #   collect          wait for the side stream only; hand out the gathered views
-    # run_steps() interleaves them so that the host work of exchange(i-1) happens while the GPU scans step i.
+    # ---- pipeline stages
     def begin(self, now, cutoff):
         self._query = (now, cutoff)
         self.backend.scan_begin(now, cutoff)
@@ -115,63 +120,61 @@ class ShardedFeeds:
     def finish_and_pack(self):
         if self.cap is None:
             # first use: learn M, agree on a capacity, and redo this scan with real buffers
-            probe = torch.zeros(self.u_pad + 1, dtype=torch.int32, device=self.device)
+            probe = torch.zeros(self.u_pad + 2, dtype=torch.int32, device=self.device)
             self.cap = self._grow(self._all_max(self.backend.scan_finish_packed(probe, self.u_pad, 0)))
             self.backend.scan_begin(*self._query)
-        if self.msg is None or self.msg[0].numel() != self.u_pad + 1 + self.cap:
+        if self.msg is None or self.msg[0].numel() != self.u_pad + 2 + self.cap:
             self._alloc()
         p = self.parity
         self.parity ^= 1
-        if self.cuda and self.gather_done[p] is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.gather_done[p])  # msg[p] is free again
+        if self.busy[p]:
+            raise RuntimeError("collect() the ticket issued two steps ago before packing into its buffers again")
         t = _Ticket()
-        t.parity, t.cap, t.u_pad, t.work, t.done = p, self.cap, self.u_pad, None, None
+        t.parity, t.cap, t.u_pad, t.issued = p, self.cap, self.u_pad, False
         t.m = self.backend.scan_finish_packed(self.msg[p], self.u_pad, self.cap)
         if self.cuda:
-            t.packed = torch.cuda.Event()
-            t.packed.record(torch.cuda.current_stream(self.device))
+            self.ev_packed[p].record(self.rs)
         return t
 
     def exchange(self, t):
         p = t.parity
-        L = t.u_pad + 1 + t.cap
+        t.issued = True
+        self.busy[p] = True
         if not self.collective:
             self.out[p].copy_(self.msg[p])
-        elif self.cuda:
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(t.packed)
-                t.work = dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group, async_op=True)
-                t.work.wait()  # orders the side stream behind the collective; the host does not block here
-                g = self.out[p].view(self.world, L)
-                self.len_host[p].copy_(g[:, t.u_pad], non_blocking=True)
-                torch.cumsum(g[:, : t.u_pad].reshape(-1), 0, out=self.offsets[p][1:])
-                t.done = torch.cuda.Event()
-                t.done.record(self.comm_stream)
-            self.gather_done[p] = t.done
+            return
+        if self.cuda:
+            prev = torch.cuda.current_stream(self.device)
+            torch.cuda.set_stream(self.comm_stream)
+            try:
+                self.comm_stream.wait_event(self.ev_packed[p])
+                dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group)  # stream-ordered, host-async
+                self.len_host[p].copy_(self.len_dev[p], non_blocking=True)
+                self.ev_done[p].record(self.comm_stream)
+            finally:
+                torch.cuda.set_stream(prev)
         else:
-            t.work = dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group, async_op=True)
+            dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group)
 
     def collect(self, t):
-        """-> dict(counts [world, U_pad], lengths [world], rows [world, cap], offsets [world*U_pad+1]) or None when a
-        rank's row list outgrew the message capacity (every rank sees the same lengths, so every rank gets None,
-        the capacity has been raised, and the caller resubmits)."""
+        """-> dict(offsets [world, U_pad+1] int32, lengths [world], rows [world, cap] int32) or None when a rank's row
+        list outgrew the message capacity (every rank sees the same lengths, so every rank gets None, the capacity has
+        been raised, and the caller resubmits).  Feed(r, u) = rows[r, offsets[r,u] : offsets[r,u+1]]."""
         p = t.parity
-        L = t.u_pad + 1 + t.cap
-        if t.done is not None:
-            t.done.synchronize()            # waits for the side stream only, never for the scan stream
+        L = t.u_pad + 2 + t.cap
+        if self.cuda and self.collective:
+            self.ev_done[p].synchronize()   # waits for the side stream only, never for the scan stream
         else:
-            if t.work is not None:
-                t.work.wait()
-            g0 = self.out[p].view(self.world, L)
-            self.len_host[p].copy_(g0[:, t.u_pad])
-            torch.cumsum(g0[:, : t.u_pad].reshape(-1), 0, out=self.offsets[p][1:])
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()
+            self.len_host[p].copy_(self.len_dev[p])
+        self.busy[p] = False
         g = self.out[p].view(self.world, L)
         need = int(self.len_host[p].max())
         if need > t.cap:
             self.cap = max(self.cap, self._grow(need))
             return None
-        return {"counts": g[:, : t.u_pad], "lengths": self.len_host[p].clone(), "rows": g[:, t.u_pad + 1:],
-                "offsets": self.offsets[p]}
+        return {"offsets": g[:, : t.u_pad + 1], "lengths": self.len_host[p].clone(), "rows": g[:, t.u_pad + 2:]}
 
     def submit(self, now, cutoff):
         """One whole step without overlap: scan, pack, issue the gather.  -> ticket for collect()."""
@@ -188,24 +191,24 @@ class ShardedFeeds:
                 return res
 
     def run_steps(self, k, now, cutoff):
-        """k steps of the same query, software-pipelined: while the GPU scans step i the host issues the gather of
-        step i-1 and collects step i-2.  Every gather is collected before returning.  -> last collected result
-        (None if a message overflowed: the capacity has been raised, call again)."""
-        last, packed, flying = None, None, None
+        """k steps of the same query, software-pipelined: while the GPU runs the table pass of step i+1 the host
+        issues the gather of step i, and collects it one step later.  Every gather is collected before returning.
+        -> last collected result (None if a message overflowed: the capacity has been raised, call again)."""
+        last, flying = None, None
         if k <= 0:
             return None
+        if self.cap is None:          # capacity negotiation needs a whole scan of its own
+            last = self.scan_and_gather(now, cutoff)
+            k -= 1
+            if k == 0:
+                return last
         self.begin(now, cutoff)
         for i in range(k):
-            if packed is not None:
-                self.exchange(packed)
-                if flying is not None:
-                    last = self.collect(flying)
-                flying, packed = packed, None
-            t = self.finish_and_pack()
+            t = self.finish_and_pack()       # waits for scan i's summary, queues its tail + pack
             if i + 1 < k:
-                self.begin(now, cutoff)
-            packed = t
-        self.exchange(packed)
-        if flying is not None:
-            last = self.collect(flying)
-        return self.collect(packed)
+                self.begin(now, cutoff)      # the next table pass is queued right behind them ...
+            self.exchange(t)                 # ... and runs while the host issues this step's gather
+            if flying is not None:           # gather of step i-1: issued a whole table pass ago
+                last = self.collect(flying)
+            flying = t
+        return self.collect(flying)

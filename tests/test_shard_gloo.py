@@ -32,10 +32,10 @@ class OracleBackend:
                                   now, cutoff, self.mask)
         m = idx.size
         k = min(m, cap)
-        dst[: c.size] = torch.from_numpy(c)
-        dst[c.size:u_pad] = 0
-        dst[u_pad] = m
-        dst[u_pad + 1:u_pad + 1 + k] = torch.from_numpy(idx[:k])
+        dst[: off.size] = torch.from_numpy(off.astype(np.int32))      # off[0..U]
+        dst[off.size:u_pad + 1] = m                                    # padding users: empty feeds at the end
+        dst[u_pad + 1] = m
+        dst[u_pad + 2:u_pad + 2 + k] = torch.from_numpy(idx[:k])
         return m
 
 
@@ -61,7 +61,7 @@ def _worker(rank, world, port, tmp, n, U):
         first = [feeds.collect(t) for t in tickets]
         assert first[0] is not None and torch.equal(first[0]["rows"], first[1]["rows"])
         piped = feeds.run_steps(5, *queries[0])
-        assert torch.equal(piped["rows"], first[0]["rows"]) and torch.equal(piped["counts"], first[0]["counts"])
+        assert torch.equal(piped["rows"], first[0]["rows"]) and torch.equal(piped["offsets"], first[0]["offsets"])
         for now, cutoff in queries:
             out = feeds.scan_and_gather(now, cutoff)
             # rebuild global feeds from the gathered buffers and compare with the oracle on the WHOLE table
@@ -69,17 +69,17 @@ def _worker(rank, world, port, tmp, n, U):
             got_counts = np.zeros(U, np.int32)
             got_feeds = {}
             for r in range(world):
-                cnt = out["counts"][r].numpy()
+                off = out["offsets"][r].numpy()
                 rows = out["rows"][r].numpy()[: int(out["lengths"][r])]
-                off = np.concatenate([[0], np.cumsum(cnt)])
+                assert off[0] == 0 and off[-1] == int(out["lengths"][r]) and np.all(np.diff(off) >= 0)
                 for lu, gu in enumerate(shards[r]["users"]):
-                    got_counts[gu] = cnt[lu]
+                    got_counts[gu] = off[lu + 1] - off[lu]
                     got_feeds[int(gu)] = shards[r]["rows"][rows[off[lu]:off[lu + 1]]]
-                assert cnt[len(shards[r]["users"]):].sum() == 0   # padding users stay empty
+                assert np.all(off[len(shards[r]["users"]):] == off[-1])   # padding users stay empty
             assert np.array_equal(got_counts, wc)
             for gu in range(U):
                 assert np.array_equal(got_feeds.get(gu, np.zeros(0, np.int64)), wi[wo[gu]:wo[gu + 1]]), (rank, gu)
-            assert int(out["offsets"][-1]) == wi.size
+            assert int(out["lengths"].sum()) == wi.size
         open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -48,11 +48,11 @@ def main():
                 for _ in range(3):
                     ctx.scan_device(now, cutoff)
                 ctx.stats_reset()
-                ctx.set_profiling(True)
+                ctx.set_profiling(1)
                 for _ in range(a.steps):
                     ctx.scan_device(now, cutoff)
                 st = ctx.stats()
-                ctx.set_profiling(False)
+                ctx.set_profiling(0)
                 if rnd == 0:
                     got = ctx.scan(now, cutoff)
                     if ref is None:
