@@ -116,6 +116,9 @@ int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
  * (and the rare big-bucket merge passes) and returns M.  Results of a finished scan end at the next begin. */
 int pie_scan_begin(pie_ctx *ctx, int64_t now, int64_t cutoff);
 int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
+/* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
+int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
+                     size_t *m_out);
 /* Device pointers of the last finished scan's results: complete in stream order (pie_ctx_aux_stream) or after
  * pie_synchronize; valid until the next pie_scan_begin. */
 int pie_result_device_ptrs(pie_ctx *ctx, void **counts_dev, void **offsets_dev, void **idx_dev);

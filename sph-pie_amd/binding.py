@@ -53,6 +53,7 @@ _SIGS = [
     ("pie_scan_device", C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     ("pie_scan_begin", C.c_int, [_P, C.c_int64, C.c_int64]),
     ("pie_scan_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_copy_results_device", C.c_int, [_P, _P, _P, _P, C.c_size_t]),
     ("pie_pack_results_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
@@ -183,6 +184,15 @@ class PieScan:
         m = C.c_size_t(0)
         self._check(self._lib.pie_scan(self._ctx, int(now), int(cutoff), _ptr(counts), _ptr(offsets), _ptr(idx), cap, C.byref(m)))
         return counts, offsets, idx[: m.value].copy() if cap > 4 * max(m.value, 1) else idx[: m.value]
+
+    def read_results(self):
+        """Host copies (counts, offsets, idx) of the last FINISHED scan (scan_finish / scan_device / scan_pipelined)."""
+        U = self.n_users
+        counts, offsets = np.empty(U, np.int32), np.empty(U + 1, np.int64)
+        idx = np.empty(max(self.n, 1), np.int32)
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_read_results(self._ctx, _ptr(counts), _ptr(offsets), _ptr(idx), self.n, C.byref(m)))
+        return counts, offsets, idx[: m.value].copy()
 
     def scan_device(self, now, cutoff):
         m = C.c_size_t(0)

@@ -758,17 +758,15 @@ int pie_scan_finish(pie_ctx* c, size_t* m_out)
     return rc;
 }
 
-int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out,
-             size_t idx_cap, size_t* m_out)
+int pie_read_results(pie_ctx* c, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)
 {
     if (!c) return PIE_E_INVAL;
+    if (!c->res || !c->res->have_result) return fail(c, PIE_E_STATE, "no scan result on this context");
     PIE_HIP(c, hipSetDevice(c->device));
-    int rc = run_scan(c, now, cutoff);
-    const size_t m = c->res ? (size_t)c->res->last.m : 0;
-    if (m_out) *m_out = m;
-    if (rc) return rc;
     Slot& sl = *c->res;
     hipStream_t a = c->stream;
+    const size_t m = (size_t)sl.last.m;
+    if (m_out) *m_out = m;
     if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, sl.counts, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, a));
     if (offsets_out) PIE_HIP(c, hipMemcpyAsync(offsets_out, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, a));
     if (idx_out && m > idx_cap) {
@@ -778,6 +776,17 @@ int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64
     if (idx_out && m) PIE_HIP(c, hipMemcpyAsync(idx_out, sl.out_idx, m * 4, hipMemcpyDeviceToHost, a));
     PIE_HIP(c, hipStreamSynchronize(a));
     return PIE_OK;
+}
+
+int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out,
+             size_t idx_cap, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = run_scan(c, now, cutoff);
+    if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
+    if (rc) return rc;
+    return pie_read_results(c, counts_out, offsets_out, idx_out, idx_cap, m_out);
 }
 
 int pie_result_device_ptrs(pie_ctx* c, void** counts_dev, void** offsets_dev, void** idx_dev)

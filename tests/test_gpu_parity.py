@@ -140,6 +140,34 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         assert ctx.stats()["k1_variant"] == 0x03
 
 
+def test_two_scans_in_flight(pie, oracle):
+    """begin(i+1) before finish(i): different queries back to back, results of each finished scan are exact and
+    stay readable while the next scan is already queued; a third begin is refused."""
+    with pie.PieScan(0) as ctx:
+        n, U, D = 600011, 3000, 32
+        s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 1)
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        now, cutoff, _ = spec_query(oracle)
+        queries = [(now, cutoff), (INT64_MIN, INT64_MIN), (oracle.T0_MS - 40 * DAY, cutoff), (2 ** 62, INT64_MIN), (now, cutoff)]
+        want = [oracle.scan(s, e, u, d, U, q[0], q[1], 0xFFFFFFFF) for q in queries]
+        ctx.scan_begin(*queries[0])
+        for i in range(len(queries)):
+            if i + 1 < len(queries):
+                ctx.scan_begin(*queries[i + 1])
+                with pytest.raises(pie.PieError):
+                    ctx.scan_begin(*queries[0])      # a third scan in flight is a state error, nothing is enqueued
+            m = ctx.scan_finish()
+            assert m == want[i][2].size
+            assert_same(ctx.read_results(), want[i])
+        with pytest.raises(pie.PieError):
+            ctx.scan_finish()
+        # the pipelined helper ends in the same state as a plain scan
+        assert ctx.scan_pipelined(7, *queries[2]) == want[2][2].size
+        assert_same(ctx.read_results(), want[2])
+        assert_same(ctx.scan(*queries[1]), want[1])
+
+
 def test_generator_parity(gpu_ctx, oracle):
     for n, U, D, flags in [(1000, 10, 3, 0), (70001, 333, 32, 1), (70001, 333, 32, 2), (4096, 4096, 64, 3)]:
         gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, flags)
