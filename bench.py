@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--js-rows", type=int, default=10 ** 6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--mode", choices=["scan", "expired"], default="scan",
+                    help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
+                         "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic)")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="scans in flight: 2 = the table pass of step i+1 overlaps the scatter/order tail of step i")
     args = ap.parse_args()
@@ -98,6 +101,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "PIE_BENCH_DEVICE" in os.environ:   # rehearsal only: several ranks on one GPU (if RCCL accepts it)
+        local_rank = int(os.environ["PIE_BENCH_DEVICE"])
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
@@ -136,10 +141,16 @@ def main():
     backend = HipShardBackend(ctx, dev) if gather else None
     feeds = ShardedFeeds(backend, rank, world, U, always_collective=gather) if gather else None
 
+    expired_window = (T0_MS - 30 * DAY, T0_MS - 29 * DAY)   # one day of expiries: ~0.83 % of the rows queue up
+
     def run_steps(k):
         """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1 (depth-1 pipeline,
         every gather is collected inside the same call)."""
         last = None
+        if args.mode == "expired":
+            for _ in range(k):
+                last = ctx.expired_queue(expired_window[0], expired_window[1], fetch=False)
+            return last
         if not gather:
             if args.depth == 1:
                 for _ in range(k):
@@ -163,7 +174,7 @@ def main():
     ctx.stats_reset()
     # HIP events around the scan kernels, on the stream they are launched on; every 4th step carries them (an event
     # between two kernels drains the pipeline for a few microseconds, which would inflate ms_per_step)
-    ctx.set_profiling(args.profile_every)
+    ctx.set_profiling(1 if args.mode == "expired" else args.profile_every)
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     fence()
@@ -180,20 +191,24 @@ def main():
         ms_per_step = dt * 1e3 / args.steps
         k1_ms = st["k1_ms_sum"] / max(st["n_profiled"], 1)
         scan_ms = st["scan_ms_sum"] / max(st["n_profiled"], 1)
-        alg = 24.0 * N
-        achieved = alg / (k1_ms * 1e-3) / 1e9
+        alg = (8.0 if args.mode == "expired" else 24.0) * N
+        achieved = alg / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         variant = st["k1_variant"]
         kname = "k_scan_live_first" if variant & 4 else "k_scan_compact"
+        if args.mode == "expired":
+            kname = "k_expired_stage"
         traffic = None
         tpath = os.path.join(REPO, "profiles", "k1_traffic.json")
-        default_workload = (N, U, D, args.order, args.variant, args.query) == (10 ** 8, 10 ** 5, 32, "random", "auth", "spec")
+        default_workload = (N, U, D, args.order, args.variant, args.query, args.mode) == (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan")
         if default_workload and os.path.exists(tpath):
             tdoc = json.load(open(tpath))
             if tdoc.get("kernel", "").endswith(kname) or kname in tdoc.get("kernel", ""):
                 traffic = tdoc["hbm_bytes_per_launch"]   # PMC-measured for this kernel form and this workload
         line = {
-            "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X",
-            "value": U * world / (ms_per_step * 1e-3), "unit": "feeds/s",
+            "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X" if args.mode == "scan" else
+                      "expired-queue pass (SURVEY 8f-1): sessions scanned/sec; value counts table rows, not feeds",
+            "value": (U if args.mode == "scan" else N) * world / (ms_per_step * 1e-3),
+            "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
             "sessions_per_sec": N * world / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",

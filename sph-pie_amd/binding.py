@@ -241,8 +241,12 @@ class PieScan:
         self._check(self._lib.pie_fetch_rows(self._ctx, _ptr(idx), m, _ptr(s), _ptr(e), _ptr(u), _ptr(d)))
         return s, e, u, d
 
-    def expired_queue(self, prev_now, now):
+    def expired_queue(self, prev_now, now, fetch=True):
+        """Ascending rows with prev_now < end <= now.  fetch=False: leave the queue on the device, return its length."""
         q = C.c_size_t(0)
+        if not fetch:
+            self._check(self._lib.pie_expired_queue(self._ctx, int(prev_now), int(now), None, 0, C.byref(q)))
+            return q.value
         out = np.empty(max(self.n, 1), np.int32)
         self._check(self._lib.pie_expired_queue(self._ctx, int(prev_now), int(now), _ptr(out), self.n, C.byref(q)))
         return out[: q.value].copy()

@@ -872,4 +872,104 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
     }
 }
 
+// exclusive prefix over blk[0..nb) by ONE block of 1024 threads in a single sweep: thread t owns the contiguous
+// chunk [t*per, (t+1)*per), so 16 K wave counts cost one block-wide scan instead of 64 of them
+__global__ __launch_bounds__(1024) void k_block_prefix_wide(const int* __restrict__ blk, int nb, long long* __restrict__ off,
+                                                            unsigned long long* __restrict__ total_out)
+{
+    __shared__ long long wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    long long mine = 0;
+    for (int k = 0; k < per; ++k)
+        if (b0 + k < nb) mine += blk[b0 + k];
+    const long long incl = wave_incl_scan(mine, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int k = 0; k < per; ++k) {
+        if (b0 + k < nb) {
+            off[b0 + k] = run;
+            run += blk[b0 + k];
+        }
+    }
+    if (threadIdx.x == 1023) {
+        off[nb] = run;
+        if (total_out) *total_out = (unsigned long long)run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ expired queue, one pass
+
+// The newly-expired change predicate (prev_now < end <= now) reads ONE column, so its roofline is 8 B/row.  The
+// count / prefix / write form above reads it twice; this form reads it once: every WAVE owns a contiguous row
+// range and the same index range of `stage` as a private, order-preserving output region (ballot + mbcnt prefix,
+// direct stores, no LDS), a single block turns the per-wave counts into offsets, and a gather moves the few hits.
+// Order of the final queue = ascending row index (the sequential-await order of
+// /root/reference/server/storage/sqlProvider.js:834-861).
+template <int UNROLL>
+__global__ __launch_bounds__(kK1Threads) void k_expired_stage(const long long* __restrict__ end, long long n,
+                                                              long long rows_per_block, long long prev_now, long long now,
+                                                              int* __restrict__ stage, int* __restrict__ wave_count)
+{
+    constexpr int kTile = kUnitRows * UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const long long rows_per_wave = rows_per_block / kK1Waves; // a multiple of every tile size (block range is 4096-aligned)
+    const long long w0 = (long long)blockIdx.x * rows_per_block + (long long)wave * rows_per_wave;
+    long long w1 = w0 + rows_per_wave;
+    if (w1 > n) w1 = n;
+    int fill = 0; // wave-uniform
+    int* out = stage + w0;
+    for (long long t = w0; t < w1; t += kTile) {
+        if (t + kTile <= w1) {
+            ll2_t e[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                e[j] = stream_load<true>(reinterpret_cast<const ll2_t*>(end + t + j * kUnitRows + 2 * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const bool h0 = (e[j].x <= now) & (e[j].x > prev_now);
+                const bool h1 = (e[j].y <= now) & (e[j].y > prev_now);
+                const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+                if ((b0 | b1) == 0) continue;
+                const int r = (int)(t + j * kUnitRows + 2 * lane);
+                const int pos = fill + prefix_in_ballot(b0) + prefix_in_ballot(b1); // rows 2l, 2l+1 are adjacent
+                if (h0) out[pos] = r;
+                if (h1) out[pos + (h0 ? 1 : 0)] = r + 1;
+                fill += __popcll(b0) + __popcll(b1);
+            }
+        } else {
+            for (long long r0 = t; r0 < w1; r0 += kWave) {
+                const long long r = r0 + lane;
+                bool h = false;
+                if (r < w1) {
+                    const long long ev = end[r];
+                    h = (ev <= now) & (ev > prev_now);
+                }
+                const unsigned long long b = __ballot(h);
+                if (h) out[fill + prefix_in_ballot(b)] = (int)r;
+                fill += __popcll(b);
+            }
+        }
+    }
+    if (lane == 0) wave_count[blockIdx.x * kK1Waves + wave] = w0 < n ? fill : 0;
+}
+
+__global__ __launch_bounds__(256) void k_expired_gather(const int* __restrict__ stage, const int* __restrict__ wave_count,
+                                                        const long long* __restrict__ wave_off, int n_waves,
+                                                        long long rows_per_wave, int* __restrict__ queue, long long cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int total_waves = gridDim.x * 4;
+    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_waves; w += total_waves) {
+        const int cnt = wave_count[w];
+        const long long src = (long long)w * rows_per_wave, dst = wave_off[w];
+        for (int i = lane; i < cnt; i += 64)
+            if (dst + i < cap) queue[dst + i] = stage[src + i];
+    }
+}
+
 } // namespace pie

@@ -249,14 +249,14 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             (void)hipFree(old_s); (void)hipFree(old_e); (void)hipFree(old_u); (void)hipFree(old_d);
         }
         const long long max_blocks = rows / (kUnitRows * 8 * kK1Waves) + 2;
-        PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks + 1) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_blk_off, (max_blocks * kK1Waves + 8) * 8)); // per-wave prefix of the expired queue
         c->cap_users = users; // counts_span() below reads it
         for (Slot& s : c->slot) {
             PIE_HIP(c, hipMalloc(&s.offsets, ((size_t)users + 1) * 8));
             // +256: K3 fetches a region's first 256 records before it knows the count
             PIE_HIP(c, hipMalloc(&s.sel, (rows + 256) * sizeof(SelRec)));
             PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
-            PIE_HIP(c, hipMalloc(&s.blk_count, max_blocks * 4));
+            PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
             PIE_HIP(c, hipMalloc(&s.bkt_start, rows * 8));
             PIE_HIP(c, hipMalloc(&s.bkt_idx, rows * 4));
             PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
@@ -867,7 +867,53 @@ int pie_fetch_rows(pie_ctx* c, const int32_t* idx, size_t m, int64_t* start, int
 int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_out, size_t cap, size_t* q_out)
 {
     if (!c) return PIE_E_INVAL;
-    return run_row_list<0>(c, (long long)prev_now, (long long)now, queue_out, cap, q_out);
+    if (q_out) *q_out = 0;
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n == 0) return PIE_OK;
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (getenv("PIE_EXPIRED_TWO_PASS")) // the count / prefix / write form, kept for A-B runs
+        return run_row_list<0>(c, (long long)prev_now, (long long)now, queue_out, cap, q_out);
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // workspace: slot 0's out_idx is the device-side queue, slot 1's out_idx the per-wave staging, slot 0's
+    // blk_count the per-wave counts (4 per block of the liveness-first plan: <= the streaming plan's block count)
+    Slot& q = c->slot[0];
+    Slot& st = c->slot[1];
+    q.have_result = st.have_result = false;
+    c->res = nullptr;
+    const int blocks = c->plan_blocks[1];
+    const long long rpb = c->plan_rows[1];
+    const int n_waves = blocks * kK1Waves;
+    const bool prof = c->profiling && c->ring_used < kEventRing;
+    if (prof && (int)c->ring.size() <= c->ring_used) {
+        ScanEvents e{};
+        PIE_HIP(c, hipEventCreate(&e.e0));
+        PIE_HIP(c, hipEventCreate(&e.e1));
+        PIE_HIP(c, hipEventCreate(&e.e2));
+        c->ring.push_back(e);
+    }
+    if (prof) PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e0, s));
+    hipLaunchKernelGGL(k_expired_stage<8>, dim3(blocks), dim3(kK1Threads), 0, s, c->d_end, c->n, rpb, (long long)prev_now,
+                       (long long)now, st.out_idx, q.blk_count);
+    if (prof) PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e1, s));
+    hipLaunchKernelGGL(k_block_prefix_wide, dim3(1), dim3(1024), 0, s, q.blk_count, n_waves, c->d_blk_off, &c->d_summary->m);
+    hipLaunchKernelGGL(k_expired_gather, dim3(blocks < c->n_cus * 8 ? blocks : c->n_cus * 8), dim3(256), 0, s, st.out_idx,
+                       q.blk_count, c->d_blk_off, n_waves, rpb / kK1Waves, q.out_idx, c->cap_rows);
+    PIE_HIP(c, hipGetLastError());
+    if (prof) {
+        PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e2, s));
+        c->ring_used++;
+    }
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    const size_t k = (size_t)c->h_summary->m;
+    if (q_out) *q_out = k;
+    if (queue_out && k > cap) return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, k);
+    if (queue_out && k) {
+        PIE_HIP(c, hipMemcpyAsync(queue_out, q.out_idx, k * 4, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    }
+    return PIE_OK;
 }
 
 int pie_set_profiling(pie_ctx* c, int enabled)

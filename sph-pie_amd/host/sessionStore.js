@@ -195,6 +195,15 @@ function createStore(options){
     return {counts: out.counts, offsets: out.offsets, idx: out.idx.subarray(0, m), m, userIds};
   }
 
+  // ordered device queue of rows with prevNow < expiresAt <= now (no change to the host map: purgeExpiredSessions does that)
+  function expiredRows(prevNow, now){
+    flush();
+    const list = new Int32Array(Math.max(rows.length, 1));
+    const prev = prevNow === null || prevNow === undefined ? END_NONE : prevNow;
+    const k = native.expiredQueue(ctx, prev, now, list);
+    return list.slice(0, k);
+  }
+
   function fetchRows(idx){
     const m = idx.length;
     const s = new BigInt64Array(m), e = new BigInt64Array(m), u = new Int32Array(m), d = new Int32Array(m);
@@ -211,7 +220,8 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, fetchRows, flush, close,
+    scanFeeds, fetchRows, expiredRows, flush, close,
+    userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,
     native, ctx

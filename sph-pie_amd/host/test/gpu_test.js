@@ -178,6 +178,39 @@ function get(port, cookie){
     console.error = quiet;
     server.close(); broken.close(); store.close();
   }
+  // ---- 4. expired-session dispatch queue: device-ordered, drained sequentially, failures summarised
+  {
+    const {dispatchExpiredSessions} = require('../dispatchQueue');
+    const store = createStore();
+    const base = 1760000000000;
+    const made = [];
+    for(let i = 0; i < 40; i++){ fakeNow = base + i * 60000; store.createSession('user-' + (i % 7), i % 2 ? 'audio' : 'drones'); made.push(fakeNow + store.SESSION_TTL_MS); }
+    const prev = made[9], now = made[24];                      // rows 10..24 expire in (prev, now]
+    const seen = [];
+    let inFlight = 0, maxInFlight = 0;
+    const send = async (payload, meta) => {
+      inFlight++; maxInFlight = Math.max(maxInFlight, inFlight);
+      await new Promise(r => setImmediate(r));
+      seen.push(payload.sessionRow); inFlight--;
+      if(payload.sessionRow === 13){ return {success: false, error: 'HTTP 500'}; }
+      if(payload.sessionRow === 17){ throw new Error('socket hang up'); }
+      assert.strictEqual(meta.event, 'session.expired');
+      return {success: true};
+    };
+    const summary = await dispatchExpiredSessions(store, prev, now, send);
+    eq(seen, Array.from({length: 15}, (_, k) => 10 + k));      // ascending row order
+    eq(maxInFlight, 1);                                        // strictly sequential, like the reference's await loop
+    eq([summary.success, summary.dispatched, summary.failed, summary.total], [false, 13, 2, 15]);
+    eq(summary.error, 'One or more expired-session payloads failed to dispatch');
+    eq(summary.results[7], {success: false, error: 'socket hang up', sessionRow: 17});
+    const p0 = summary.results.length && (await dispatchExpiredSessions(store, prev, prev, send));
+    eq(p0, {success: true, dispatched: 0, failed: 0, total: 0, results: []});
+    const one = [];
+    await dispatchExpiredSessions(store, made[38], made[39], async p => { one.push(p); return {success: true}; });
+    eq(one, [{sessionRow: 39, userId: 'user-4', discipline: 'audio', createdAt: new Date(base + 39 * 60000).toISOString(),
+      expiredAt: new Date(made[39]).toISOString()}]);
+    store.close();
+  }
   Date.now = realNow;
   console.log('host gpu_test ok: ' + checks + ' checks');
 })().catch(err => { console.error(err); process.exit(1); });

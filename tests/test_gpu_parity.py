@@ -265,6 +265,31 @@ def test_config2_parity_1e7(gpu_ctx, oracle):
         assert got[2].size > 0
 
 
+def test_config4_user_hash_shards_reassemble(pie, gpu_ctx, oracle):
+    """BASELINE config 4 as a parity case: the table is user-hash sharded 8 ways, every shard is scanned by the HIP
+    path (one after the other on this one GPU), and the per-shard feeds reassemble to the oracle's feeds of the
+    whole table — same rows, same order, for every user."""
+    from sph_pie_amd.shard import partition_by_user_hash
+    n, U, D, G = 2 * 10 ** 6, 5003, 32, 8
+    cols = oracle.gen(SEED, n, 0, n, U, D, 1)
+    now, cutoff, mask = spec_query(oracle)
+    now -= 20 * DAY   # a less selective query, so most users have a feed
+    wc, wo, wi = oracle.scan(*cols, U, now, cutoff, mask & 0xFFFFFFFF)
+    shards = partition_by_user_hash(*cols, U, G)
+    assert sum(s["rows"].size for s in shards) == n
+    seen_users = 0
+    for r, sh in enumerate(shards):
+        gpu_ctx.load_columns(sh["start"], sh["end"], sh["user"], sh["disc"], sh["n_users"])
+        gpu_ctx.set_disciplines(mask, D)
+        c, o, idx = gpu_ctx.scan(now, cutoff)
+        for lu, gu in enumerate(sh["users"]):
+            assert pie.shard_of(int(gu), G) == r
+            feed = sh["rows"][idx[o[lu]:o[lu + 1]]]
+            assert np.array_equal(feed, wi[wo[gu]:wo[gu + 1]])
+            seen_users += 1
+    assert seen_users == U and wi.size > U
+
+
 def test_full_size_properties_1e8(gpu_ctx, oracle):
     """BASELINE config 3 (10^8 / 10^5 / 32): properties that need no full-size oracle run, plus an exact
     oracle comparison on the selected rows only."""
