@@ -99,6 +99,10 @@ int pie_set_end(pie_ctx *ctx, const int32_t *rows, const int64_t *new_end, size_
  * indices in ascending order so the host can drop their token-map entries; *n_deleted their number. */
 int pie_delete_user(pie_ctx *ctx, int32_t user, int32_t *rows_out, size_t cap, size_t *n_deleted);
 
+/* _pruneCalendarEvents (server/storage/sqlProvider.js:956-968): tombstone every row with start < cutoff (the
+ * complement of the scan's window predicate); rows_out / n_pruned as in pie_delete_user. */
+int pie_prune_before(pie_ctx *ctx, int64_t cutoff, int32_t *rows_out, size_t cap, size_t *n_pruned);
+
 /* ---- discipline predicate table: replaces findDiscipline() lookups (server/disciplineConfig.js:88-97) -
  * bit d of mask = rows of discipline d are wanted; bits >= n_disc are ignored. n_disc <= 64. */
 int pie_set_disciplines(pie_ctx *ctx, uint64_t mask, int32_t n_disc);

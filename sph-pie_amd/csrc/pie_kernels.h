@@ -28,6 +28,13 @@ struct alignas(16) SelRec {
     int user;
 };
 
+// one bucket slot: the sort key (start, idx); one 16-B store / load per record
+struct alignas(16) BktRec {
+    long long start;
+    int idx;
+    int pad;
+};
+
 struct alignas(16) Segment {
     long long pos; // first slot in the bucket arrays
     int len;
@@ -42,6 +49,8 @@ struct Summary {
     unsigned int bad_rows;      // rows whose user id fell outside [0, U): never selected, reported
     unsigned long long q;       // expired-queue length (pie_expired_queue)
     unsigned long long live;    // rows with end > now seen by K1 (drives the choice of K1 variant for the next scan)
+    unsigned int n_small;       // entries in the small-segment list (17..256 rows: one wave each)
+    unsigned int pad;
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -66,6 +75,7 @@ constexpr int kWaveTileRows = kUnitRows * kUnroll; // 512 rows per wave per iter
 constexpr int kBlockTileRows = kWaveTileRows * kK1Waves;
 constexpr int kStage = 128;                     // per-wave LDS ring of selected records
 constexpr int kTinyMax = 16;
+constexpr int kSmallMax = 512;                  // buckets of 17..512 rows: sorted by ONE wave in LDS, no block barriers
 constexpr int kSegMax = 4096;
 constexpr int kScanTile = 2048;                 // counts per K2 block (256 threads x 8)
 
@@ -464,7 +474,8 @@ constexpr unsigned long long kTileReady = 1ull << 62;
 __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
-                                                 Segment* __restrict__ seg_list, int* __restrict__ big_list,
+                                                 Segment* __restrict__ seg_list, Segment* __restrict__ small_list,
+                                                 int* __restrict__ big_list,
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16)
 {
@@ -522,7 +533,14 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
             const int n = c[k];
             local_max = max(local_max, (unsigned)n);
             if (n > kTinyMax) {
-                if (n <= kSegMax) {
+                if (n <= kSmallMax) {
+                    const unsigned slot = atomicAdd(&summary->n_small, 1u);
+                    Segment sg;
+                    sg.pos = run;
+                    sg.len = n;
+                    sg.flags = 0;
+                    small_list[slot] = sg;
+                } else if (n <= kSegMax) {
                     const unsigned slot = atomicAdd(&summary->n_seg, 1u);
                     Segment sg;
                     sg.pos = run;
@@ -569,6 +587,8 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
             out.bad_rows = __hip_atomic_load(&summary->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.q = 0;
             out.live = __hip_atomic_load(&summary->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.n_small = __hip_atomic_load(&summary->n_small, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.pad = 0;
             host->s = out;
             __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -584,7 +604,7 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
 __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank,
                                                  const int* __restrict__ blk_count, int nb, long long rows_per_block,
                                                  const long long* __restrict__ offsets,
-                                                 long long* __restrict__ bkt_start, int* __restrict__ bkt_idx)
+                                                 BktRec* __restrict__ bkt)
 {
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
         const long long base = (long long)b * rows_per_block;
@@ -599,8 +619,11 @@ __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel,
                 rank = sel_rank[base + i];
             }
             const long long pos = offsets[rec.user] + rank;
-            bkt_start[pos] = rec.start;
-            bkt_idx[pos] = rec.idx;
+            BktRec out;
+            out.start = rec.start;
+            out.idx = rec.idx;
+            out.pad = 0;
+            bkt[pos] = out;
         }
     }
 }
@@ -610,16 +633,20 @@ __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel,
 // Register sorting network (bitonic, fully unrolled so every index is a compile-time constant): NS slots,
 // the first n hold the bucket, the rest are +inf padding.
 template <int NS>
-__device__ __forceinline__ void sort_bucket_regs(long long o, int n, const long long* __restrict__ bkt_start,
-                                                 const int* __restrict__ bkt_idx, int* __restrict__ out_idx)
+__device__ __forceinline__ void sort_bucket_regs(long long o, int n, const BktRec* __restrict__ bkt,
+                                                 int* __restrict__ out_idx)
 {
     long long ks[NS];
     int ki[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const bool in = k < n;
-        ks[k] = in ? bkt_start[o + k] : INT64_MAX;
-        ki[k] = in ? bkt_idx[o + k] : INT32_MAX;
+        BktRec r;
+        r.start = INT64_MAX;
+        r.idx = INT32_MAX;
+        if (in) r = bkt[o + k];
+        ks[k] = r.start;
+        ki[k] = r.idx;
     }
 #pragma unroll
     for (int k = 2; k <= NS; k <<= 1) {
@@ -647,15 +674,14 @@ __device__ __forceinline__ void sort_bucket_regs(long long o, int n, const long 
 // K4a: one thread per bucket of <= kTinyMax (16) rows: every load issued at once, sorting network in
 // registers (8 slots for the common case, 16 otherwise).  Keys (start, idx) are unique.
 __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                 const long long* __restrict__ bkt_start, const int* __restrict__ bkt_idx,
-                                                 int* __restrict__ out_idx)
+                                                 const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
 {
     const int n = counts[u];
     if (n == 0 || n > kTinyMax) return;
     const long long o = offsets[u];
-    if (n == 1) { out_idx[o] = bkt_idx[o]; return; }
-    if (n <= 8) sort_bucket_regs<8>(o, n, bkt_start, bkt_idx, out_idx);
-    else sort_bucket_regs<16>(o, n, bkt_start, bkt_idx, out_idx);
+    if (n == 1) { out_idx[o] = bkt[o].idx; return; }
+    if (n <= 8) sort_bucket_regs<8>(o, n, bkt, out_idx);
+    else sort_bucket_regs<16>(o, n, bkt, out_idx);
 }
 
 // K4b: one block per segment (<= kSegMax rows): bitonic sort of (start, idx) in LDS.
@@ -663,14 +689,13 @@ __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ 
 __global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ counts, const long long* __restrict__ offsets,
                                                       int n_users, int tiny_blocks, const Segment* __restrict__ seg_list,
                                                       const Summary* __restrict__ summary,
-                                                      long long* __restrict__ bkt_start, int* __restrict__ bkt_idx,
-                                                      int* __restrict__ out_idx)
+                                                      BktRec* __restrict__ bkt, int* __restrict__ out_idx)
 {
     __shared__ long long ks[kSegMax];
     __shared__ int ki[kSegMax];
     if ((int)blockIdx.x < tiny_blocks) {
         const int u = blockIdx.x * 256 + threadIdx.x;
-        if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt_start, bkt_idx, out_idx);
+        if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, out_idx);
         return;
     }
     const unsigned n_seg = summary->n_seg;
@@ -681,8 +706,12 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ co
         while (p < sg.len) p <<= 1;
         for (int i = threadIdx.x; i < p; i += blockDim.x) {
             const bool in = i < sg.len;
-            ks[i] = in ? bkt_start[sg.pos + i] : INT64_MAX;
-            ki[i] = in ? bkt_idx[sg.pos + i] : INT32_MAX;
+            BktRec r;
+            r.start = INT64_MAX;
+            r.idx = INT32_MAX;
+            if (in) r = bkt[sg.pos + i];
+            ks[i] = r.start;
+            ki[i] = r.idx;
         }
         __syncthreads();
         for (int k = 2; k <= p; k <<= 1) {
@@ -704,8 +733,11 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ co
         }
         if (sg.flags & 1) {
             for (int i = threadIdx.x; i < sg.len; i += blockDim.x) {
-                bkt_start[sg.pos + i] = ks[i];
-                bkt_idx[sg.pos + i] = ki[i];
+                BktRec r;
+                r.start = ks[i];
+                r.idx = ki[i];
+                r.pad = 0;
+                bkt[sg.pos + i] = r;
             }
         } else {
             for (int i = threadIdx.x; i < sg.len; i += blockDim.x) out_idx[sg.pos + i] = ki[i];
@@ -714,37 +746,114 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ co
     }
 }
 
+// K4 (small segments): buckets of 17..512 rows, ONE WAVE each, entirely in registers: lane l holds elements
+// [l*EPL, (l+1)*EPL) of the padded bucket; bitonic steps with partner distance < EPL are compare-exchanges inside
+// the lane, the others exchange with lane l ^ (j/EPL) through the cross-lane network (__shfl_xor).  No LDS storage,
+// no barriers: the first version of this kernel kept the bucket in LDS and was LDS-bandwidth bound (0.92 ms for
+// 10^5 buckets of ~254 rows); every loop below has compile-time bounds so all indices are static registers.
+template <int EPL>
+__device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec* __restrict__ bkt, int* __restrict__ out_idx,
+                                                  int lane)
+{
+    constexpr int P = EPL * 64;
+    long long ks[EPL];
+    int ki[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = lane * EPL + e;
+        BktRec r;
+        r.start = INT64_MAX;
+        r.idx = INT32_MAX;
+        if (i < sg.len) r = bkt[sg.pos + i];
+        ks[e] = r.start;
+        ki[e] = r.idx;
+    }
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= EPL) { // partner lives in another lane, same slot
+                const int lm = j / EPL;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int i = lane * EPL + e;
+                    const long long os = __shfl_xor(ks[e], lm, kWave);
+                    const int oi = __shfl_xor(ki[e], lm, kWave);
+                    const bool up = (i & k) == 0;
+                    const bool lower = (i & j) == 0;
+                    const bool keep_min = lower == up;
+                    const bool other_less = key_less(os, oi, ks[e], ki[e]);
+                    const bool take = keep_min ? other_less : !other_less;
+                    ks[e] = take ? os : ks[e];
+                    ki[e] = take ? oi : ki[e];
+                }
+            } else { // partner is another slot of this lane
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int l = e ^ j;
+                    if (l > e) {
+                        const bool up = ((lane * EPL + e) & k) == 0;
+                        const bool lt = key_less(ks[l], ki[l], ks[e], ki[e]); // slot l sorts before slot e
+                        const bool sw = up ? lt : !lt;
+                        const long long s0 = sw ? ks[l] : ks[e], s1 = sw ? ks[e] : ks[l];
+                        const int i0 = sw ? ki[l] : ki[e], i1 = sw ? ki[e] : ki[l];
+                        ks[e] = s0; ks[l] = s1; ki[e] = i0; ki[l] = i1;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int i = lane * EPL + e;
+        if (i < sg.len) out_idx[sg.pos + i] = ki[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sort_small(const Segment* __restrict__ small_list, const Summary* __restrict__ summary,
+                                                    const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned n_small = summary->n_small;
+    for (unsigned w = blockIdx.x * 4 + wave; w < n_small; w += gridDim.x * 4) {
+        const Segment sg = small_list[w];
+        if (sg.len <= 128) wave_sort_segment<2>(sg, bkt, out_idx, lane);
+        else if (sg.len <= 256) wave_sort_segment<4>(sg, bkt, out_idx, lane);
+        else wave_sort_segment<8>(sg, bkt, out_idx, lane);
+    }
+}
+
 // K4c: one merge pass over every big bucket: sorted runs of `width` -> sorted runs of 2*width.  Each thread
 // owns one input element, binary-searches its rank in the sibling run, and stores it at its final slot
 // (keys are unique, so ranks are a permutation).  grid.y indexes big_list.
 __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_list, int n_big, const int* __restrict__ counts,
                                                     const long long* __restrict__ offsets, long long width,
-                                                    const long long* __restrict__ src_s, const int* __restrict__ src_i,
-                                                    long long* __restrict__ dst_s, int* __restrict__ dst_i)
+                                                    const BktRec* __restrict__ src, BktRec* __restrict__ dst,
+                                                    int* __restrict__ dst_idx_only)
 {
     for (int bb = blockIdx.y; bb < n_big; bb += gridDim.y) {
-    const int u = big_list[bb];
-    const long long n = counts[u], o = offsets[u];
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const long long run = p / width;
-        const long long pair0 = (run >> 1) * 2 * width; // first slot of this pair of runs
-        const bool right = run & 1;
-        const long long sib0 = right ? pair0 : pair0 + width;
-        long long sib_n = n - sib0;
-        if (sib_n > width) sib_n = width;
-        if (sib_n < 0) sib_n = 0;
-        const long long s = src_s[o + p];
-        const int i = src_i[o + p];
-        long long lo = 0, hi = sib_n; // number of sibling keys smaller than (s, i)
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (key_less(src_s[o + sib0 + mid], src_i[o + sib0 + mid], s, i)) lo = mid + 1; else hi = mid;
+        const int u = big_list[bb];
+        const long long n = counts[u], o = offsets[u];
+        for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+            const long long run = p / width;
+            const long long pair0 = (run >> 1) * 2 * width; // first slot of this pair of runs
+            const bool right = run & 1;
+            const long long sib0 = right ? pair0 : pair0 + width;
+            long long sib_n = n - sib0;
+            if (sib_n > width) sib_n = width;
+            if (sib_n < 0) sib_n = 0;
+            const BktRec me = src[o + p];
+            long long lo = 0, hi = sib_n; // number of sibling keys smaller than mine
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                const BktRec x = src[o + sib0 + mid];
+                if (key_less(x.start, x.idx, me.start, me.idx)) lo = mid + 1; else hi = mid;
+            }
+            const long long in_run = p - run * width;
+            const long long q = o + pair0 + in_run + lo;
+            if (dst_idx_only) dst_idx_only[q] = me.idx; // last pass: only the row order is wanted
+            else dst[q] = me;
         }
-        const long long in_run = p - run * width;
-        const long long q = o + pair0 + in_run + lo;
-        dst_s[q] = s;
-        dst_i[q] = i;
-    }
     }
 }
 
@@ -815,6 +924,8 @@ __global__ __launch_bounds__(256) void k_validate_users(const int* __restrict__ 
 //           /root/reference/server/sessionStore.js:69 at `now`, not yet dead at `prev_now`)
 //   MODE 1  deleteSessionsForUser (/root/reference/server/sessionStore.js:55-64): user == target, strict
 //           match; the write step tombstones the row (end = INT64_MIN: never live again)
+//   MODE 2  _pruneCalendarEvents (/root/reference/server/storage/sqlProvider.js:956-968): start < cutoff, the
+//           complement of the window predicate; tombstones like MODE 1.  `aux` is the start column here.
 template <int MODE>
 __device__ __forceinline__ bool list_match(const long long* __restrict__ end, const int* __restrict__ user, long long r,
                                            long long a, long long b)
@@ -822,8 +933,10 @@ __device__ __forceinline__ bool list_match(const long long* __restrict__ end, co
     if constexpr (MODE == 0) {
         const long long e = end[r];
         return e <= b && e > a;
-    } else {
+    } else if constexpr (MODE == 1) {
         return user[r] == (int)a && end[r] != INT64_MIN;
+    } else {
+        return reinterpret_cast<const long long*>(user)[r] < a && end[r] != INT64_MIN;
     }
 }
 
@@ -863,7 +976,7 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
         for (int w = 0; w < wave; ++w) base += wcount[w];
         const long long pos = base + prefix_in_ballot(bal);
         if (hit && pos < cap) queue[pos] = (int)r;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE != 0) {
             if (hit) end[r] = INT64_MIN;
         }
         __syncthreads();

@@ -48,10 +48,10 @@ struct Slot {
     SelRec* sel = nullptr;
     int* sel_rank = nullptr;
     int* blk_count = nullptr;
-    long long* bkt_start = nullptr;
-    int* bkt_idx = nullptr;
+    BktRec* bkt = nullptr;
     int* out_idx = nullptr;
     Segment* seg_list = nullptr;
+    Segment* small_list = nullptr;
     int* big_list = nullptr;
     // per-scan host state
     bool in_flight = false;
@@ -156,7 +156,7 @@ void free_slots(pie_ctx* c)
         s.counts = nullptr; s.sum = nullptr;
         s.tile_pub = nullptr; s.ctl = nullptr;
         dfree(s.offsets); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
-        dfree(s.bkt_start); dfree(s.bkt_idx); dfree(s.out_idx); dfree(s.seg_list); dfree(s.big_list);
+        dfree(s.bkt); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list);
         s.in_flight = s.have_result = false;
     }
     for (char*& sp : c->span) dfree(sp);
@@ -257,10 +257,10 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             PIE_HIP(c, hipMalloc(&s.sel, (rows + 256) * sizeof(SelRec)));
             PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
-            PIE_HIP(c, hipMalloc(&s.bkt_start, rows * 8));
-            PIE_HIP(c, hipMalloc(&s.bkt_idx, rows * 4));
+            PIE_HIP(c, hipMalloc(&s.bkt, rows * sizeof(BktRec)));
             PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
             PIE_HIP(c, hipMalloc(&s.seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
+            PIE_HIP(c, hipMalloc(&s.small_list, ((size_t)users + 16) * sizeof(Segment)));
             PIE_HIP(c, hipMalloc(&s.big_list, ((size_t)users + 16) * 4));
         }
         for (char*& sp : c->span) PIE_HIP(c, hipMalloc(&sp, counts_span(c)));
@@ -402,7 +402,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e1, s));
     sl.seq = ++c->seq_counter;
     hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl, sl.offsets,
-                       sl.seg_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, (long long)(counts_span(c) / 16));
+                       sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, (long long)(counts_span(c) / 16));
     PIE_HIP(c, hipGetLastError());
     sl.in_flight = true;
     c->n_flight++;
@@ -446,30 +446,33 @@ int scan_finish(pie_ctx* c)
         int scat_blocks = sl.k1_blocks;
         if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
         hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
-                           sl.rows_per_block, sl.offsets, sl.bkt_start, sl.bkt_idx);
+                           sl.rows_per_block, sl.offsets, sl.bkt);
         const int tiny_blocks = (c->n_users + 255) / 256;
         const int seg_blocks = sl.last.n_seg < (unsigned)(c->n_cus * 3) ? (int)sl.last.n_seg : c->n_cus * 3;
         hipLaunchKernelGGL(k_sort_buckets, dim3(tiny_blocks + seg_blocks), dim3(256), 0, a, sl.counts, sl.offsets,
-                           c->n_users, tiny_blocks, sl.seg_list, sl.sum, sl.bkt_start, sl.bkt_idx, sl.out_idx);
+                           c->n_users, tiny_blocks, sl.seg_list, sl.sum, sl.bkt, sl.out_idx);
+        if (sl.last.n_small > 0) {
+            unsigned small_blocks = (sl.last.n_small + 3) / 4;
+            if (small_blocks > (unsigned)c->n_cus * 8) small_blocks = (unsigned)c->n_cus * 8;
+            hipLaunchKernelGGL(k_sort_small, dim3(small_blocks), dim3(256), 0, a, sl.small_list, sl.sum, sl.bkt, sl.out_idx);
+        }
     }
     if (sl.last.n_big > 0) {
         // big buckets: tiles of kSegMax were sorted in place by K4; merge passes ping-pong between the bucket
         // arrays and scratch carved out of this slot's (now consumed) record staging; the last pass lands in out_idx.
-        long long* tmp_s = reinterpret_cast<long long*>(sl.sel);
-        int* tmp_i = reinterpret_cast<int*>(tmp_s + c->cap_rows);
+        BktRec* tmp = reinterpret_cast<BktRec*>(sl.sel); // same 16-B records, n of them
         int passes = 0;
         for (long long w = kSegMax; w < (long long)sl.last.max_count; w <<= 1) ++passes;
-        bool in_bkt = true; // which buffer pair holds the current runs
+        bool in_bkt = true; // which buffer holds the current runs
         long long w = kSegMax;
         for (int p = 0; p < passes; ++p, w <<= 1) {
-            const long long* src_s = in_bkt ? sl.bkt_start : tmp_s;
-            const int* src_i = in_bkt ? sl.bkt_idx : tmp_i;
-            long long* dst_s = in_bkt ? tmp_s : sl.bkt_start;
-            int* dst_i = (p == passes - 1) ? sl.out_idx : (in_bkt ? tmp_i : sl.bkt_idx);
+            const BktRec* src = in_bkt ? sl.bkt : tmp;
+            BktRec* dst = in_bkt ? tmp : sl.bkt;
+            int* idx_only = (p == passes - 1) ? sl.out_idx : nullptr;
             const unsigned gx = (unsigned)((sl.last.max_count + 255u) / 256u);
             const unsigned gy = sl.last.n_big < 65535u ? sl.last.n_big : 65535u;
             hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, a, sl.big_list,
-                               (int)sl.last.n_big, sl.counts, sl.offsets, w, src_s, src_i, dst_s, dst_i);
+                               (int)sl.last.n_big, sl.counts, sl.offsets, w, src, dst, idx_only);
             in_bkt = !in_bkt;
         }
     }
@@ -508,9 +511,11 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     if (c->res == &sl) c->res = nullptr;
     const int blocks = c->plan_blocks[0];
     const long long rpb = c->plan_rows[0];
-    hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, a, b, sl.blk_count);
+    // MODE 2 matches on the start column: it travels through the kernels' generic second-column pointer
+    const int* col2 = MODE == 2 ? reinterpret_cast<const int*>(c->d_start) : c->d_user;
+    hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
-    hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, a, b,
+    hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
                        c->d_blk_off, sl.out_idx, c->cap_rows);
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
@@ -722,6 +727,14 @@ int pie_delete_user(pie_ctx* c, int32_t user, int32_t* rows_out, size_t cap, siz
     if (c->n == 0 || user < 0 || user >= c->n_users) return PIE_OK; // unknown / falsy id: no-op (sessionStore.js:56-58)
     // the rows are tombstoned even when rows_out is too small to list them (PIE_E_CAPACITY then tells the count)
     return run_row_list<1>(c, (long long)user, 0, rows_out, cap, n_deleted);
+}
+
+int pie_prune_before(pie_ctx* c, int64_t cutoff, int32_t* rows_out, size_t cap, size_t* n_pruned)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_pruned) *n_pruned = 0;
+    if (c->n == 0) return PIE_OK;
+    return run_row_list<2>(c, (long long)cutoff, 0, rows_out, cap, n_pruned);
 }
 
 int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)

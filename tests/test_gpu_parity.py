@@ -243,6 +243,22 @@ def test_append_rows_equals_bulk_load(gpu_ctx, oracle):
     assert_same(got, want)
 
 
+def test_prune_before_is_the_window_complement(gpu_ctx, oracle):
+    """_pruneCalendarEvents (sqlProvider.js:956-968): rows with start < cutoff go, exactly the rows the window
+    predicate (:284) would have rejected; a scan without window after the prune equals a scan with window before it."""
+    n, U = 120001, 77
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    now, cutoff, mask = spec_query(oracle)
+    now -= 90 * DAY
+    gpu_ctx.load_columns(s, e, u, d, U)
+    gpu_ctx.set_disciplines(mask, 32)
+    with_window = gpu_ctx.scan(now, cutoff)
+    pruned = gpu_ctx.prune_before(cutoff)
+    assert np.array_equal(pruned, np.nonzero(s < cutoff)[0])
+    assert_same(gpu_ctx.scan(now, INT64_MIN), with_window)
+    assert gpu_ctx.prune_before(cutoff).size == 0
+
+
 def test_expired_queue_parity(gpu_ctx, oracle):
     for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
         s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)
