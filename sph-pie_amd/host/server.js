@@ -78,6 +78,17 @@ function createServer(options){
       if(req.method === 'GET' && path === '/api/calendar'){
         return handleCalendar(req, res);
       }
+      if(req.method === 'GET' && path === '/api/health'){
+        // existing keys of /root/reference/server/index.js:132-144 kept (status, storage, storageMeta); the device
+        // scan statistics ride along under a new key, nothing existing changes meaning
+        const st = store.native.stats(store.ctx);
+        return sendJson(res, 200, {
+          status: 'ok',
+          storage: 'MI355X HBM columns',
+          storageMeta: {label: 'MI355X HBM columns', driver: 'libpie_hip', sessions: store.size()},
+          scan: {rows: st.rows, users: st.users, lastSelected: st.selected, algBytesPerScan: st.algBytes}
+        });
+      }
       return sendJson(res, 404, {error: 'Not found'});
     }catch(err){
       console.error(err);

@@ -165,6 +165,10 @@ function get(port, cookie){
     eq(lead.body.events[0].endTs - lead.body.events[0].startTs, store.SESSION_TTL_MS);
     eq((await get(port, ck(cookies['u-crew']))).body.events.length, 2);
     eq((await get(port, ck(cookies['u-admin']))).body.events.length, 1);
+    const health = await new Promise((resolve, reject) => {
+      http.get({host: '127.0.0.1', port, path: '/api/health'}, res => { let b = ''; res.on('data', c => { b += c; }); res.on('end', () => resolve(JSON.parse(b))); }).on('error', reject);
+    });
+    eq([health.status, health.storage, health.scan.rows, health.scan.users], ['ok', 'MI355X HBM columns', 10, 6]);
     // expiry: 12 h later every session is dead -> 401; the device agrees (no live rows)
     fakeNow = t + store.SESSION_TTL_MS + 10000;
     eq((await get(port, ck(cookies['u-lead']))).status, 401);

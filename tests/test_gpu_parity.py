@@ -168,6 +168,37 @@ def test_two_scans_in_flight(pie, oracle):
         assert_same(ctx.scan(*queries[1]), want[1])
 
 
+def test_randomized_tables_and_queries(pie, oracle):
+    """Seeded fuzz: 40 tables of random size / user count / skew / sentinels, each scanned with several random
+    queries (the same query twice in a row so that both the first-scan form and the adapted form run)."""
+    rng = np.random.default_rng(20261004)
+    with pie.PieScan(0) as ctx:
+        for case in range(40):
+            n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 129, 4095, 4096, 4097, int(rng.integers(1, 300000))]))
+            U = int(rng.integers(1, 4000))
+            D = int(rng.integers(1, 65))
+            s, e, u, d = oracle.gen(int(rng.integers(0, 2 ** 62)), max(n, 1), 0, n, U, D, int(rng.integers(0, 4)))
+            if n and rng.random() < 0.5:      # power-law users: a few huge buckets, many empty ones
+                u = np.minimum((U * rng.random(n) ** 4).astype(np.int32), U - 1)
+            if n and rng.random() < 0.3:
+                e[rng.random(n) < 0.2] = INT64_MIN
+            if n and rng.random() < 0.3:
+                d[rng.random(n) < 0.1] = int(rng.choice([-1, 64, 200, -2 ** 31]))
+            if n and rng.random() < 0.3:
+                s[rng.random(n) < 0.5] = int(s[0])       # many equal starts: tie rule
+            ctx.load_columns(s, e, u, d, U)
+            for _ in range(3):
+                now = int(rng.choice([INT64_MIN, 2 ** 62, int(oracle.T0_MS - rng.integers(0, 130) * DAY)]))
+                cutoff = int(rng.choice([INT64_MIN, int(oracle.T0_MS - rng.integers(0, 130) * DAY)]))
+                mask = int(rng.integers(0, 2 ** 63)) | (int(rng.integers(0, 2)) << 63)
+                ctx.set_disciplines(mask, D)
+                want = oracle.scan(s, e, u, d, U, now, cutoff, mask if D >= 64 else mask & ((1 << D) - 1))
+                assert_same(ctx.scan(now, cutoff), want)
+                assert_same(ctx.scan(now, cutoff), want)
+                prev = int(now - rng.integers(1, 40) * DAY) if abs(now) < 2 ** 61 else INT64_MIN
+                assert np.array_equal(ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now))
+
+
 def test_generator_parity(gpu_ctx, oracle):
     for n, U, D, flags in [(1000, 10, 3, 0), (70001, 333, 32, 1), (70001, 333, 32, 2), (4096, 4096, 64, 3)]:
         gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, flags)

@@ -145,3 +145,20 @@ def test_generator_slices_agree(oracle):
     l = oracle.lib()
     assert l.pie_oracle_splitmix64(0) == 0xE220A8397B1DCDAF
     assert l.pie_oracle_splitmix64(0x9E3779B97F4A7C15) == 0x6E789E6AA1B965F4
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """ASan + UBSan over the native CPU code (the only native code a sanitizer can cover here: GPU ASan is not
+    available on the pool).  Sizes straddle the merge-sort run length and the realloc growth points."""
+    import shutil
+    import subprocess
+    from conftest import REPO
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    odir = os.path.join(REPO, "oracle")
+    exe = tmp_path / "selftest_asan"
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-o", str(exe), os.path.join(odir, "selftest.c"),
+                           os.path.join(odir, "pie_oracle.c")])
+    res = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "oracle selftest ok" in res.stdout, res.stdout
