@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--users", type=int, default=10 ** 5, help="users per GPU shard")
     ap.add_argument("--disc", type=int, default=32)
     ap.add_argument("--order", choices=["random", "clustered"], default="random")
+    ap.add_argument("--users-dist", choices=["uniform", "zipf"], default="uniform", help="zipf: Zipf(1.1) over the shard's users")
     ap.add_argument("--variant", choices=["auth", "interval"], default="auth")
     ap.add_argument("--query", choices=["spec", "wide"], default="spec",
                     help="spec: now=T0-6h, cutoff=T0-61d, 16/32 disciplines (SURVEY.md §8d); wide: ~25%% selected")
@@ -134,7 +135,10 @@ def main():
     ctx = pie.PieScan(local_rank)
     t_gen = time.perf_counter()
     # every rank owns the users that hash to it; its shard is rows [rank*N, (rank+1)*N) of the world*N-row corpus
-    ctx.gen_synthetic(SEED, N * world, N * rank, N, U, D, flags)
+    if args.users_dist == "zipf":
+        ctx.gen_synthetic_cdf(SEED, N * world, N * rank, N, U, D, flags, pie.zipf_cdf(U))
+    else:
+        ctx.gen_synthetic(SEED, N * world, N * rank, N, U, D, flags)
     ctx.set_disciplines(mask, D)
     log("rank %d: generated %d rows in %.2f s" % (rank, N, time.perf_counter() - t_gen))
 
@@ -199,7 +203,8 @@ def main():
             kname = "k_expired_stage"
         traffic = None
         tpath = os.path.join(REPO, "profiles", "k1_traffic.json")
-        default_workload = (N, U, D, args.order, args.variant, args.query, args.mode) == (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan")
+        default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist) == \
+            (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform")
         if default_workload and os.path.exists(tpath):
             tdoc = json.load(open(tpath))
             if tdoc.get("kernel", "").endswith(kname) or kname in tdoc.get("kernel", ""):
@@ -214,7 +219,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
-                            "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s variant, %s query" % (N, U, D, args.order, args.variant, args.query),
+                            "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s users, %s variant, %s query" % (N, U, D, args.order, args.users_dist, args.variant, args.query),
                 "sessions_per_gpu": N, "users_per_gpu": U, "disciplines": D, "selected_rows_rank0": int(m),
                 "parallelism": "user-hash shards x%d, RCCL all-gather of per-user offsets + row lists, overlapped with the next scan" % world if world > 1 else "single GPU",
             },

@@ -90,6 +90,10 @@ int pie_append_rows(pie_ctx *ctx, const int64_t *start, const int64_t *end, cons
 /* Fill the table on the device with rows [row0, row0+n) of the deterministic synthetic corpus. */
 int pie_gen_synthetic(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
                       int32_t n_disc, uint32_t flags);
+/* Same corpus with skewed users (the "Zipf(1.1)" variant of SURVEY.md §8d): user = first k with r0 < cdf[k], cdf =
+ * n_users ascending 64-bit thresholds floor(CDF_k * 2^64) computed by the caller. */
+int pie_gen_synthetic_cdf(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
+                          int32_t n_disc, uint32_t flags, const uint64_t *cdf);
 /* Copy the resident columns back (any pointer may be NULL). */
 int pie_read_columns(pie_ctx *ctx, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, size_t n);
 /* touchSession (server/sessionStore.js:37-45): end[row] = new_end.  deleteSession (:47-53): new_end = PIE_END_NONE. */

@@ -31,6 +31,8 @@ def lib():
         P = C.c_void_p
         l.pie_oracle_gen.restype = None
         l.pie_oracle_gen.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, P, P, P, P]
+        l.pie_oracle_gen_cdf.restype = None
+        l.pie_oracle_gen_cdf.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, P, P, P, P, P]
         l.pie_oracle_selected.restype = C.c_int
         l.pie_oracle_selected.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_uint64]
         l.pie_oracle_scan.restype = C.c_int
@@ -54,6 +56,24 @@ def gen(seed, n_total, row0, n, n_users, n_disc, flags=0):
     s, e = np.empty(n, np.int64), np.empty(n, np.int64)
     u, d = np.empty(n, np.int32), np.empty(n, np.int32)
     lib().pie_oracle_gen(seed, n_total, row0, n, n_users, n_disc, flags, _p(s), _p(e), _p(u), _p(d))
+    return s, e, u, d
+
+
+def zipf_cdf(n_users, exponent=1.1):
+    """uint64 thresholds floor(CDF_k * 2^64) of Zipf(exponent) over n_users ranks; the last one is 2^64 - 1."""
+    w = 1.0 / np.arange(1, n_users + 1, dtype=np.float64) ** exponent
+    c = np.cumsum(w) / w.sum()
+    thr = np.minimum(np.floor(c * 2.0 ** 64), 2.0 ** 64 - 2048).astype(np.uint64)
+    thr[-1] = np.uint64(2 ** 64 - 1)
+    return np.maximum.accumulate(thr)
+
+
+def gen_cdf(seed, n_total, row0, n, n_users, n_disc, flags, cdf):
+    s, e = np.empty(n, np.int64), np.empty(n, np.int64)
+    u, d = np.empty(n, np.int32), np.empty(n, np.int32)
+    cdf = np.ascontiguousarray(cdf, np.uint64)
+    assert cdf.shape[0] == n_users
+    lib().pie_oracle_gen_cdf(seed, n_total, row0, n, n_users, n_disc, flags, _p(cdf), _p(s), _p(e), _p(u), _p(d))
     return s, e, u, d
 
 

@@ -50,6 +50,21 @@ void pie_oracle_gen(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int
     }
 }
 
+void pie_oracle_gen_cdf(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
+                        uint32_t flags, const uint64_t *cdf, int64_t *start, int64_t *end, int32_t *user, int32_t *disc)
+{
+    pie_oracle_gen(seed, n_total, row0, n, n_users, n_disc, flags & ~PIE_GEN_CLUSTERED, start, end, user, disc);
+    for (int64_t k = 0; k < n; ++k) {
+        const uint64_t r0 = sm_out(seed, 4 * (uint64_t)(row0 + k));
+        int32_t lo = 0, hi = n_users - 1; /* first index with r0 < cdf[index]; the last threshold catches everything */
+        while (lo < hi) {
+            const int32_t mid = lo + (hi - lo) / 2;
+            if (r0 < cdf[mid]) hi = mid; else lo = mid + 1;
+        }
+        user[k] = lo;
+    }
+}
+
 /* ---------------------------------------------------------------- row predicate (SURVEY.md §8 a-D) */
 
 int pie_oracle_selected(int64_t start, int64_t end, int32_t disc, int64_t now, int64_t cutoff, uint64_t disc_mask)

@@ -37,6 +37,13 @@ extern "C" {
 void pie_oracle_gen(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
                     uint32_t flags, int64_t *start, int64_t *end, int32_t *user, int32_t *disc);
 
+/* Skewed-user variant (SURVEY.md §8d "Zipf(1.1)"): like pie_oracle_gen, but user = the first k with r0 < cdf[k],
+ * where cdf[0..n_users) are ascending 64-bit thresholds supplied by the caller (floor(CDF_k * 2^64), last = 2^64-1).
+ * The table is computed once on the host in floating point and handed to both the oracle and the product, so the
+ * corpus itself stays integer-exact on both sides. */
+void pie_oracle_gen_cdf(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
+                        uint32_t flags, const uint64_t *cdf, int64_t *start, int64_t *end, int32_t *user, int32_t *disc);
+
 /* Row-level predicate of the [DERIVED] contract. */
 int pie_oracle_selected(int64_t start, int64_t end, int32_t disc, int64_t now, int64_t cutoff, uint64_t disc_mask);
 

@@ -10,5 +10,15 @@ from .binding import (ABI_SYMBOLS, PIE_END_NONE, PIE_GEN_CLUSTERED, PIE_GEN_INTE
                       load_library, shard_of)
 from .build import build_all, build_hip, build_napi, build_oracle
 
+
+def zipf_cdf(n_users, exponent=1.1):
+    """uint64 thresholds floor(CDF_k * 2^64) of Zipf(exponent) over n_users ranks (for gen_synthetic_cdf)."""
+    import numpy as np
+    w = 1.0 / np.arange(1, n_users + 1, dtype=np.float64) ** exponent
+    c = np.cumsum(w) / w.sum()
+    thr = np.minimum(np.floor(c * 2.0 ** 64), 2.0 ** 64 - 2048).astype(np.uint64)
+    thr[-1] = np.uint64(2 ** 64 - 1)
+    return np.maximum.accumulate(thr)
+
 __all__ = ["ABI_SYMBOLS", "PIE_END_NONE", "PIE_GEN_CLUSTERED", "PIE_GEN_INTERVAL", "PieError", "PieScan",
-           "load_library", "shard_of", "build_all", "build_hip", "build_napi", "build_oracle"]
+           "load_library", "shard_of", "zipf_cdf", "build_all", "build_hip", "build_napi", "build_oracle"]

@@ -44,6 +44,7 @@ _SIGS = [
     ("pie_ctx_aux_stream", C.c_int, [_P, C.POINTER(_P)]),
     ("pie_load_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_gen_synthetic", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
+    ("pie_gen_synthetic_cdf", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, _P]),
     ("pie_read_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
     ("pie_set_end", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("pie_delete_user", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -145,6 +146,14 @@ class PieScan:
 
     def gen_synthetic(self, seed, n_total, row0, n, n_users, n_disc, flags=0):
         self._check(self._lib.pie_gen_synthetic(self._ctx, seed, n_total, row0, n, n_users, n_disc, flags))
+        self.n, self.n_users = int(n), int(n_users)
+
+    def gen_synthetic_cdf(self, seed, n_total, row0, n, n_users, n_disc, flags, cdf):
+        """Skewed users: cdf = n_users ascending uint64 thresholds (floor(CDF_k * 2^64))."""
+        cdf = np.ascontiguousarray(cdf, np.uint64)
+        if cdf.shape[0] != n_users:
+            raise ValueError("cdf must have n_users entries")
+        self._check(self._lib.pie_gen_synthetic_cdf(self._ctx, seed, n_total, row0, n, n_users, n_disc, flags, _ptr(cdf)))
         self.n, self.n_users = int(n), int(n_users)
 
     def read_columns(self):

@@ -93,6 +93,7 @@ struct pie_ctx {
     int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
     bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
     double live_frac = -1;    // live fraction seen by the last finished scan of this table (-1: none yet)
+    bool hot_bucket = false;  // the last finished scan had one bucket with > 1/64 of the selected rows
 
     Slot slot[2];
     char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
@@ -270,6 +271,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     c->n_users = n_users;
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
     c->live_frac = -1;
+    c->hot_bucket = false;
     c->res = nullptr;
     for (Slot& s : c->slot) s.have_result = false;
     // all three spans start clean; from here on every K2 zeroes the span of the scan after it
@@ -313,7 +315,8 @@ int resolve_events(pie_ctx* c)
 }
 
 // K1 forms.  Variant code: bit0 nontemporal loads, bit1 late user materialisation, bit2 liveness-first form
-// (streams only `end`, gathers the other columns for live rows); bits 4.. = unroll (0 -> 4).
+// (streams only `end`, gathers the other columns for live rows); bits 4,5,7 = unroll (0 -> 4, 0x20 -> 2, 0x80 -> 8);
+// bit6 (0x40, liveness-first only) = wave-aggregated histogram atomics for skewed users.
 // PIE_K1_VARIANT pins one form (tuning / A-B runs); otherwise the form follows the live fraction that the
 // previous scan on this table observed: liveness-first below kLiveFirstBelow, the streaming form above.
 constexpr double kLiveFirstBelow = 0.10; // measured crossover ~0.16 live (profiles/r01_c_live_fraction_crossover.txt)
@@ -325,10 +328,15 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
                        sl.sel_rank, sl.blk_count, sl.sum)
 #define PIE_K1L(UN, NT)                                                                                             \
-    hipLaunchKernelGGL((k_scan_live_first<UN, NT>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+    if (sl.variant & 0x40)                                                                                          \
+        hipLaunchKernelGGL((k_scan_live_first<UN, NT, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
+                           c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
+                           sl.sel_rank, sl.blk_count, sl.sum);                                                      \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
                        sl.sel_rank, sl.blk_count, sl.sum)
-    switch (sl.variant) {
+    switch (sl.variant & ~0x40) {
     case 0x00: PIE_K1(4, false, false); break;
     case 0x01: PIE_K1(4, true, false); break;
     case 0x02: PIE_K1(4, false, true); break;
@@ -380,6 +388,8 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
     sl.variant = c->k1_variant;
     if (!c->k1_pinned && c->live_frac >= 0) sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+    // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
+    if (!c->k1_pinned && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
     const int plan = (sl.variant & 4) ? 1 : 0;
     sl.k1_blocks = c->plan_blocks[plan];
     sl.rows_per_block = c->plan_rows[plan];
@@ -441,6 +451,7 @@ int scan_finish(pie_ctx* c)
     }
     sl.last = sl.h_sum->s;
     c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
+    c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
 
     if (sl.last.m > 0) {
         int scat_blocks = sl.k1_blocks;
@@ -677,6 +688,28 @@ int pie_gen_synthetic(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, 
         PIE_HIP(c, hipGetLastError());
     }
     PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
+int pie_gen_synthetic_cdf(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
+                          int32_t n_disc, uint32_t flags, const uint64_t* cdf)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!cdf) return fail(c, PIE_E_INVAL, "cdf is NULL");
+    int rc = pie_gen_synthetic(c, seed, n_total, row0, n, n_users, n_disc, flags & ~2u);
+    if (rc || n == 0) return rc;
+    unsigned long long* d_cdf = nullptr;
+    PIE_HIP(c, hipMalloc(&d_cdf, (size_t)n_users * 8));
+    hipError_t e = hipMemcpyAsync(d_cdf, cdf, (size_t)n_users * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gen_users_cdf, dim3(c->n_cus * 8), dim3(256), 0, c->stream, seed, (long long)row0, (long long)n,
+                           n_users, d_cdf, c->d_user);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_cdf);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, PIE_E_HIP, "pie_gen_synthetic_cdf: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return PIE_OK;
 }
 

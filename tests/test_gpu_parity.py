@@ -103,7 +103,7 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
     run_both(gpu_ctx, oracle, cols, U, D, oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)
 
 
-@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85])
+@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
     through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
@@ -209,6 +209,30 @@ def test_generator_parity(gpu_ctx, oracle):
     gpu_ctx.gen_synthetic(SEED, 10 ** 6, 123456, 5000, 100, 32, 1)  # a slice of a bigger table
     for a, b in zip(gpu_ctx.read_columns(), oracle.gen(SEED, 10 ** 6, 123456, 5000, 100, 32, 1)):
         assert np.array_equal(a, b)
+
+
+def test_zipf_corpus_parity(pie, gpu_ctx, oracle):
+    """The skewed-user corpus (Zipf(1.1) thresholds from the host): generator and scan bit-exact vs the oracle; the head
+    user's bucket goes through the tile + merge path."""
+    n, U, D = 2 * 10 ** 6, 20000, 32
+    cdf = pie.zipf_cdf(U)
+    assert np.array_equal(cdf, oracle.zipf_cdf(U)) and np.all(np.diff(cdf.astype(np.float64)) >= 0)
+    gpu_ctx.gen_synthetic_cdf(SEED, n, 0, n, U, D, 1, cdf)
+    want_cols = oracle.gen_cdf(SEED, n, 0, n, U, D, 1, cdf)
+    for a, b in zip(gpu_ctx.read_columns(), want_cols):
+        assert np.array_equal(a, b)
+    head = np.bincount(want_cols[2], minlength=U)
+    assert head[0] > 0.08 * n and head[0] > 20 * head[100]
+    gpu_ctx.set_disciplines(ALL, D)
+    for now, cutoff in [(INT64_MIN, INT64_MIN), spec_query(oracle)[:2], (oracle.T0_MS - 60 * DAY, INT64_MIN)]:
+        assert_same(gpu_ctx.scan(now, cutoff), oracle.scan(*want_cols, U, now, cutoff, 0xFFFFFFFF))
+    assert gpu_ctx.stats()["n_big"] >= 1
+    # a skewed table switches the liveness-first form to wave-aggregated histogram atomics on the next scan
+    now, cutoff, _ = spec_query(oracle)
+    want = oracle.scan(*want_cols, U, now, cutoff, 0xFFFFFFFF)
+    for _ in range(3):
+        assert_same(gpu_ctx.scan(now, cutoff), want)
+    assert gpu_ctx.stats()["k1_variant"] == 0xC5
 
 
 def test_skewed_users_big_buckets(gpu_ctx, oracle):
