@@ -8,8 +8,9 @@
 //                        agent-scope granules, tiles claimed by ticket), work lists for K4, summary to the
 //                        host through mapped memory, and the zeroing of the other slot's histogram
 //   K3  k_scatter        selected records -> per-user buckets (slot = offsets[u] + atomic rank)
-//   K4  k_sort_buckets  one launch: buckets of <= 16 rows in registers (one thread each, sorting network);
-//                       larger buckets (or 4096-row tiles of big buckets) one block each, LDS bitonic
+//   K4  k_sort_tiny      buckets of <= 16 rows: one thread each, bitonic network in registers
+//       k_sort_small     17..512 rows: one wave each, bitonic in registers + cross-lane exchanges (launched if any)
+//       k_sort_segments  513..4096 rows and 4096-row tiles of big buckets: one 1024-thread block each, LDS bitonic
 //   K4c k_merge_pass     big buckets only: log2(n/4096) rank-merge passes
 // Order inside a bucket is (start asc, row index asc): ORDER BY start_ts ASC
 // (/root/reference/server/storage/sqlProvider.js:276) with the tie rule of SURVEY.md §8 a-D.
@@ -723,31 +724,32 @@ __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ 
 }
 
 // K4b: one block per segment (<= kSegMax rows): bitonic sort of (start, idx) in LDS.
-// K4 is ONE launch: blocks [0, tiny_blocks) run K4a, the remaining blocks walk the segment list.
-__global__ __launch_bounds__(256) void k_sort_buckets(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                      int n_users, int tiny_blocks, const Segment* __restrict__ seg_list,
-                                                      const Summary* __restrict__ summary,
-                                                      BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+// K4 (tiny buckets): one thread per user, buckets of <= 16 rows sorted in registers.
+__global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                   int n_users, const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, out_idx);
+}
+
+// K4 (segments): buckets of 513..4096 rows, and the 4096-row tiles of bigger buckets: one 1024-thread block each,
+// bitonic sort of (start, idx) in LDS.  1024 threads because the sort is a chain of up to 78 barrier-separated
+// steps: its latency, not its throughput, is what a skewed table pays (one hot bucket = one block).
+__global__ __launch_bounds__(1024) void k_sort_segments(const Segment* __restrict__ seg_list, const Summary* __restrict__ summary,
+                                                        BktRec* __restrict__ bkt, int* __restrict__ out_idx)
 {
     __shared__ long long ks[kSegMax];
     __shared__ int ki[kSegMax];
-    if ((int)blockIdx.x < tiny_blocks) {
-        const int u = blockIdx.x * 256 + threadIdx.x;
-        if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, out_idx);
-        return;
-    }
     const unsigned n_seg = summary->n_seg;
-    const unsigned seg_blocks = gridDim.x - tiny_blocks;
-    for (unsigned w = blockIdx.x - tiny_blocks; w < n_seg; w += seg_blocks) {
+    for (unsigned w = blockIdx.x; w < n_seg; w += gridDim.x) {
         const Segment sg = seg_list[w];
-        int p = 32;
+        int p = 64;
         while (p < sg.len) p <<= 1;
         for (int i = threadIdx.x; i < p; i += blockDim.x) {
-            const bool in = i < sg.len;
             BktRec r;
             r.start = INT64_MAX;
             r.idx = INT32_MAX;
-            if (in) r = bkt[sg.pos + i];
+            if (i < sg.len) r = bkt[sg.pos + i];
             ks[i] = r.start;
             ki[i] = r.idx;
         }

@@ -459,9 +459,11 @@ int scan_finish(pie_ctx* c)
         hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
                            sl.rows_per_block, sl.offsets, sl.bkt);
         const int tiny_blocks = (c->n_users + 255) / 256;
-        const int seg_blocks = sl.last.n_seg < (unsigned)(c->n_cus * 3) ? (int)sl.last.n_seg : c->n_cus * 3;
-        hipLaunchKernelGGL(k_sort_buckets, dim3(tiny_blocks + seg_blocks), dim3(256), 0, a, sl.counts, sl.offsets,
-                           c->n_users, tiny_blocks, sl.seg_list, sl.sum, sl.bkt, sl.out_idx);
+        hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, a, sl.counts, sl.offsets, c->n_users, sl.bkt, sl.out_idx);
+        if (sl.last.n_seg > 0) {
+            const unsigned seg_blocks = sl.last.n_seg < (unsigned)(c->n_cus * 3) ? sl.last.n_seg : (unsigned)(c->n_cus * 3);
+            hipLaunchKernelGGL(k_sort_segments, dim3(seg_blocks), dim3(1024), 0, a, sl.seg_list, sl.sum, sl.bkt, sl.out_idx);
+        }
         if (sl.last.n_small > 0) {
             unsigned small_blocks = (sl.last.n_small + 3) / 4;
             if (small_blocks > (unsigned)c->n_cus * 8) small_blocks = (unsigned)c->n_cus * 8;
