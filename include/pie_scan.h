@@ -147,6 +147,13 @@ int pie_fetch_rows(pie_ctx *ctx, const int32_t *idx, size_t m, int64_t *start, i
  * not yet dead at `prev_now`); order = the sequential-await order of server/storage/sqlProvider.js:834-861. */
 int pie_expired_queue(pie_ctx *ctx, int64_t prev_now, int64_t now, int32_t *queue_out, size_t cap, size_t *q_out);
 
+/* The reference's own archive chain (server/storage/sqlProvider.js:758-816 _archiveDailyShows), [DERIVED] onto the
+ * session table with the user column as the group key: a group's earliest = min(start) over its (non-tombstoned)
+ * rows; it qualifies iff now - earliest >= window_ms (:798, AUTO_ARCHIVE_WINDOW_MS :9); every row of a qualifying
+ * group is queued, groups in order of first appearance (Map insertion order), rows in table order inside a group —
+ * the order in which :834-861 dispatches them. */
+int pie_archive_queue(pie_ctx *ctx, int64_t now, int64_t window_ms, int32_t *queue_out, size_t cap, size_t *q_out);
+
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
  * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */

@@ -182,3 +182,47 @@ int pie_oracle_expired_queue(const int64_t *end, size_t n, int64_t prev_now, int
     if (q_out) *q_out = q;
     return q > cap ? -1 : 0;
 }
+
+/* ---------------------------------------------------------------- "next" row: archive group-min chain */
+
+int pie_oracle_archive_queue(const int64_t *start, const int64_t *end, const int32_t *user, size_t n, int32_t n_users,
+                             int64_t now, int64_t window_ms, int32_t *queue, size_t cap, size_t *q_out)
+{
+    /* groups = new Map(); rows.forEach(...groups.get(key).push(...)) — server/storage/sqlProvider.js:763-782 */
+    int64_t *earliest = (int64_t *)malloc((size_t)n_users * sizeof(int64_t));
+    int32_t *order = (int32_t *)malloc((size_t)n_users * sizeof(int32_t)); /* keys in first-appearance order */
+    unsigned char *seen = (unsigned char *)calloc((size_t)n_users, 1);
+    if (!earliest || !order || !seen) { free(earliest); free(order); free(seen); return -3; }
+    int32_t n_groups = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (end[i] == INT64_MIN) continue; /* deleted row: not in the table */
+        const int32_t g = user[i];
+        if (g < 0 || g >= n_users) { free(earliest); free(order); free(seen); return -2; }
+        if (!seen[g]) { seen[g] = 1; order[n_groups++] = g; earliest[g] = start[i]; }
+        else if (start[i] < earliest[g]) earliest[g] = start[i]; /* list.reduce(min), :785-794 */
+    }
+    /* now - earliest >= AUTO_ARCHIVE_WINDOW_MS (:798); JS numbers cannot overflow, int64 can: compare without
+     * forming the difference when it would */
+    unsigned char *qual = seen; /* reuse: 1 = seen, 2 = qualifies */
+    for (int32_t k = 0; k < n_groups; ++k) {
+        const int32_t g = order[k];
+        const __int128 diff = (__int128)now - (__int128)earliest[g];
+        if (diff >= (__int128)window_ms) qual[g] = 2;
+    }
+    /* for (const list of groups.values()) ... for (const item of list) archivedShows.push(...) — :784-811:
+     * group order = first appearance, row order inside the group */
+    size_t q = 0;
+    for (int32_t k = 0; k < n_groups; ++k) {
+        const int32_t g = order[k];
+        if (qual[g] != 2) continue;
+        for (size_t i = 0; i < n; ++i) { /* O(groups x n): this is an oracle for small cases */
+            if (user[i] == g && end[i] != INT64_MIN) {
+                if (q < cap) queue[q] = (int32_t)i;
+                ++q;
+            }
+        }
+    }
+    free(earliest); free(order); free(seen);
+    if (q_out) *q_out = q;
+    return q > cap ? -1 : 0;
+}

@@ -57,6 +57,14 @@ int pie_oracle_scan(const int64_t *start, const int64_t *end, const int32_t *use
 int pie_oracle_expired_queue(const int64_t *end, size_t n, int64_t prev_now, int64_t now, int32_t *queue,
                              size_t cap, size_t *q_out);
 
+/* "next" row, the reference's own chain (server/storage/sqlProvider.js:758-816 _archiveDailyShows): rows are
+ * grouped by a key (there: the show's date string; here [DERIVED]: the user column), a group's `earliest` is the
+ * minimum createdAt (= start) of its rows, a group qualifies iff now - earliest >= window, and EVERY row of a
+ * qualifying group is queued — groups in order of first appearance (Map insertion order, :769-789), rows in table
+ * order inside a group — for the sequential dispatch of :834-861.  Tombstoned rows (end == INT64_MIN) are absent. */
+int pie_oracle_archive_queue(const int64_t *start, const int64_t *end, const int32_t *user, size_t n, int32_t n_users,
+                             int64_t now, int64_t window_ms, int32_t *queue, size_t cap, size_t *q_out);
+
 /* user-hash sharding rule shared with the product: rank = splitmix64(user) mod G. */
 uint64_t pie_oracle_splitmix64(uint64_t x);
 int32_t pie_oracle_shard_of(int32_t user, int32_t n_shards);

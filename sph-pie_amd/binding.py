@@ -61,6 +61,7 @@ _SIGS = [
     ("pie_pack_results_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_fetch_rows", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("pie_expired_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_archive_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_set_profiling", C.c_int, [_P, C.c_int]),
     ("pie_stats_get", C.c_int, [_P, C.POINTER(PieStats)]),
     ("pie_stats_reset", C.c_int, [_P]),
@@ -266,6 +267,13 @@ class PieScan:
             return q.value
         out = np.empty(max(self.n, 1), np.int32)
         self._check(self._lib.pie_expired_queue(self._ctx, int(prev_now), int(now), _ptr(out), self.n, C.byref(q)))
+        return out[: q.value].copy()
+
+    def archive_queue(self, now, window_ms=43200000):
+        """Rows of every group (user) whose earliest start is at least window_ms old, groups in first-appearance order."""
+        q = C.c_size_t(0)
+        out = np.empty(max(self.n, 1), np.int32)
+        self._check(self._lib.pie_archive_queue(self._ctx, int(now), int(window_ms), _ptr(out), self.n, C.byref(q)))
         return out[: q.value].copy()
 
     # ---- measurement / plumbing

@@ -216,13 +216,17 @@ __device__ __forceinline__ T stream_load(const T* p)
 //   NT      nontemporal (streaming) loads for the read-once columns
 //   LATE_U  load user[] only in lanes whose row passed the predicate (late materialisation): the user column
 //           is output data, not predicate input, so unselected rows never need it
-template <int UNROLL, bool NT, bool LATE_U>
+//   GQ      group-qualified form (archive queue): the row predicate is "row not tombstoned and qual[user] != 0" and the
+//           staged sort key is 0, so the per-bucket order is plain row order
+template <int UNROLL, bool NT, bool LATE_U, bool GQ = false>
 __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
+    const unsigned char* __restrict__ qual = nullptr)
 {
+    static_assert(!(GQ && LATE_U), "the group-qualified predicate needs the user column up front");
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
     __shared__ int blk_cursor;
@@ -263,8 +267,15 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
             int rank[2 * UNROLL];
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
-                p[2 * j] = row_selected(s[j].x, e[j].x, d[j].x, now, cutoff, mask);
-                p[2 * j + 1] = row_selected(s[j].y, e[j].y, d[j].y, now, cutoff, mask);
+                if constexpr (GQ) {
+                    p[2 * j] = (e[j].x != INT64_MIN) && (unsigned)u[j].x < (unsigned)n_users && qual[u[j].x];
+                    p[2 * j + 1] = (e[j].y != INT64_MIN) && (unsigned)u[j].y < (unsigned)n_users && qual[u[j].y];
+                    s[j].x = 0;
+                    s[j].y = 0;
+                } else {
+                    p[2 * j] = row_selected(s[j].x, e[j].x, d[j].x, now, cutoff, mask);
+                    p[2 * j + 1] = row_selected(s[j].y, e[j].y, d[j].y, now, cutoff, mask);
+                }
                 nlive += __popcll(__ballot(e[j].x > now)) + __popcll(__ballot(e[j].y > now));
                 if constexpr (LATE_U) {
                     const long long r = t + j * kUnitRows + 2 * lane;
@@ -306,6 +317,11 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
                 if (r < t1) {
                     sv = start[r];
                     sel_row = row_selected(sv, ev, disc[r], now, cutoff, mask);
+                    if constexpr (GQ) {
+                        const int ug = user[r];
+                        sel_row = (ev != INT64_MIN) && (unsigned)ug < (unsigned)n_users && qual[ug];
+                        sv = 0;
+                    }
                     if (sel_row) {
                         uv = user[r];
                         if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[uv], 1);
@@ -1122,6 +1138,48 @@ __global__ __launch_bounds__(256) void k_expired_gather(const int* __restrict__ 
         const long long src = (long long)w * rows_per_wave, dst = wave_off[w];
         for (int i = lane; i < cnt; i += 64)
             if (dst + i < cap) queue[dst + i] = stage[src + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ archive group-min chain
+
+// Per group (key = user column): earliest = min(start) and first = min(row) over the rows present (not tombstoned):
+// the `list.reduce(min)` and the Map insertion order of /root/reference/server/storage/sqlProvider.js:763-794.
+// A row only issues an atomic when it improves the value it reads first (minima only decrease, so a stale read can
+// only cause a redundant atomic, never a missed one): ~ln(group size) atomics per group instead of one per row.
+__global__ __launch_bounds__(256) void k_group_stats(const long long* __restrict__ start, const long long* __restrict__ end,
+                                                     const int* __restrict__ user, long long n, int n_users,
+                                                     long long* __restrict__ min_start, int* __restrict__ first_row)
+{
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        if (end[r] == INT64_MIN) continue;
+        const int g = user[r];
+        if ((unsigned)g >= (unsigned)n_users) continue;
+        const long long sv = start[r];
+        if (sv < min_start[g]) atomicMin(&min_start[g], sv);
+        if ((int)r < first_row[g]) atomicMin(&first_row[g], (int)r);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_group_init(long long* __restrict__ min_start, int* __restrict__ first_row, int n_users)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < n_users) {
+        min_start[g] = INT64_MAX;
+        first_row[g] = INT32_MAX;
+    }
+}
+
+// queue = concatenation of the qualifying groups' row lists in first-appearance order: group k (user grp_user[k]) owns
+// queue[grp_off[k] .. grp_off[k+1]); its rows sit, already in row order, at idx[offsets[user] .. +counts[user])
+__global__ __launch_bounds__(256) void k_group_gather(const int* __restrict__ grp_user, const long long* __restrict__ grp_off,
+                                                      int n_groups, const long long* __restrict__ offsets,
+                                                      const int* __restrict__ idx, int* __restrict__ queue, long long cap)
+{
+    for (int k = blockIdx.x; k < n_groups; k += gridDim.x) {
+        const long long src = offsets[grp_user[k]], dst = grp_off[k], cnt = grp_off[k + 1] - dst;
+        for (long long i = threadIdx.x; i < cnt; i += 256)
+            if (dst + i < cap) queue[dst + i] = idx[src + i];
     }
 }
 

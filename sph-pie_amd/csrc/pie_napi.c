@@ -38,6 +38,7 @@
     X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
     X(int, pie_fetch_rows, (pie_ctx *, const int32_t *, size_t, int64_t *, int64_t *, int32_t *, int32_t *))        \
     X(int, pie_expired_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
+    X(int, pie_archive_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
     X(int, pie_stats_get, (pie_ctx *, pie_stats *))                                                                 \
     X(int, pie_stats_reset, (pie_ctx *))
@@ -460,6 +461,24 @@ static napi_value fn_expired_queue(napi_env env, napi_callback_info info)
     return js_int(env, (int64_t)q);
 }
 
+/* archiveQueue(ctx, now, windowMs, queue Int32Array) -> q */
+static napi_value fn_archive_queue(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t now, window;
+    size_t cap = 0, q = 0;
+    int32_t *queue = typed(env, argv[3], napi_int32_array, &cap);
+    if (!get_i64(env, argv[1], &now) || !get_i64(env, argv[2], &window) || !queue) {
+        napi_throw_type_error(env, NULL, "archiveQueue(ctx, now, windowMs, Int32Array)");
+        return NULL;
+    }
+    int rc = p_pie_archive_queue(ctx, now, window, queue, cap, &q);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)q);
+}
+
 /* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
@@ -505,7 +524,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
         {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
-        {"expiredQueue", fn_expired_queue}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+        {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

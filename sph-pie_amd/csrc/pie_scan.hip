@@ -20,6 +20,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -103,6 +104,7 @@ struct pie_ctx {
     int next_slot = 0;   // slot the next pie_scan_begin uses
     int n_flight = 0;    // scans begun and not finished (0..2)
     Slot* res = nullptr; // last finished scan (results)
+    const unsigned char* d_qual = nullptr; // group-qualified scan form (archive queue): per-user flag
 
     // shared scratch
     long long* d_blk_off = nullptr;
@@ -217,7 +219,7 @@ size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_
 // a re-allocation (append path; capacity grows geometrically so appends are amortised O(1) per row).
 int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 0)
 {
-    if (n < 0 || n >= (1LL << 31)) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31)", n);
+    if (n < 0 || n >= (1LL << 31) - 1) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31 - 1)", n);
     if (n_users < 1) return fail(c, PIE_E_INVAL, "n_users must be >= 1 (got %d)", n_users);
     if (c->n_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     int rc = sync_all(c);
@@ -336,6 +338,12 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
                        sl.sel_rank, sl.blk_count, sl.sum)
+    if (sl.variant == 0x101) { // group-qualified form, used only by pie_archive_queue
+        hipLaunchKernelGGL((k_scan_compact<4, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
+                           c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
+                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, c->d_qual);
+        return;
+    }
     switch (sl.variant & ~0x40) {
     case 0x00: PIE_K1(4, false, false); break;
     case 0x01: PIE_K1(4, true, false); break;
@@ -387,9 +395,10 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     }
     const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
     sl.variant = c->k1_variant;
-    if (!c->k1_pinned && c->live_frac >= 0) sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+    if (c->d_qual) sl.variant = 0x101;
+    else if (!c->k1_pinned && c->live_frac >= 0) sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
     // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
-    if (!c->k1_pinned && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
+    if (!c->k1_pinned && !c->d_qual && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
     const int plan = (sl.variant & 4) ? 1 : 0;
     sl.k1_blocks = c->plan_blocks[plan];
     sl.rows_per_block = c->plan_rows[plan];
@@ -450,8 +459,10 @@ int scan_finish(pie_ctx* c)
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     sl.last = sl.h_sum->s;
-    c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
-    c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+    if (!c->d_qual) {
+        c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
+        c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+    }
 
     if (sl.last.m > 0) {
         int scat_blocks = sl.k1_blocks;
@@ -961,6 +972,106 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
         PIE_HIP(c, hipMemcpyAsync(queue_out, q.out_idx, k * 4, hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
     }
+    return PIE_OK;
+}
+
+// The reference's archive chain on the device: group stats -> threshold on the host (U values) -> group-qualified
+// scan (buckets per group, rows in table order) -> groups laid out in first-appearance order.
+int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue_out, size_t cap, size_t* q_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (q_out) *q_out = 0;
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n == 0) return PIE_OK;
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const size_t U = (size_t)c->n_users;
+    // 1. per-group earliest start / first row
+    long long* d_min = nullptr;
+    int* d_first = nullptr;
+    unsigned char* d_qual = nullptr;
+    int* d_grp_user = nullptr;
+    long long* d_grp_off = nullptr;
+    std::vector<long long> h_min(U);
+    std::vector<int> h_first(U), h_counts(U);
+    std::vector<unsigned char> h_qual(U);
+    auto cleanup = [&]() {
+        if (d_min) (void)hipFree(d_min);
+        if (d_first) (void)hipFree(d_first);
+        if (d_qual) (void)hipFree(d_qual);
+        if (d_grp_user) (void)hipFree(d_grp_user);
+        if (d_grp_off) (void)hipFree(d_grp_off);
+        c->d_qual = nullptr;
+    };
+#define PIE_TRY(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            cleanup();                                                                                \
+            return fail(c, PIE_E_HIP, "%s: %s", #call, hipGetErrorString(e_));                        \
+        }                                                                                             \
+    } while (0)
+    PIE_TRY(hipMalloc(&d_min, U * 8));
+    PIE_TRY(hipMalloc(&d_first, U * 4));
+    PIE_TRY(hipMalloc(&d_qual, U));
+    hipLaunchKernelGGL(k_group_init, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, s, d_min, d_first, c->n_users);
+    hipLaunchKernelGGL(k_group_stats, dim3(c->n_cus * 16), dim3(256), 0, s, c->d_start, c->d_end, c->d_user, c->n, c->n_users,
+                       d_min, d_first);
+    PIE_TRY(hipGetLastError());
+    PIE_TRY(hipMemcpyAsync(h_min.data(), d_min, U * 8, hipMemcpyDeviceToHost, s));
+    PIE_TRY(hipMemcpyAsync(h_first.data(), d_first, U * 4, hipMemcpyDeviceToHost, s));
+    PIE_TRY(hipStreamSynchronize(s));
+    // 2. threshold (now - earliest >= window, sqlProvider.js:798) and first-appearance order, on the host: U values
+    const int kNone = INT32_MAX; // no row index can be INT32_MAX: n < 2^31 - 1 is enforced at load
+    std::vector<int> order;
+    for (size_t g = 0; g < U; ++g) {
+        h_qual[g] = 0;
+        if (h_first[g] == kNone) continue; // empty group
+        const __int128 diff = (__int128)now - (__int128)h_min[g];
+        if (diff >= (__int128)window_ms) {
+            h_qual[g] = 1;
+            order.push_back((int)g);
+        }
+    }
+    if (order.empty()) { cleanup(); return PIE_OK; }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return h_first[a] < h_first[b]; });
+    // 3. group-qualified scan: one bucket per qualifying group, rows in table order
+    PIE_TRY(hipMemcpyAsync(d_qual, h_qual.data(), U, hipMemcpyHostToDevice, s));
+    c->d_qual = d_qual;
+    rc = run_scan(c, 0, 0);
+    c->d_qual = nullptr;
+    if (rc) { cleanup(); return rc; }
+    Slot& sl = *c->res;
+    PIE_TRY(hipMemcpyAsync(h_counts.data(), sl.counts, U * 4, hipMemcpyDeviceToHost, s));
+    PIE_TRY(hipStreamSynchronize(s));
+    // 4. lay the groups out in first-appearance order
+    std::vector<long long> grp_off(order.size() + 1);
+    grp_off[0] = 0;
+    for (size_t k = 0; k < order.size(); ++k) grp_off[k + 1] = grp_off[k] + h_counts[order[k]];
+    const size_t q = (size_t)grp_off.back();
+    if (q_out) *q_out = q;
+    if (queue_out && q > cap) { cleanup(); return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, q); }
+    if (queue_out && q) {
+        Slot& other = c->slot[(&sl == &c->slot[0]) ? 1 : 0]; // its out_idx is free: the device-side queue
+        PIE_TRY(hipMalloc(&d_grp_user, order.size() * 4));
+        PIE_TRY(hipMalloc(&d_grp_off, grp_off.size() * 8));
+        PIE_TRY(hipMemcpyAsync(d_grp_user, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
+        PIE_TRY(hipMemcpyAsync(d_grp_off, grp_off.data(), grp_off.size() * 8, hipMemcpyHostToDevice, s));
+        const unsigned gb = order.size() < (size_t)c->n_cus * 16 ? (unsigned)order.size() : (unsigned)c->n_cus * 16;
+        hipLaunchKernelGGL(k_group_gather, dim3(gb), dim3(256), 0, s, d_grp_user, d_grp_off, (int)order.size(), sl.offsets,
+                           sl.out_idx, other.out_idx, c->cap_rows);
+        PIE_TRY(hipGetLastError());
+        PIE_TRY(hipMemcpyAsync(queue_out, other.out_idx, q * 4, hipMemcpyDeviceToHost, s));
+        PIE_TRY(hipStreamSynchronize(s));
+        other.have_result = false;
+    }
+#undef PIE_TRY
+    sl.have_result = false; // the scan above is an implementation detail, not a feed result
+    c->res = nullptr;
+    cleanup();
     return PIE_OK;
 }
 

@@ -23,7 +23,17 @@ function buildExpiredSessionPayload(row, cols, i, userIds){
 // store: a device-backed session store (host/sessionStore.js createStore()).  send(payload, meta) -> Promise of
 // {success: boolean, ...}.  Rows with prevNow < expiresAt <= now are dispatched in ascending row order.
 async function dispatchExpiredSessions(store, prevNow, now, send){
-  const rows = store.expiredRows(prevNow, now);
+  return drain(store, store.expiredRows(prevNow, now), send, 'session.expired', 'session-expired-entry');
+}
+
+// The reference's daily-archive trigger (/root/reference/server/storage/sqlProvider.js:758-861) on sessions: every
+// session of every user whose earliest session is at least windowMs (default 12 h = AUTO_ARCHIVE_WINDOW_MS, :9) old,
+// users in first-appearance order, dispatched one at a time.
+async function dispatchArchivedGroups(store, now, send, windowMs){
+  return drain(store, store.archivedRows(now, windowMs), send, 'session.archived', 'session-archive-entry');
+}
+
+async function drain(store, rows, send, event, kind){
   if(rows.length === 0){
     return {success: true, dispatched: 0, failed: 0, total: 0, results: []};
   }
@@ -33,7 +43,7 @@ async function dispatchExpiredSessions(store, prevNow, now, send){
     const payload = buildExpiredSessionPayload(rows[i], cols, i, store.userIds());
     let res;
     try{
-      res = await send(payload, {event: 'session.expired', kind: 'session-expired-entry', sessionRow: rows[i]});
+      res = await send(payload, {event, kind, sessionRow: rows[i]});
     }catch(err){
       res = {success: false, error: err && err.message ? err.message : String(err)};
     }
@@ -48,9 +58,10 @@ async function dispatchExpiredSessions(store, prevNow, now, send){
     results
   };
   if(failures.length){
-    summary.error = 'One or more expired-session payloads failed to dispatch';
+    summary.error = event === 'session.expired' ? 'One or more expired-session payloads failed to dispatch'
+      : 'One or more archived-session payloads failed to dispatch';
   }
   return summary;
 }
 
-module.exports = {dispatchExpiredSessions, buildExpiredSessionPayload};
+module.exports = {dispatchExpiredSessions, dispatchArchivedGroups, buildExpiredSessionPayload};

@@ -204,6 +204,15 @@ function createStore(options){
     return list.slice(0, k);
   }
 
+  // the reference's archive chain on the session table (sqlProvider.js:758-816): rows of every user whose earliest
+  // session is at least windowMs old, users in order of first appearance, rows in table order
+  function archivedRows(now, windowMs){
+    flush();
+    const list = new Int32Array(Math.max(rows.length, 1));
+    const k = native.archiveQueue(ctx, now, windowMs === undefined ? SESSION_TTL_MS : windowMs, list);
+    return list.slice(0, k);
+  }
+
   function fetchRows(idx){
     const m = idx.length;
     const s = new BigInt64Array(m), e = new BigInt64Array(m), u = new Int32Array(m), d = new Int32Array(m);
@@ -220,7 +229,7 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, fetchRows, expiredRows, flush, close,
+    scanFeeds, fetchRows, expiredRows, archivedRows, flush, close,
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,

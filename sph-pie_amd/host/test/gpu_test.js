@@ -213,6 +213,15 @@ function get(port, cookie){
     await dispatchExpiredSessions(store, made[38], made[39], async p => { one.push(p); return {success: true}; });
     eq(one, [{sessionRow: 39, userId: 'user-4', discipline: 'audio', createdAt: new Date(base + 39 * 60000).toISOString(),
       expiredAt: new Date(made[39]).toISOString()}]);
+    // archive chain: users u0..u6 first appear in rows 0..6; at `t` only users whose FIRST session is >= 12 h old qualify
+    const {dispatchArchivedGroups} = require('../dispatchQueue');
+    const order = [];
+    const t = base + 3 * 60000 + store.SESSION_TTL_MS;          // earliest of user-0..user-3 (rows 0..3) is old enough
+    const sum2 = await dispatchArchivedGroups(store, t, async p => { order.push(p.sessionRow); return {success: true}; });
+    const expectRows = [];
+    for(let g = 0; g < 4; g++){ for(let i = g; i < 40; i += 7){ expectRows.push(i); } }
+    eq(order, expectRows);
+    eq([sum2.success, sum2.total], [true, expectRows.length]);
     store.close();
   }
   Date.now = realNow;

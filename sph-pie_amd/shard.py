@@ -212,3 +212,32 @@ class ShardedFeeds:
                 last = self.collect(flying)
             flying = t
         return self.collect(flying)
+
+
+def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device="cpu", group=None):
+    """Multi-GPU form of the expired-session dispatch queue: every rank contributes the ordered
+    queue of ITS shard (local row indices from `pie_expired_queue`), mapped to global row ids; one all-gather of the
+    padded lists; every rank merges them into the single ascending global order in which the host drains the queue
+    (the sequential-await order of /root/reference/server/storage/sqlProvider.js:834-861).
+    local_queue: int array of local rows (ascending); local_to_global_rows: the shard's row map (ascending, so each
+    rank's global list is ascending too).  -> np.int64 array, identical on every rank."""
+    glob = np.asarray(local_to_global_rows, np.int64)[np.asarray(local_queue, np.int64)]
+    dev = torch.device(device)
+    n = torch.tensor([glob.size], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    cap = int(n.item())
+    msg = torch.full((cap + 1,), -1, dtype=torch.int64, device=dev)
+    msg[0] = glob.size
+    if glob.size:
+        msg[1:1 + glob.size] = torch.from_numpy(glob).to(dev)
+    if world > 1:
+        out = torch.empty(world * (cap + 1), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, msg, group=group)
+    else:
+        out = msg
+    out = out.view(world, cap + 1).cpu().numpy()
+    lists = [out[r, 1:1 + int(out[r, 0])] for r in range(world)]
+    merged = np.concatenate(lists) if lists else np.zeros(0, np.int64)
+    merged.sort(kind="stable")   # k-way merge of ascending lists; ids are unique
+    return merged

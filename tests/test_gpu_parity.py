@@ -314,6 +314,31 @@ def test_prune_before_is_the_window_complement(gpu_ctx, oracle):
     assert gpu_ctx.prune_before(cutoff).size == 0
 
 
+def test_archive_group_min_queue(gpu_ctx, oracle):
+    """The reference's archive chain (sqlProvider.js:758-816) on the session table: segmented min by group, threshold,
+    whole-group selection, queue in (group first appearance, row) order — vs the C oracle on small tables and its numpy
+    twin on a larger one."""
+    W = 43200000
+    for n, U, flags in [(1, 1, 0), (300, 7, 1), (5000, 37, 0), (20000, 2000, 3)]:
+        s, e, u, d = oracle.gen(SEED, n, 0, n, U, 3, flags)
+        e[::11] = INT64_MIN
+        gpu_ctx.load_columns(s, e, u, d, U)
+        for now in [oracle.T0_MS - 60 * DAY, oracle.T0_MS, INT64_MIN, 2 ** 62, oracle.T0_MS - 119 * DAY, int(s.min()) + W, int(s.min()) + W - 1]:
+            want = oracle.archive_queue(s, e, u, U, now, W)
+            assert np.array_equal(gpu_ctx.archive_queue(now, W), want), (n, now)
+    n, U = 1500000, 30011
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    e[::7] = INT64_MIN
+    gpu_ctx.load_columns(s, e, u, d, U)
+    for now in [oracle.T0_MS - 118 * DAY, oracle.T0_MS - 119 * DAY - 20 * 3600 * 1000, oracle.T0_MS]:
+        got = gpu_ctx.archive_queue(now, W)
+        assert np.array_equal(got, oracle.archive_queue_numpy(s, e, u, U, now, W))
+    assert got.size == np.count_nonzero(e != INT64_MIN)      # at T0 every present row belongs to an old-enough group
+    # a feed scan afterwards is unaffected
+    gpu_ctx.set_disciplines(ALL, 32)
+    assert_same(gpu_ctx.scan(*spec_query(oracle)[:2]), oracle.scan(s, e, u, d, U, *spec_query(oracle)[:2], 0xFFFFFFFF))
+
+
 def test_expired_queue_parity(gpu_ctx, oracle):
     for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
         s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)

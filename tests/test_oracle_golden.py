@@ -162,3 +162,27 @@ def test_oracle_under_sanitizers(tmp_path):
                            os.path.join(odir, "pie_oracle.c")])
     res = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "oracle selftest ok" in res.stdout, res.stdout
+
+
+def test_archive_chain_hand_vector_and_twin(oracle):
+    """sqlProvider.js:758-816 restated: hand-worked vector (groups in first-appearance order, rows in table order,
+    threshold inclusive) + the C oracle against its independent numpy twin."""
+    u = [2, 0, 2, 1, 0]
+    s = [100, 50, 90, 300, 60]
+    e = [10 ** 12] * 5
+    # W = 10: earliest g2 = 90, g0 = 50, g1 = 300; at now = 105 g2 and g0 qualify (15, 55 >= 10), g1 does not
+    assert oracle.archive_queue(s, e, u, 3, 105, 10).tolist() == [0, 2, 1, 4]
+    assert oracle.archive_queue(s, e, u, 3, 99, 10).tolist() == [1, 4]        # 99 - 90 = 9 < 10: g2 waits
+    assert oracle.archive_queue(s, e, u, 3, 100, 10).tolist() == [0, 2, 1, 4]  # == window: inclusive (:798 `>=`)
+    assert oracle.archive_queue(s, e, u, 3, 310, 10).tolist() == [0, 2, 1, 4, 3]
+    e2 = list(e)
+    e2[2] = INT64_MIN                                                          # the row holding g2's minimum is gone
+    assert oracle.archive_queue(s, e2, u, 3, 105, 10).tolist() == [1, 4]       # g2's earliest is now 100: 5 < 10
+    rng = np.random.default_rng(5)
+    for n, U in [(0, 3), (1, 1), (2000, 11), (20000, 700)]:
+        s, e, u, d = oracle.gen(0x5EED5EED, max(n, 1), 0, n, U, 3, 1)
+        if n:
+            e[rng.random(n) < 0.1] = INT64_MIN
+        for now in [oracle.T0_MS, oracle.T0_MS - 119 * 86400000, INT64_MIN, 2 ** 62]:
+            assert np.array_equal(oracle.archive_queue(s, e, u, U, now, 43200000),
+                                  oracle.archive_queue_numpy(s, e, u, U, now, 43200000))

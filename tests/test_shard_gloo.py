@@ -80,6 +80,12 @@ def _worker(rank, world, port, tmp, n, U):
             for gu in range(U):
                 assert np.array_equal(got_feeds.get(gu, np.zeros(0, np.int64)), wi[wo[gu]:wo[gu + 1]]), (rank, gu)
             assert int(out["lengths"].sum()) == wi.size
+        # multi-rank expired-session dispatch queue: per-shard ordered queues -> one global ascending order
+        from sph_pie_amd.shard import gather_expired_queues
+        for prev, now in [(T0 - 50 * DAY, T0 - 20 * DAY), (INT64_MIN, 2 ** 62), (5, 4)]:
+            local = oracle_py.expired_queue(sh["end"], prev, now)
+            merged = gather_expired_queues(local, sh["rows"], rank, world)
+            assert np.array_equal(merged, oracle_py.expired_queue(cols[1], prev, now).astype(np.int64))
         open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
