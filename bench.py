@@ -199,6 +199,8 @@ def main():
         achieved = alg / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         variant = st["k1_variant"]
         kname = "k_scan_live_first" if variant & 4 else "k_scan_compact"
+        if variant & 0x200:
+            kname = "k_scan_live_first_part"
         if args.mode == "expired":
             kname = "k_expired_stage"
         traffic = None

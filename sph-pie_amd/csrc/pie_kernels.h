@@ -463,6 +463,311 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ partitioned fast path
+//
+// For a sparse query (few selected rows per user range) the whole tail collapses into ONE kernel with no host round
+// trip: K1P appends every selected record to the partition of its user range (partition = user >> shift, one returning
+// atomic on the partition's cursor — the same atomic count as the histogram of the general path), and the tail kernel
+// gives each partition to ONE WAVE that sorts its records by (user, start, idx) in registers, derives the per-user
+// counts / offsets from the sorted run and the partition totals, and writes counts, offsets and idx directly.
+// The host chooses this path from the previous scan's M (records per partition must fit kPartCap with a wide margin);
+// a partition that overflows sets a flag and the host reruns the scan on the general path.
+__device__ __forceinline__ long long wave_incl_scan(long long v, int lane); // defined with the K2 helpers below
+
+constexpr int kPartCap = 256;   // records per partition the tail wave can sort (4 per lane: keeps the tail under 128 VGPRs)
+constexpr int kPartMax = 4096;  // partitions (cursor array size)
+constexpr int kPartRange = 256;  // users per partition the tail wave can histogram in its LDS slice
+
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(kK1Threads) void k_scan_live_first_part(
+    const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
+    const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
+    unsigned long long mask, int n_users, int shift, int* __restrict__ part_cursor, SelRec* __restrict__ part_rec,
+    Summary* __restrict__ summary)
+{
+    __shared__ int live_ring[kK1Waves][kLiveRing];
+    __shared__ int blk_live;
+    constexpr int kTile = kUnitRows * UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) blk_live = 0;
+    __syncthreads();
+    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    long long c1 = c0 + rows_per_block;
+    if (c1 > n) c1 = n;
+    int* lring = live_ring[wave];
+    int lhead = 0, lfill = 0, nlive = 0; // wave-uniform
+
+    auto drain = [&](int cnt) {
+        if (lane < cnt) {
+            const int row = lring[(lhead + lane) & (kLiveRing - 1)];
+            const long long sv = start[row];
+            const int dv = disc[row];
+            if ((sv >= cutoff) & ((unsigned)dv < 64u) & (((mask >> (dv & 63)) & 1ull) != 0)) {
+                const int uv = user[row];
+                if ((unsigned)uv < (unsigned)n_users) {
+                    const int pt = uv >> shift;
+                    const int pos = atomicAdd(&part_cursor[pt], 1);
+                    if (pos < kPartCap) {
+                        SelRec r;
+                        r.start = sv;
+                        r.idx = row;
+                        r.user = uv;
+                        part_rec[(long long)pt * kPartCap + pos] = r;
+                    }
+                } else {
+                    atomicAdd(&summary->bad_rows, 1u);
+                }
+            }
+        }
+        lhead = (lhead + cnt) & (kLiveRing - 1);
+        lfill -= cnt;
+    };
+    auto push_live = [&](bool live, int row) {
+        const unsigned long long b = __ballot(live);
+        if (b == 0) return;
+        if (live) lring[(lhead + lfill + prefix_in_ballot(b)) & (kLiveRing - 1)] = row;
+        const int c = __popcll(b);
+        lfill += c;
+        nlive += c;
+        __builtin_amdgcn_wave_barrier();
+        if (lfill >= kWave) drain(kWave);
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
+        if (t + kTile <= c1) {
+            ll2_t e[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                e[j] = stream_load<NT>(reinterpret_cast<const ll2_t*>(end + t + j * kUnitRows + 2 * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int r = (int)(t + j * kUnitRows + 2 * lane);
+                push_live(e[j].x > now, r);
+                push_live(e[j].y > now, r + 1);
+            }
+        } else {
+            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
+            for (long long r0 = t; r0 < t1; r0 += kWave) {
+                const long long r = r0 + lane;
+                push_live(r < t1 && end[r] > now, (int)r);
+            }
+        }
+    }
+    if (lfill > 0) drain(lfill);
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+}
+
+// bucket of n <= NS records at LDS slots [o, o+n) -> out[0..n) in (start, idx) order: bitonic network in registers,
+// every index a compile-time constant (the LDS twin of sort_bucket_regs)
+template <int NS>
+__device__ __forceinline__ void sort_lds_bucket(const long long* __restrict__ ls, const int* __restrict__ li, int o, int n,
+                                                int* __restrict__ out)
+{
+    long long ks[NS];
+    int ki[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const bool in = k < n;
+        ks[k] = in ? ls[o + k] : INT64_MAX;
+        ki[k] = in ? li[o + k] : INT32_MAX;
+    }
+#pragma unroll
+    for (int k = 2; k <= NS; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool lt = key_less(ks[l], ki[l], ks[i], ki[i]);
+                    const bool sw = up ? lt : !lt;
+                    const long long s0 = sw ? ks[l] : ks[i], s1 = sw ? ks[i] : ks[l];
+                    const int i0 = sw ? ki[l] : ki[i], i1 = sw ? ki[i] : ki[l];
+                    ks[i] = s0; ks[l] = s1; ki[i] = i0; ki[l] = i1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        if (k < n) out[k] = ki[k];
+}
+
+// The tail of the partitioned path: one wave per partition, all in the wave's LDS slice:
+//   per-user histogram of the partition's records (LDS atomics; the returned value is the record's slot inside its
+//   user's bucket) -> exclusive prefix over the partition's users (counts / offsets go to global memory) -> records
+//   placed at their bucket slot in LDS -> every bucket (<= 16 rows) ordered by ONE lane with the register network.
+// A sort of the whole partition by (user, start, idx) through the cross-lane network was measured first: 336
+// ds_bpermute per wave made the kernel LDS-crossbar bound (25-34 us); bucketing first needs ~200 plain LDS accesses.
+// No same-address global atomics anywhere (per-block maxima go to an array; k_publish_summary reduces them).
+constexpr int kTailThreads = 512;
+constexpr int kTailWaves = kTailThreads / 64;
+__global__ __launch_bounds__(kTailThreads) void k_tail_partitions(const int* __restrict__ part_cursor, const SelRec* __restrict__ part_rec,
+                                                                  int n_parts, int shift, int n_users, int* __restrict__ counts,
+                                                                  long long* __restrict__ offsets, int* __restrict__ out_idx,
+                                                                  Summary* __restrict__ summary, unsigned int* __restrict__ blk_max,
+                                                                  int4* __restrict__ zero_span, long long zero_vec16)
+{
+    __shared__ int hist_all[kTailWaves][kPartRange];   // per-user record count, then per-user base inside the partition
+    __shared__ long long ls_all[kTailWaves][kPartCap]; // records in bucket order: start ...
+    __shared__ int li_all[kTailWaves][kPartCap];       // ... and row index
+    __shared__ unsigned int wmax[kTailWaves];
+    unsigned int wave_max = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (zero_span) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        for (long long i = (long long)blockIdx.x * kTailThreads + threadIdx.x; i < zero_vec16; i += (long long)gridDim.x * kTailThreads)
+            zero_span[i] = z;
+    }
+    const int range = 1 << shift;
+    int* hist = hist_all[wave];
+    long long* ls = ls_all[wave];
+    int* li = li_all[wave];
+    const int total_waves = gridDim.x * kTailWaves;
+    for (int p = blockIdx.x * kTailWaves + wave; p < n_parts; p += total_waves) {
+        for (int k = lane; k < range; k += 64) hist[k] = 0;
+        // the partition's records are fetched at once, before its count is known (slots past the count are ignored):
+        // cursor, cursor prefix and records all travel in the same memory round trip
+        const SelRec* rec = part_rec + (long long)p * kPartCap;
+        SelRec r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r4[e] = rec[e * 64 + lane];
+        const int raw = part_cursor[p];
+        const int cnt = raw < kPartCap ? raw : kPartCap;
+        bool overflow = raw > kPartCap;
+        // base = records in the partitions before this one: the whole cursor array (<= 4096 ints, zero padded) is
+        // fetched with 16 independent 16-B loads per lane, issued together
+        long long part = 0;
+#pragma unroll 4
+        for (int k = 0; k < kPartMax / 256; ++k) {
+            const int q0 = (k * 64 + lane) * 4;
+            if (k * 256 >= p) break; // wave-uniform: nothing at or past partition p counts
+            const int4 v = reinterpret_cast<const int4*>(part_cursor)[k * 64 + lane];
+            part += (q0 + 0 < p) ? min(v.x, kPartCap) : 0;
+            part += (q0 + 1 < p) ? min(v.y, kPartCap) : 0;
+            part += (q0 + 2 < p) ? min(v.z, kPartCap) : 0;
+            part += (q0 + 3 < p) ? min(v.w, kPartCap) : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+        const long long base = part;
+        const int u0 = p << shift;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 1. slot of every record inside its user's bucket (arrival order; the bucket sort fixes the order)
+        int slot[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            slot[e] = 0;
+            if (e * 64 + lane < cnt) slot[e] = atomicAdd(&hist[r4[e].user - u0], 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 2. exclusive prefix over the partition's users; counts / offsets out; hist[] becomes the bucket base
+        const int per = range >= 64 ? range / 64 : 1;
+        const int first = lane * per;
+        int mine = 0;
+        for (int k = 0; k < per; ++k)
+            if (first + k < range) mine += hist[first + k];
+        int run = (int)(wave_incl_scan((long long)mine, lane) - mine);
+        unsigned int mx = 0;
+        for (int k = 0; k < per; ++k) {
+            if (first + k < range) {
+                const int c = hist[first + k];
+                const int u = u0 + first + k;
+                if (u < n_users) {
+                    counts[u] = c;
+                    offsets[u] = base + run;
+                }
+                hist[first + k] = run | (c << 16); // bucket base (< 256) and size (<= 256) packed for step 4
+                run += c;
+                mx = max(mx, (unsigned)c);
+            }
+        }
+        wave_max = max(wave_max, mx);
+        overflow |= mx > (unsigned)kTinyMax; // a bucket too large for the register network: general path
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 3. records to their bucket slot
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e * 64 + lane < cnt) {
+                const int pos = (hist[r4[e].user - u0] & 0xFFFF) + slot[e];
+                ls[pos] = r4[e].start;
+                li[pos] = r4[e].idx;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 4. one lane per user: order the bucket, write the rows
+        for (int k = 0; k < per; ++k) {
+            if (first + k < range) {
+                const int h = hist[first + k];
+                const int o = h & 0xFFFF, c = h >> 16;
+                if (c == 1) out_idx[base + o] = li[o];
+                else if (c > 1 && c <= 8) sort_lds_bucket<8>(ls, li, o, c, out_idx + base + o);
+                else if (c > 8 && c <= kTinyMax) { // rare (9..16 rows): insertion sort in place, few registers
+                    for (int a = 1; a < c; ++a) {
+                        const long long sv = ls[o + a];
+                        const int iv = li[o + a];
+                        int b = a;
+                        while (b > 0 && key_less(sv, iv, ls[o + b - 1], li[o + b - 1])) {
+                            ls[o + b] = ls[o + b - 1];
+                            li[o + b] = li[o + b - 1];
+                            --b;
+                        }
+                        ls[o + b] = sv;
+                        li[o + b] = iv;
+                    }
+                    for (int a = 0; a < c; ++a) out_idx[base + o + a] = li[o + a];
+                }
+            }
+        }
+        if (__ballot(overflow) && lane == 0) atomicOr(&summary->pad, 1u); // rare: the host reruns on the general path
+        if (p == n_parts - 1 && lane == 0) {
+            offsets[n_users] = base + cnt;
+            __hip_atomic_store(&summary->m, (unsigned long long)(base + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_max = max(wave_max, (unsigned)__shfl_xor((int)wave_max, o, kWave));
+    if (lane == 0) wmax[wave] = wave_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int m = 0;
+        for (int w = 0; w < kTailWaves; ++w) m = max(m, wmax[w]);
+        blk_max[blockIdx.x] = m;
+    }
+}
+
+// One block behind the tail: largest bucket = max over the tail blocks' maxima; summary -> mapped host memory.
+__global__ __launch_bounds__(256) void k_publish_summary(Summary* __restrict__ summary, const unsigned int* __restrict__ blk_max,
+                                                         int n_blk, HostSummary* __restrict__ host, unsigned long long seq)
+{
+    __shared__ unsigned int wmax[4];
+    unsigned int m = 0;
+    for (int i = threadIdx.x; i < n_blk; i += 256) m = max(m, blk_max[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, kWave));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Summary out = *summary;
+        out.max_count = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        out.n_seg = out.n_big = out.n_small = 0;
+        out.q = 0;
+        summary->max_count = out.max_count;
+        host->s = out;
+        __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K2 offsets
 
 __device__ __forceinline__ long long wave_incl_scan(long long v, int lane)
@@ -807,6 +1112,23 @@ __global__ __launch_bounds__(1024) void k_sort_segments(const Segment* __restric
 // the lane, the others exchange with lane l ^ (j/EPL) through the cross-lane network (__shfl_xor).  No LDS storage,
 // no barriers: the first version of this kernel kept the bucket in LDS and was LDS-bandwidth bound (0.92 ms for
 // 10^5 buckets of ~254 rows); every loop below has compile-time bounds so all indices are static registers.
+template <int EPL, int J>
+__device__ __forceinline__ void sort2_inlane_step(long long (&ks)[EPL], int (&ki)[EPL], int lane, int k)
+{
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int l = e ^ J;
+        if (l > e) {
+            const bool up = ((lane * EPL + e) & k) == 0;
+            const bool lt = key_less(ks[l], ki[l], ks[e], ki[e]); // slot l sorts before slot e
+            const bool sw = up ? lt : !lt;
+            const long long s0 = sw ? ks[l] : ks[e], s1 = sw ? ks[e] : ks[l];
+            const int i0 = sw ? ki[l] : ki[e], i1 = sw ? ki[e] : ki[l];
+            ks[e] = s0; ks[l] = s1; ki[e] = i0; ki[l] = i1;
+        }
+    }
+}
+
 template <int EPL>
 __device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec* __restrict__ bkt, int* __restrict__ out_idx,
                                                   int lane)
@@ -824,40 +1146,28 @@ __device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec
         ks[e] = r.start;
         ki[e] = r.idx;
     }
-#pragma unroll
+    // real loops over the stages (see wave_sort3): the body stays resident in the instruction cache
+#pragma nounroll
     for (int k = 2; k <= P; k <<= 1) {
+#pragma nounroll
+        for (int j = k >> 1; j >= EPL; j >>= 1) { // partner lives in lane ^ (j / EPL), same slot
+            const int lm = j / EPL;
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= EPL) { // partner lives in another lane, same slot
-                const int lm = j / EPL;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int i = lane * EPL + e;
-                    const long long os = __shfl_xor(ks[e], lm, kWave);
-                    const int oi = __shfl_xor(ki[e], lm, kWave);
-                    const bool up = (i & k) == 0;
-                    const bool lower = (i & j) == 0;
-                    const bool keep_min = lower == up;
-                    const bool other_less = key_less(os, oi, ks[e], ki[e]);
-                    const bool take = keep_min ? other_less : !other_less;
-                    ks[e] = take ? os : ks[e];
-                    ki[e] = take ? oi : ki[e];
-                }
-            } else { // partner is another slot of this lane
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int l = e ^ j;
-                    if (l > e) {
-                        const bool up = ((lane * EPL + e) & k) == 0;
-                        const bool lt = key_less(ks[l], ki[l], ks[e], ki[e]); // slot l sorts before slot e
-                        const bool sw = up ? lt : !lt;
-                        const long long s0 = sw ? ks[l] : ks[e], s1 = sw ? ks[e] : ks[l];
-                        const int i0 = sw ? ki[l] : ki[e], i1 = sw ? ki[e] : ki[l];
-                        ks[e] = s0; ks[l] = s1; ki[e] = i0; ki[l] = i1;
-                    }
-                }
+            for (int e = 0; e < EPL; ++e) {
+                const int i = lane * EPL + e;
+                const long long os = __shfl_xor(ks[e], lm, kWave);
+                const int oi = __shfl_xor(ki[e], lm, kWave);
+                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                const bool other_less = key_less(os, oi, ks[e], ki[e]);
+                const bool take = keep_min ? other_less : !other_less;
+                ks[e] = take ? os : ks[e];
+                ki[e] = take ? oi : ki[e];
             }
         }
+        const int jmax = (k >> 1) < EPL ? (k >> 1) : (EPL >> 1);
+        if constexpr (EPL >= 8) { if (jmax >= 4) sort2_inlane_step<EPL, 4>(ks, ki, lane, k); }
+        if constexpr (EPL >= 4) { if (jmax >= 2) sort2_inlane_step<EPL, 2>(ks, ki, lane, k); }
+        if constexpr (EPL >= 2) { if (jmax >= 1) sort2_inlane_step<EPL, 1>(ks, ki, lane, k); }
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {

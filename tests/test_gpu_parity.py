@@ -140,6 +140,52 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         assert ctx.stats()["k1_variant"] == 0x03
 
 
+def test_partition_overflow_reruns_on_the_general_path(pie, oracle, monkeypatch):
+    """The opt-in partitioned path (PIE_FAST_PATH=1: table pass + ONE tail kernel, no host round trip; measured at
+    parity with the default path, kept as an experiment) is chosen from the PREVIOUS scan's M.  When the next query selects far more rows than
+    a partition can hold, the tail flags the overflow and the same scan reruns on the general path — same bytes — and
+    the fast path stays off for that table."""
+    monkeypatch.setenv("PIE_FAST_PATH", "1")
+    with pie.PieScan(0) as ctx:
+        n, U, D = 3000000, 30000, 32
+        s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
+        now, cutoff, mask = spec_query(oracle)
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(mask, D)
+        sparse = oracle.scan(s, e, u, d, U, now, cutoff, mask & 0xFFFFFFFF)
+        dense = oracle.scan(s, e, u, d, U, INT64_MIN, INT64_MIN, mask & 0xFFFFFFFF)   # ~50 rows per user
+        assert sparse[0].max() <= 16 < dense[0].max()
+        assert_same(ctx.scan(now, cutoff), sparse)
+        assert_same(ctx.scan(now, cutoff), sparse)
+        assert ctx.stats()["k1_variant"] == 0x285
+        assert_same(ctx.scan(INT64_MIN, INT64_MIN), dense)                      # overflow -> rerun, transparently
+        assert ctx.stats()["k1_variant"] == 0x85
+        assert_same(ctx.scan(now, cutoff), sparse)
+        assert ctx.stats()["k1_variant"] != 0x285                               # fast path is off for this table now
+        ctx.load_columns(s, e, u, d, U)                                         # ... until the table is reloaded
+        assert_same(ctx.scan(now, cutoff), sparse)
+        assert_same(ctx.scan(now, cutoff), sparse)
+        assert ctx.stats()["k1_variant"] == 0x285
+
+
+def test_partitioned_path_parity(pie, oracle, monkeypatch):
+    """PIE_FAST_PATH=1 on tables of many shapes: whenever the path engages (variant 0x285) its bytes equal the oracle's,
+    including buckets of 9..16 rows, empty partitions, user counts that are not a multiple of the partition range."""
+    monkeypatch.setenv("PIE_FAST_PATH", "1")
+    rng = np.random.default_rng(99)
+    engaged = 0
+    with pie.PieScan(0) as ctx:
+        for n, U in [(200000, 1), (200000, 33), (500000, 5000), (1 << 20, 100000), (1 << 20, 4097 * 3), (3000017, 1000003)]:
+            s, e, u, d = oracle.gen(int(rng.integers(1, 2 ** 60)), n, 0, n, U, 32, 1)
+            ctx.load_columns(s, e, u, d, U)
+            ctx.set_disciplines(ALL, 32)
+            for now in [oracle.T0_MS - 3600 * 1000, oracle.T0_MS - 2 * DAY, oracle.T0_MS - 3600 * 1000, 2 ** 62, oracle.T0_MS - 5 * DAY]:
+                want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+                assert_same(ctx.scan(now, INT64_MIN), want)
+                engaged += ctx.stats()["k1_variant"] == 0x285
+    assert engaged >= 8
+
+
 def test_two_scans_in_flight(pie, oracle):
     """begin(i+1) before finish(i): different queries back to back, results of each finished scan are exact and
     stay readable while the next scan is already queued; a third begin is refused."""
