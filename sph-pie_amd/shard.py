@@ -101,7 +101,9 @@ class ShardedFeeds:
 
     @staticmethod
     def _grow(need):
-        return max(1024, int(need * 1.25) + 64)
+        # 6 % headroom: the message is what crosses xGMI every step, so slack is kept small; a query that outgrows
+        # it is detected by every rank from the gathered lengths and costs one collective re-negotiation
+        return max(1024, int(need * 1.06) + 64)
 
     def _alloc(self):
         L = self.u_pad + 2 + self.cap
