@@ -107,6 +107,14 @@ int pie_delete_user(pie_ctx *ctx, int32_t user, int32_t *rows_out, size_t cap, s
  * complement of the scan's window predicate); rows_out / n_pruned as in pie_delete_user. */
 int pie_prune_before(pie_ctx *ctx, int64_t cutoff, int32_t *rows_out, size_t cap, size_t *n_pruned);
 
+/* Retention purge with calendar-month arithmetic (server/storage/sqlProvider.js:863-890 _purgeExpiredArchives, :991-1009
+ * _isArchiveExpired / _addMonths; ARCHIVE_RETENTION_MONTHS = 2, :10): tombstone every row with
+ * now >= addMonths(start, months), where addMonths is JS `setMonth(getMonth() + months)` on a local-time Date (day
+ * overflow rolls into the next month) and local time = UTC + tz_offset_ms (a fixed offset of whole minutes; DST is not
+ * modelled).  rows_out / n_purged as in pie_delete_user. */
+int pie_retention_purge(pie_ctx *ctx, int64_t now, int32_t months, int64_t tz_offset_ms, int32_t *rows_out, size_t cap,
+                        size_t *n_purged);
+
 /* ---- discipline predicate table: replaces findDiscipline() lookups (server/disciplineConfig.js:88-97) -
  * bit d of mask = rows of discipline d are wanted; bits >= n_disc are ignored. n_disc <= 64. */
 int pie_set_disciplines(pie_ctx *ctx, uint64_t mask, int32_t n_disc);

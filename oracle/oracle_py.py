@@ -42,6 +42,10 @@ def lib():
         l.pie_oracle_expired_queue.argtypes = [P, C.c_size_t, C.c_int64, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_archive_queue.restype = C.c_int
         l.pie_oracle_archive_queue.argtypes = [P, P, P, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.pie_oracle_add_months.restype = C.c_int64
+        l.pie_oracle_add_months.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int)]
+        l.pie_oracle_retention_queue.restype = C.c_int
+        l.pie_oracle_retention_queue.argtypes = [P, P, C.c_size_t, C.c_int64, C.c_int32, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_splitmix64.restype = C.c_uint64
         l.pie_oracle_splitmix64.argtypes = [C.c_uint64]
         l.pie_oracle_shard_of.restype = C.c_int32
@@ -131,6 +135,24 @@ def archive_queue_numpy(start, end, user, n_users, now, window_ms):
     keep = rows[qual[g]]
     order = np.lexsort((keep, first[user[keep]]))
     return keep[order].astype(np.int32)
+
+
+def add_months(ts, months, tz_offset_ms=0):
+    """-> int, or None when the JS result would be NaN"""
+    nan = C.c_int(0)
+    v = lib().pie_oracle_add_months(int(ts), int(months), int(tz_offset_ms), C.byref(nan))
+    return None if nan.value else v
+
+
+def retention_queue(start, end, now, months=2, tz_offset_ms=0):
+    start, end = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(end, np.int64)
+    n = start.shape[0]
+    q = np.empty(max(n, 1), np.int32)
+    k = C.c_size_t(0)
+    rc = lib().pie_oracle_retention_queue(_p(start), _p(end), n, int(now), int(months), int(tz_offset_ms), _p(q), n, C.byref(k))
+    if rc != 0:
+        raise RuntimeError("pie_oracle_retention_queue rc=%d" % rc)
+    return q[: k.value].copy()
 
 
 def selected(start, end, disc, now, cutoff, mask):

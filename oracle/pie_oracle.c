@@ -2,10 +2,12 @@
  * TEST INFRASTRUCTURE — CPU oracle (see pie_oracle.h for scope and the parity-pin statement).
  * Citations are relative to /root/reference.
  */
+#define _GNU_SOURCE
 #include "pie_oracle.h"
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---------------------------------------------------------------- synthetic corpus */
 
@@ -223,6 +225,45 @@ int pie_oracle_archive_queue(const int64_t *start, const int64_t *end, const int
         }
     }
     free(earliest); free(order); free(seen);
+    if (q_out) *q_out = q;
+    return q > cap ? -1 : 0;
+}
+
+/* ---------------------------------------------------------------- "next" row: retention purge (calendar months) */
+
+#define JS_DATE_MAX 8640000000000000LL
+
+int64_t pie_oracle_add_months(int64_t ts, int32_t months, int64_t tz_offset_ms, int *is_nan)
+{
+    if (is_nan) *is_nan = 0;
+    if (ts > JS_DATE_MAX || ts < -JS_DATE_MAX) return ts; /* invalid Date: returned as is, sqlProvider.js:1003-1005 */
+    const __int128 local = (__int128)ts + tz_offset_ms;
+    /* floor division: milliseconds of the (local) second, seconds since the epoch */
+    int64_t secs = (int64_t)(local / 1000), ms = (int64_t)(local % 1000);
+    if (ms < 0) { ms += 1000; secs -= 1; }
+    time_t t = (time_t)secs;
+    struct tm tm;
+    if (!gmtime_r(&t, &tm)) { if (is_nan) *is_nan = 1; return 0; }
+    tm.tm_mon += months; /* date.setMonth(date.getMonth() + months), :1007: timegm normalises month and day overflow */
+    const time_t t2 = timegm(&tm);
+    const __int128 out = (__int128)t2 * 1000 + ms - tz_offset_ms;
+    if (out > JS_DATE_MAX || out < -JS_DATE_MAX) { if (is_nan) *is_nan = 1; return 0; } /* TimeClip -> NaN */
+    return (int64_t)out;
+}
+
+int pie_oracle_retention_queue(const int64_t *start, const int64_t *end, size_t n, int64_t now, int32_t months,
+                               int64_t tz_offset_ms, int32_t *queue, size_t cap, size_t *q_out)
+{
+    size_t q = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (end[i] == INT64_MIN) continue;
+        int nan = 0;
+        const int64_t expiry = pie_oracle_add_months(start[i], months, tz_offset_ms, &nan);
+        if (!nan && now >= expiry) { /* _isArchiveExpired, :991-997 */
+            if (q < cap) queue[q] = (int32_t)i;
+            ++q;
+        }
+    }
     if (q_out) *q_out = q;
     return q > cap ? -1 : 0;
 }

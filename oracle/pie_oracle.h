@@ -65,6 +65,17 @@ int pie_oracle_expired_queue(const int64_t *end, size_t n, int64_t prev_now, int
 int pie_oracle_archive_queue(const int64_t *start, const int64_t *end, const int32_t *user, size_t n, int32_t n_users,
                              int64_t now, int64_t window_ms, int32_t *queue, size_t cap, size_t *q_out);
 
+/* "next" row: retention purge with calendar-month arithmetic, server/storage/sqlProvider.js:991-1009.
+ * expiry = `date.setMonth(date.getMonth() + months)` on a local-time Date; here local = UTC + tz_offset_ms (a fixed
+ * offset; DST is not modelled).  JS Date range rules apply: |ts| > 8.64e15 is an invalid Date and is returned unchanged
+ * (:1003-1005); a result outside the range is NaN (*is_nan = 1) and `now >= NaN` is false (:996).
+ * This restatement goes through libc (gmtime_r / timegm) — a different route from the product's integer civil-date
+ * arithmetic — and is pinned by tests/golden/addmonths_utc.json (vectors from the JS engine's own Date). */
+int64_t pie_oracle_add_months(int64_t ts, int32_t months, int64_t tz_offset_ms, int *is_nan);
+/* rows (not tombstoned) with now >= addMonths(start, months), ascending row order (:863-890 _purgeExpiredArchives) */
+int pie_oracle_retention_queue(const int64_t *start, const int64_t *end, size_t n, int64_t now, int32_t months,
+                               int64_t tz_offset_ms, int32_t *queue, size_t cap, size_t *q_out);
+
 /* user-hash sharding rule shared with the product: rank = splitmix64(user) mod G. */
 uint64_t pie_oracle_splitmix64(uint64_t x);
 int32_t pie_oracle_shard_of(int32_t user, int32_t n_shards);

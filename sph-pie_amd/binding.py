@@ -49,6 +49,7 @@ _SIGS = [
     ("pie_set_end", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("pie_delete_user", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_prune_before", C.c_int, [_P, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_retention_purge", C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_append_rows", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_set_disciplines", C.c_int, [_P, C.c_uint64, C.c_int32]),
     ("pie_scan", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -187,6 +188,13 @@ class PieScan:
         k = C.c_size_t(0)
         rows = np.empty(max(self.n, 1), np.int32)
         self._check(self._lib.pie_prune_before(self._ctx, int(cutoff), _ptr(rows), self.n, C.byref(k)))
+        return rows[: k.value].copy()
+
+    def retention_purge(self, now, months=2, tz_offset_ms=0):
+        """Tombstone rows with now >= addMonths(start, months) (JS calendar-month arithmetic); -> their ascending indices."""
+        k = C.c_size_t(0)
+        rows = np.empty(max(self.n, 1), np.int32)
+        self._check(self._lib.pie_retention_purge(self._ctx, int(now), int(months), int(tz_offset_ms), _ptr(rows), self.n, C.byref(k)))
         return rows[: k.value].copy()
 
     def set_disciplines(self, mask, n_disc):

@@ -1290,8 +1290,52 @@ __global__ __launch_bounds__(256) void k_validate_users(const int* __restrict__ 
 //           /root/reference/server/sessionStore.js:69 at `now`, not yet dead at `prev_now`)
 //   MODE 1  deleteSessionsForUser (/root/reference/server/sessionStore.js:55-64): user == target, strict
 //           match; the write step tombstones the row (end = INT64_MIN: never live again)
+//   MODE 3  retention purge with calendar months (see add_months_ms); tombstones like MODE 1; `aux` = start column
 //   MODE 2  _pruneCalendarEvents (/root/reference/server/storage/sqlProvider.js:956-968): start < cutoff, the
 //           complement of the window predicate; tombstones like MODE 1.  `aux` is the start column here.
+// Calendar-month arithmetic of /root/reference/server/storage/sqlProvider.js:999-1009 (_addMonths:
+// `date.setMonth(date.getMonth() + months)` on a local-time Date), in integers: local = UTC + tz (fixed offset),
+// civil date from the day number, month index shifted, day number of (year', month', 1) + (day - 1) — the
+// normalisation JS's MakeDay performs, so "Dec 31 + 2 months" lands on Mar 3 (Mar 2 in a leap year) — and back.
+// JS Date range rules: |ts| > 8.64e15 is an invalid Date and comes back unchanged; a result outside the range is
+// NaN (ok = false), for which `now >= expiry` is false.
+__device__ __forceinline__ long long floor_div(long long a, long long b) { const long long q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+__device__ __forceinline__ long long add_months_ms(long long ts, int months, long long tz_ms, bool& ok)
+{
+    constexpr long long kMax = 8640000000000000LL, kDay = 86400000LL;
+    ok = true;
+    if (ts > kMax || ts < -kMax) return ts;
+    const long long local = ts + tz_ms; // |ts| <= 8.64e15, |tz| <= a day: no overflow
+    const long long days = floor_div(local, kDay);
+    const long long ms_of_day = local - days * kDay;
+    // civil_from_days (proleptic Gregorian; day 0 = 1970-01-01)
+    long long z = days + 719468;
+    const long long era = floor_div(z, 146097);
+    const long long doe = z - era * 146097;                                  // [0, 146096]
+    const long long yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365; // [0, 399]
+    const long long doy = doe - (365 * yoe + yoe / 4 - yoe / 100);            // [0, 365]
+    const long long mp = (5 * doy + 2) / 153;                                 // [0, 11], March-based
+    const long long d = doy - (153 * mp + 2) / 5 + 1;                         // [1, 31]
+    const long long m = mp < 10 ? mp + 3 : mp - 9;                            // [1, 12]
+    const long long y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+    // shift the month index, renormalise the year
+    const long long mi = (m - 1) + months;
+    const long long y2 = y + floor_div(mi, 12);
+    const long long m2 = mi - floor_div(mi, 12) * 12 + 1;                     // [1, 12]
+    // days_from_civil(y2, m2, 1) + (d - 1)
+    const long long yy = y2 - (m2 <= 2 ? 1 : 0);
+    const long long era2 = floor_div(yy, 400);
+    const long long yoe2 = yy - era2 * 400;
+    const long long doy2 = (153 * (m2 > 2 ? m2 - 3 : m2 + 9) + 2) / 5;        // day of (March-based) year of the 1st
+    const long long doe2 = yoe2 * 365 + yoe2 / 4 - yoe2 / 100 + doy2;
+    const long long days2 = era2 * 146097 + doe2 - 719468 + (d - 1);
+    const long long out_local = days2 * kDay + ms_of_day;                     // < ~9e15 * small: fits
+    const long long out = out_local - tz_ms;
+    if (out > kMax || out < -kMax) ok = false;
+    return out;
+}
+
 template <int MODE>
 __device__ __forceinline__ bool list_match(const long long* __restrict__ end, const int* __restrict__ user, long long r,
                                            long long a, long long b)
@@ -1301,8 +1345,17 @@ __device__ __forceinline__ bool list_match(const long long* __restrict__ end, co
         return e <= b && e > a;
     } else if constexpr (MODE == 1) {
         return user[r] == (int)a && end[r] != INT64_MIN;
-    } else {
+    } else if constexpr (MODE == 2) {
         return reinterpret_cast<const long long*>(user)[r] < a && end[r] != INT64_MIN;
+    } else {
+        // MODE 3  retention purge (/root/reference/server/storage/sqlProvider.js:863-890,991-997): now >= addMonths(start,
+        //         months); `a` = now, `b` packs months (low 16 bits, signed) and the zone offset in minutes (above)
+        if (end[r] == INT64_MIN) return false;
+        const int months = (int)(short)(b & 0xFFFF);
+        const long long tz_ms = (b >> 16) * 60000LL;
+        bool ok;
+        const long long expiry = add_months_ms(reinterpret_cast<const long long*>(user)[r], months, tz_ms, ok);
+        return ok && a >= expiry;
     }
 }
 

@@ -621,7 +621,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     const int blocks = c->plan_blocks[0];
     const long long rpb = c->plan_rows[0];
     // MODE 2 matches on the start column: it travels through the kernels' generic second-column pointer
-    const int* col2 = MODE == 2 ? reinterpret_cast<const int*>(c->d_start) : c->d_user;
+    const int* col2 = (MODE == 2 || MODE == 3) ? reinterpret_cast<const int*>(c->d_start) : c->d_user;
     hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
@@ -867,6 +867,19 @@ int pie_prune_before(pie_ctx* c, int64_t cutoff, int32_t* rows_out, size_t cap, 
     if (n_pruned) *n_pruned = 0;
     if (c->n == 0) return PIE_OK;
     return run_row_list<2>(c, (long long)cutoff, 0, rows_out, cap, n_pruned);
+}
+
+int pie_retention_purge(pie_ctx* c, int64_t now, int32_t months, int64_t tz_offset_ms, int32_t* rows_out, size_t cap,
+                        size_t* n_purged)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_purged) *n_purged = 0;
+    if (months < -32768 || months > 32767) return fail(c, PIE_E_INVAL, "months outside int16");
+    if (tz_offset_ms % 60000 != 0 || tz_offset_ms > 86400000LL || tz_offset_ms < -86400000LL)
+        return fail(c, PIE_E_INVAL, "tz offset must be whole minutes within a day");
+    if (c->n == 0) return PIE_OK;
+    const long long packed = ((tz_offset_ms / 60000) << 16) | (long long)((unsigned)months & 0xFFFFu);
+    return run_row_list<3>(c, (long long)now, packed, rows_out, cap, n_purged);
 }
 
 int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)

@@ -385,6 +385,41 @@ def test_archive_group_min_queue(gpu_ctx, oracle):
     assert_same(gpu_ctx.scan(*spec_query(oracle)[:2]), oracle.scan(s, e, u, d, U, *spec_query(oracle)[:2], 0xFFFFFFFF))
 
 
+def test_retention_purge_calendar_months(gpu_ctx, oracle):
+    """sqlProvider.js:863-890,991-1009: now >= addMonths(createdAt, 2) with JS month arithmetic.  The device's integer
+    civil-date arithmetic against (1) the JS engine's own Date results (tests/golden/addmonths_utc.json) and (2) the
+    libc-based oracle on the synthetic corpus and on extreme timestamps, with and without a zone offset."""
+    g = json.load(open(os.path.join(GOLDEN, "addmonths_utc.json")))
+    by_months = {}
+    for ts, m, want in g["cases"]:
+        by_months.setdefault(m, []).append((ts, want))
+    for m, lst in by_months.items():
+        ts = np.array([t for t, _ in lst], np.int64)
+        e = np.full(ts.size, 2 ** 62, np.int64)
+        z = np.zeros(ts.size, np.int32)
+        for probe in (0, -1):   # now == expiry purges (>=); one millisecond earlier does not
+            for k, (t, want) in enumerate(lst):
+                if want is None:
+                    continue
+                gpu_ctx.load_columns(ts[k:k + 1], e[k:k + 1], z[:1], z[:1], 1)
+                assert gpu_ctx.retention_purge(want + probe, m).size == (1 if probe == 0 else 0), (t, m, want)
+                if len(lst) > 60 and k > 40:
+                    break
+        # whole list at once against the oracle
+        gpu_ctx.load_columns(ts, e, z, z, 1)
+        now = int(np.median(ts)) + 40 * DAY
+        want_rows = oracle.retention_queue(ts, e, now, m)
+        assert np.array_equal(gpu_ctx.retention_purge(now, m), want_rows)
+        assert gpu_ctx.retention_purge(now, m).size == 0           # purged rows are tombstoned
+    n, U = 300000, 50
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 3, 1)
+    e[::9] = INT64_MIN
+    for tz in (0, 330 * 60000, -8 * 3600000):
+        for now in (oracle.T0_MS, oracle.T0_MS - 30 * DAY, oracle.T0_MS - 200 * DAY):
+            gpu_ctx.load_columns(s, e, u, d, U)
+            assert np.array_equal(gpu_ctx.retention_purge(now, 2, tz), oracle.retention_queue(s, e, now, 2, tz))
+
+
 def test_expired_queue_parity(gpu_ctx, oracle):
     for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
         s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)

@@ -186,3 +186,18 @@ def test_archive_chain_hand_vector_and_twin(oracle):
         for now in [oracle.T0_MS, oracle.T0_MS - 119 * 86400000, INT64_MIN, 2 ** 62]:
             assert np.array_equal(oracle.archive_queue(s, e, u, U, now, 43200000),
                                   oracle.archive_queue_numpy(s, e, u, U, now, 43200000))
+
+
+def test_add_months_matches_js_date_vectors(oracle):
+    """The libc-based add-months oracle against 927 results of the JS engine's Date (TZ=UTC): month-end overflow, leap
+    years, negative timestamps, year wrap, the +-8.64e15 range rules of sqlProvider.js:999-1009."""
+    g = json.load(open(os.path.join(GOLDEN, "addmonths_utc.json")))
+    assert len(g["cases"]) > 900
+    for ts, m, want in g["cases"]:
+        assert oracle.add_months(ts, m, 0) == want, (ts, m)
+    # hand-checked: Dec 31 + 2 months overflows February (2025: Mar 3; leap 2024: Mar 2), sqlProvider.js:1007
+    assert oracle.add_months(1735603200000, 2) == 1740960000000       # 2024-12-31T00:00Z -> 2025-03-03T00:00Z
+    assert oracle.add_months(1703980800000, 2) == 1709337600000       # 2023-12-31T00:00Z -> 2024-03-02T00:00Z
+    # a fixed zone offset shifts the local calendar day: 2025-01-31T20:00Z is Feb 1 in UTC+05:30
+    assert oracle.add_months(1738353600000, 1, 330 * 60000) == 1738353600000 + 28 * 86400000
+    assert oracle.add_months(1738353600000, 1, 0) == 1738353600000 + 31 * 86400000   # Jan 31 + 1 month = "Feb 31" = Mar 3
