@@ -94,6 +94,10 @@ int pie_gen_synthetic(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0
  * n_users ascending 64-bit thresholds floor(CDF_k * 2^64) computed by the caller. */
 int pie_gen_synthetic_cdf(pie_ctx *ctx, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
                           int32_t n_disc, uint32_t flags, const uint64_t *cdf);
+/* Flat column files: <dir>/{start.i64,end.i64,user.i32,disc.i32} + header.json; the table survives a
+ * restart (the reference keeps sessions in memory only, server/sessionStore.js:6).  Load mmaps the files and uploads. */
+int pie_save_columns(pie_ctx *ctx, const char *dir);
+int pie_load_columns_dir(pie_ctx *ctx, const char *dir);
 /* Copy the resident columns back (any pointer may be NULL). */
 int pie_read_columns(pie_ctx *ctx, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, size_t n);
 /* touchSession (server/sessionStore.js:37-45): end[row] = new_end.  deleteSession (:47-53): new_end = PIE_END_NONE. */

@@ -45,6 +45,8 @@ _SIGS = [
     ("pie_load_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_gen_synthetic", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
     ("pie_gen_synthetic_cdf", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    ("pie_save_columns", C.c_int, [_P, C.c_char_p]),
+    ("pie_load_columns_dir", C.c_int, [_P, C.c_char_p]),
     ("pie_read_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t]),
     ("pie_set_end", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("pie_delete_user", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -157,6 +159,14 @@ class PieScan:
             raise ValueError("cdf must have n_users entries")
         self._check(self._lib.pie_gen_synthetic_cdf(self._ctx, seed, n_total, row0, n, n_users, n_disc, flags, _ptr(cdf)))
         self.n, self.n_users = int(n), int(n_users)
+
+    def save_columns(self, directory):
+        self._check(self._lib.pie_save_columns(self._ctx, os.fsencode(directory)))
+
+    def load_columns_dir(self, directory):
+        self._check(self._lib.pie_load_columns_dir(self._ctx, os.fsencode(directory)))
+        st = self.stats()
+        self.n, self.n_users = int(st["rows"]), int(st["users"])
 
     def read_columns(self):
         n = self.n

@@ -22,7 +22,13 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace pie;
 
@@ -810,6 +816,96 @@ int pie_gen_synthetic_cdf(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t ro
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, PIE_E_HIP, "pie_gen_synthetic_cdf: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return PIE_OK;
+}
+
+// ---- on-disk column format: <dir>/start.i64, end.i64, user.i32, disc.i32 (raw little-endian arrays) and
+// <dir>/header.json {"format":"pie-columns","version":1,"rows":N,"users":U}.  Contrast: the reference exports its whole
+// SQLite image after every mutation (/root/reference/server/storage/sqlProvider.js:737-744) and keeps sessions in memory
+// only (/root/reference/server/sessionStore.js:6).
+namespace {
+int write_file(pie_ctx* c, const std::string& path, const void* data, size_t bytes)
+{
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(c, PIE_E_INVAL, "cannot create %s", path.c_str());
+    const char* p = static_cast<const char*>(data);
+    size_t left = bytes;
+    while (left) {
+        const ssize_t w = write(fd, p, left > (1u << 30) ? (1u << 30) : left);
+        if (w <= 0) { close(fd); return fail(c, PIE_E_INVAL, "short write to %s", path.c_str()); }
+        p += w;
+        left -= (size_t)w;
+    }
+    close(fd);
+    return PIE_OK;
+}
+} // namespace
+
+int pie_save_columns(pie_ctx* c, const char* dir)
+{
+    if (!c || !dir) return PIE_E_INVAL;
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    PIE_HIP(c, hipSetDevice(c->device));
+    (void)mkdir(dir, 0755);
+    const size_t n = (size_t)c->n;
+    std::vector<char> host(n * 8 + 8);
+    const std::string base(dir);
+    struct { const char* name; const void* dev; size_t width; } cols[4] = {
+        {"/start.i64", c->d_start, 8}, {"/end.i64", c->d_end, 8}, {"/user.i32", c->d_user, 4}, {"/disc.i32", c->d_disc, 4}};
+    for (auto& col : cols) {
+        if (n) PIE_HIP(c, hipMemcpy(host.data(), col.dev, n * col.width, hipMemcpyDeviceToHost));
+        int rc = write_file(c, base + col.name, host.data(), n * col.width);
+        if (rc) return rc;
+    }
+    char hdr[256];
+    const int len = snprintf(hdr, sizeof hdr, "{\"format\":\"pie-columns\",\"version\":1,\"rows\":%lld,\"users\":%d}\n", c->n, c->n_users);
+    return write_file(c, base + "/header.json", hdr, (size_t)len);
+}
+
+int pie_load_columns_dir(pie_ctx* c, const char* dir)
+{
+    if (!c || !dir) return PIE_E_INVAL;
+    const std::string base(dir);
+    FILE* f = fopen((base + "/header.json").c_str(), "r");
+    if (!f) return fail(c, PIE_E_INVAL, "no header.json under %s", dir);
+    char hdr[512] = {0};
+    const size_t got = fread(hdr, 1, sizeof hdr - 1, f);
+    fclose(f);
+    (void)got;
+    long long rows = -1;
+    int users = -1, version = -1;
+    const char* pr = strstr(hdr, "\"rows\":");
+    const char* pu = strstr(hdr, "\"users\":");
+    const char* pv = strstr(hdr, "\"version\":");
+    if (!strstr(hdr, "\"pie-columns\"") || !pr || !pu || !pv) return fail(c, PIE_E_INVAL, "%s/header.json is not a pie-columns header", dir);
+    rows = atoll(pr + 7);
+    users = atoi(pu + 8);
+    version = atoi(pv + 10);
+    if (version != 1 || rows < 0 || users < 1) return fail(c, PIE_E_INVAL, "unsupported header in %s (version %d)", dir, version);
+    const size_t n = (size_t)rows;
+    const char* names[4] = {"/start.i64", "/end.i64", "/user.i32", "/disc.i32"};
+    const size_t width[4] = {8, 8, 4, 4};
+    void* maps[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = PIE_OK;
+    for (int k = 0; k < 4 && rc == PIE_OK; ++k) {
+        const int fd = open((base + names[k]).c_str(), O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size != n * width[k]) {
+            if (fd >= 0) close(fd);
+            rc = fail(c, PIE_E_INVAL, "%s%s missing or not %zu bytes", dir, names[k], n * width[k]);
+            break;
+        }
+        if (n) {
+            maps[k] = mmap(nullptr, n * width[k], PROT_READ, MAP_PRIVATE, fd, 0);
+            if (maps[k] == MAP_FAILED) { maps[k] = nullptr; rc = fail(c, PIE_E_NOMEM, "mmap of %s%s failed", dir, names[k]); }
+        }
+        close(fd);
+    }
+    if (rc == PIE_OK)
+        rc = pie_load_columns(c, (const int64_t*)maps[0], (const int64_t*)maps[1], (const int32_t*)maps[2], (const int32_t*)maps[3], n, users);
+    for (int k = 0; k < 4; ++k)
+        if (maps[k]) munmap(maps[k], n * width[k]);
+    return rc;
 }
 
 int pie_read_columns(pie_ctx* c, int64_t* start, int64_t* end, int32_t* user, int32_t* disc, size_t n)

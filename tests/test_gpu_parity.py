@@ -420,6 +420,35 @@ def test_retention_purge_calendar_months(gpu_ctx, oracle):
             assert np.array_equal(gpu_ctx.retention_purge(now, 2, tz), oracle.retention_queue(s, e, now, 2, tz))
 
 
+def test_column_files_round_trip(pie, gpu_ctx, oracle, tmp_path):
+    """Flat column files: save, load into a fresh context, same table and same feeds; bad directories fail loudly."""
+    n, U = 123457, 321
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    e[::13] = INT64_MIN
+    gpu_ctx.load_columns(s, e, u, d, U)
+    gpu_ctx.save_columns(str(tmp_path / "tbl"))
+    assert sorted(os.listdir(tmp_path / "tbl")) == ["disc.i32", "end.i64", "header.json", "start.i64", "user.i32"]
+    assert json.load(open(tmp_path / "tbl" / "header.json")) == {"format": "pie-columns", "version": 1, "rows": n, "users": U}
+    assert np.array_equal(np.fromfile(tmp_path / "tbl" / "end.i64", np.int64), e)
+    with pie.PieScan(0) as ctx2:
+        ctx2.load_columns_dir(str(tmp_path / "tbl"))
+        assert (ctx2.n, ctx2.n_users) == (n, U)
+        for a, b in zip(ctx2.read_columns(), (s, e, u, d)):
+            assert np.array_equal(a, b)
+        ctx2.set_disciplines(ALL, 32)
+        now, cutoff, _ = spec_query(oracle)
+        assert_same(ctx2.scan(now, cutoff), oracle.scan(s, e, u, d, U, now, cutoff, 0xFFFFFFFF))
+        with pytest.raises(pie.PieError):
+            ctx2.load_columns_dir(str(tmp_path / "nope"))
+        (tmp_path / "tbl" / "user.i32").write_bytes(b"\0" * 8)
+        with pytest.raises(pie.PieError):
+            ctx2.load_columns_dir(str(tmp_path / "tbl"))
+    gpu_ctx.load_columns(s[:0], e[:0], u[:0], d[:0], 1)      # an empty table round-trips too
+    gpu_ctx.save_columns(str(tmp_path / "empty"))
+    gpu_ctx.load_columns_dir(str(tmp_path / "empty"))
+    assert gpu_ctx.n == 0
+
+
 def test_expired_queue_parity(gpu_ctx, oracle):
     for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
         s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)
