@@ -201,6 +201,8 @@ def main():
         kname = "k_scan_live_first" if variant & 4 else "k_scan_compact"
         if variant & 0x200:
             kname = "k_scan_live_first_part"
+        if variant & 0x400:
+            kname = "k_scan_keyed"
         if args.mode == "expired":
             kname = "k_expired_stage"
         traffic = None

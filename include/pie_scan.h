@@ -57,8 +57,9 @@ typedef struct pie_stats {
     uint32_t n_segments;   /* block-sorted segments of the last scan */
     uint32_t n_big;        /* buckets that needed the multi-pass merge in the last scan */
     uint32_t k1_blocks;    /* grid of the scan kernel */
-    uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first) */
-    uint32_t reserved;
+    uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first,
+                              0x400 keyed: streams the 2-byte liveness key instead of the `end` column) */
+    uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
     uint64_t live;         /* rows with end > now seen by the last scan */
 } pie_stats;
 

@@ -28,7 +28,7 @@ class PieStats(C.Structure):
         ("struct_size", C.c_uint32), ("n_profiled", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
         ("selected", C.c_uint64), ("alg_bytes", C.c_uint64), ("k1_ms_sum", C.c_double), ("scan_ms_sum", C.c_double),
         ("max_bucket", C.c_uint32), ("n_segments", C.c_uint32), ("n_big", C.c_uint32), ("k1_blocks", C.c_uint32),
-        ("k1_variant", C.c_uint32), ("reserved", C.c_uint32), ("live", C.c_uint64),
+        ("k1_variant", C.c_uint32), ("key_ambiguous", C.c_uint32), ("live", C.c_uint64),
     ]
 
 

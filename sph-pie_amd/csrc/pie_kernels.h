@@ -52,6 +52,7 @@ struct Summary {
     unsigned long long live;    // rows with end > now seen by K1 (drives the choice of K1 variant for the next scan)
     unsigned int n_small;       // entries in the small-segment list (17..256 rows: one wave each)
     unsigned int pad;
+    unsigned long long amb;     // keyed table pass: rows whose liveness key equalled the query's (full `end` compare needed)
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -66,6 +67,36 @@ struct HostSummary {
     Summary s;
     unsigned long long seq;
 };
+
+// Per-scan row statistics of the table pass (rows live, rows with an ambiguous key).  Thousands of K1 blocks adding to ONE
+// address serialise at ~11 ns each in the L2 (a 6 000-block grid then cannot finish in under 130 us, whatever it
+// streams), so the blocks spread over 64 counters on separate 128-byte lines, right behind the scan's Summary; the
+// kernel that publishes the summary adds them up.
+struct alignas(128) StatSlot {
+    unsigned long long live, amb;
+    unsigned long long pad[14];
+};
+constexpr int kStatSlots = 64;
+constexpr int kSummaryBytes = 128; // Summary, padded: the slots start here
+static_assert(sizeof(Summary) <= kSummaryBytes, "Summary outgrew its padded slot");
+__device__ __forceinline__ StatSlot* stat_slots(Summary* s) { return reinterpret_cast<StatSlot*>(reinterpret_cast<char*>(s) + kSummaryBytes); }
+__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb)
+{
+    StatSlot* slot = stat_slots(s) + (blockIdx.x & (kStatSlots - 1));
+    if (live) atomicAdd(&slot->live, (unsigned long long)live);
+    if (amb) atomicAdd(&slot->amb, (unsigned long long)amb);
+}
+// one wave: lane l reads slot l; every lane returns the totals
+__device__ __forceinline__ void sum_row_stats(Summary* s, int lane, unsigned long long& live, unsigned long long& amb)
+{
+    StatSlot* slot = stat_slots(s) + (lane & (kStatSlots - 1));
+    live = __hip_atomic_load(&slot->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    amb = __hip_atomic_load(&slot->amb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_xor(live, o, 64);
+        amb += __shfl_xor(amb, o, 64);
+    }
+}
 
 constexpr int kWave = 64;
 constexpr int kK1Threads = 256;
@@ -337,7 +368,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_count[blockIdx.x] = blk_cursor;
-        if (blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+        add_row_stats(summary, blk_live, 0);
     }
 }
 
@@ -459,7 +490,217 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_count[blockIdx.x] = blk_cursor;
-        if (blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+        add_row_stats(summary, blk_live, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ liveness-key column
+//
+// The resident table carries one derived column next to `end`: a 15-bit monotone key of it in a uint16,
+//     key(e) = 0                                    e <  base          (tombstones, INT64_MIN, land here)
+//            = min(((e - base) >> shift) + 1, 32767) e >= base
+// built at load time with base = the smallest live `end` and the smallest shift that keeps the largest one below the
+// clamp.  key() is monotone non-decreasing over all of int64, so for any query time
+//     key(end) > key(now)  =>  end > now      key(end) < key(now)  =>  end < now
+// and only rows with key(end) == key(now) need the full 8-byte compare.  The liveness-first table pass then streams
+// 2 B/row instead of 8 B/row; correctness never depends on how well base/shift fit the data (a bad fit only makes more
+// rows ambiguous, which the scan reports in Summary::amb so the host can rebuild the column).
+// Every writer of `end` (k_set_end, the tombstoning list kernels, load / append / generate) keeps the key in step.
+typedef unsigned short lkey_t;
+constexpr unsigned kKeyMax = 32767u;
+
+__device__ __forceinline__ unsigned key_of(long long e, long long base, int shift)
+{
+    if (e < base) return 0u;
+    const unsigned long long k = ((unsigned long long)e - (unsigned long long)base) >> shift;
+    return k >= (unsigned long long)(kKeyMax - 1u) ? kKeyMax : (unsigned)k + 1u;
+}
+
+// smallest and largest `end` of the rows that are not tombstoned (range[0] = INT64_MAX, range[1] = INT64_MIN going in)
+__global__ __launch_bounds__(256) void k_end_range(const long long* __restrict__ end, long long n, long long* __restrict__ range)
+{
+    long long lo = INT64_MAX, hi = INT64_MIN;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const long long e = end[r];
+        if (e != INT64_MIN) {
+            lo = e < lo ? e : lo;
+            hi = e > hi ? e : hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long l2 = __shfl_xor(lo, o, kWave), h2 = __shfl_xor(hi, o, kWave);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&range[0], lo);
+        atomicMax(&range[1], hi);
+    }
+}
+
+// The second derived column: the three immutable fields of a row side by side, so that a candidate row costs ONE
+// 16-byte gather (one 128-byte HBM sector) instead of three gathers in three columns.  Written once per row (load,
+// append, generate); nothing ever changes start / user / disc afterwards.
+struct alignas(16) PayRec {
+    long long start;
+    int user;
+    int disc;
+};
+
+__global__ __launch_bounds__(256) void k_build_key(const long long* __restrict__ end, long long row0, long long n, long long base,
+                                                   int shift, lkey_t* __restrict__ key, const long long* __restrict__ start,
+                                                   const int* __restrict__ user, const int* __restrict__ disc,
+                                                   PayRec* __restrict__ pay)
+{
+    for (long long r = row0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        key[r] = (lkey_t)key_of(end[r], base, shift);
+        if (pay) {
+            PayRec p;
+            p.start = start[r];
+            p.user = user[r];
+            p.disc = disc[r];
+            pay[r] = p;
+        }
+    }
+}
+
+// K1, keyed liveness-first form: streams the 2-byte key column (eight rows per 16-byte load), finds the candidate rows
+// (key >= key(now)) with a SWAR compare, and from there on works like k_scan_live_first: candidates queue up in a
+// per-wave LDS ring and are evaluated 64 at a time — `end` only for the ambiguous ones, and one 16-byte record of the
+// payload column (start, user, disc) per candidate.  Output identical to the other forms.
+constexpr int kKeyRowsPerLoad = 8 * kWave; // 512 rows per wave per 16-byte load
+
+template <int UNROLL, bool AGG>
+__global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
+    const PayRec* __restrict__ pay, const long long* __restrict__ end, const lkey_t* __restrict__ key, long long n,
+    long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
+    SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
+{
+    __shared__ SelRec stage[kK1Waves][kStage];
+    __shared__ int stage_rank[kK1Waves][kStage];
+    __shared__ int live_ring[kK1Waves][kLiveRing];
+    __shared__ int blk_cursor;
+    __shared__ int blk_live;
+    __shared__ int blk_amb;
+    constexpr int kTile = kKeyRowsPerLoad * UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; }
+    __syncthreads();
+
+    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    long long c1 = c0 + rows_per_block;
+    if (c1 > n) c1 = n;
+    SelRec* out = sel + c0;
+    int* out_rank = sel_rank + c0;
+    WaveStage st;
+    st.ring = stage[wave];
+    st.ring_rank = stage_rank[wave];
+    st.head = 0;
+    st.fill = 0;
+    int* lring = live_ring[wave];
+    int lhead = 0, lfill = 0, nlive = 0, namb = 0; // wave-uniform
+
+    // evaluate `cnt` queued candidates (cnt <= 64), one per lane; bit 31 of a ring entry marks an ambiguous key
+    auto drain = [&](int cnt) {
+        bool p = false, live = false, amb = false;
+        long long sv = 0;
+        int row = 0, uv = -1, rk = 0;
+        if (lane < cnt) {
+            const int ent = lring[(lhead + lane) & (kLiveRing - 1)];
+            row = ent & 0x7FFFFFFF;
+            amb = ent < 0;
+            const PayRec pr = pay[row]; // issued before the (rare) `end` compare resolves: one gather per candidate
+            live = amb ? (end[row] > now) : true;
+            sv = pr.start;
+            const int dv = pr.disc;
+            p = live & (sv >= cutoff) & ((unsigned)dv < 64u) & (((mask >> (dv & 63)) & 1ull) != 0);
+            if (p) {
+                uv = pr.user;
+                if ((unsigned)uv >= (unsigned)n_users) { atomicAdd(&summary->bad_rows, 1u); p = false; }
+            }
+        }
+        nlive += __popcll(__ballot(live));
+        namb += __popcll(__ballot(amb));
+        // wave-aggregated histogram atomics for skewed users (see k_scan_live_first)
+        int grp_leader = lane, grp_prefix = 0, grp_size = 1;
+        unsigned long long todo = AGG ? __ballot(p) : 0ull;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int u_lead = __shfl(uv, leader, kWave);
+            const unsigned long long same = __ballot(p && uv == u_lead);
+            if (p && uv == u_lead) {
+                grp_leader = leader;
+                grp_prefix = prefix_in_ballot(same);
+                grp_size = __popcll(same);
+            }
+            todo &= ~same;
+        }
+        int base = 0;
+        if (p && grp_leader == lane) base = atomicAdd(&counts[uv], grp_size);
+        base = __shfl(base, grp_leader, kWave);
+        rk = base + grp_prefix;
+        lhead = (lhead + cnt) & (kLiveRing - 1);
+        lfill -= cnt;
+        stage_rows(p, sv, row, uv, rk, st, out, out_rank, &blk_cursor, lane);
+    };
+    auto push = [&](bool cand, int entry) {
+        const unsigned long long b = __ballot(cand);
+        if (b == 0) return false;
+        if (cand) lring[(lhead + lfill + prefix_in_ballot(b)) & (kLiveRing - 1)] = entry;
+        lfill += __popcll(b);
+        __builtin_amdgcn_wave_barrier();
+        if (lfill >= kWave) drain(kWave);
+        __builtin_amdgcn_wave_barrier();
+        return true;
+    };
+
+    // SWAR: keys are < 2^15, so with bit 15 of each half forced on, subtracting key(now) from both halves at once never
+    // borrows across them, and bit 15 of a half survives exactly when that key >= key(now)
+    const unsigned nk2 = now_key | (now_key << 16);
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
+        if (t + kTile <= c1) {
+            u4_t kv[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + t + j * kKeyRowsPerLoad + 8 * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int r0 = (int)(t + j * kKeyRowsPerLoad + 8 * lane);
+                const unsigned g0 = ((kv[j].x | 0x80008000u) - nk2) & 0x80008000u, g1 = ((kv[j].y | 0x80008000u) - nk2) & 0x80008000u;
+                const unsigned g2 = ((kv[j].z | 0x80008000u) - nk2) & 0x80008000u, g3 = ((kv[j].w | 0x80008000u) - nk2) & 0x80008000u;
+                // rows 0..3 keep their flags at bits 15/31/47/63, rows 4..7 move to bits 7/23/39/55
+                unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
+                                       (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
+                for (;;) {
+                    const bool has = m != 0;
+                    const int pbit = __ffsll((long long)m) - 1;         // meaningless when !has
+                    const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);   // row within the lane's eight
+                    const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
+                    const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
+                    const int entry = (r0 + q) | (kq == now_key ? (int)0x80000000 : 0);
+                    if (!push(has, entry)) break;
+                    m &= m - 1;
+                }
+            }
+        } else {
+            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
+            for (long long r0 = t; r0 < t1; r0 += kWave) {
+                const long long r = r0 + lane;
+                const unsigned kq = r < t1 ? key[r] : 0u;
+                push(r < t1 && kq >= now_key, (int)r | (kq == now_key ? (int)0x80000000 : 0));
+            }
+        }
+    }
+    if (lfill > 0) drain(lfill);
+    if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_count[blockIdx.x] = blk_cursor;
+        add_row_stats(summary, blk_live, blk_amb);
     }
 }
 
@@ -557,7 +798,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first_part(
     if (lfill > 0) drain(lfill);
     if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
     __syncthreads();
-    if (threadIdx.x == 0 && blk_live) atomicAdd(&summary->live, (unsigned long long)blk_live);
+    if (threadIdx.x == 0) add_row_stats(summary, blk_live, 0);
 }
 
 // bucket of n <= NS records at LDS slots [o, o+n) -> out[0..n) in (start, idx) order: bitonic network in registers,
@@ -757,8 +998,13 @@ __global__ __launch_bounds__(256) void k_publish_summary(Summary* __restrict__ s
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, kWave));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
+    if (threadIdx.x >= 64) return;
+    unsigned long long live = 0, amb = 0;
+    sum_row_stats(summary, (int)threadIdx.x, live, amb);
     if (threadIdx.x == 0) {
         Summary out = *summary;
+        out.live = live;
+        out.amb = amb;
         out.max_count = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         out.n_seg = out.n_big = out.n_small = 0;
         out.q = 0;
@@ -936,9 +1182,13 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
     // (vmcnt drain + barrier), and the reader uses agent-scope loads.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned d = atomicAdd(&ctl->done, 1u);
-        if (d == gridDim.x - 1 && host) {
+    __shared__ int is_last;
+    if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == gridDim.x - 1 && host) ? 1 : 0;
+    __syncthreads();
+    if (is_last && threadIdx.x < 64) {
+        unsigned long long live = 0, amb = 0;
+        sum_row_stats(summary, (int)threadIdx.x, live, amb); // K1 finished before this kernel started
+        if (threadIdx.x == 0) {
             Summary out;
             out.m = __hip_atomic_load(&summary->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.n_seg = __hip_atomic_load(&summary->n_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -946,9 +1196,10 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
             out.max_count = __hip_atomic_load(&summary->max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.bad_rows = __hip_atomic_load(&summary->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.q = 0;
-            out.live = __hip_atomic_load(&summary->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.live = live;
             out.n_small = __hip_atomic_load(&summary->n_small, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.pad = 0;
+            out.amb = amb;
             host->s = out;
             __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1250,10 +1501,14 @@ __global__ __launch_bounds__(256) void k_pack_results(const long long* __restric
 // ------------------------------------------------------------------------------------------------ table maintenance
 
 __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, const int* __restrict__ rows,
-                                                 const long long* __restrict__ new_end, long long k, long long n)
+                                                 const long long* __restrict__ new_end, long long k, long long n,
+                                                 lkey_t* __restrict__ key, long long key_base, int key_shift)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < k && (unsigned)rows[t] < (unsigned long long)n) end[rows[t]] = new_end[t];
+    if (t < k && (unsigned)rows[t] < (unsigned long long)n) {
+        end[rows[t]] = new_end[t];
+        key[rows[t]] = (lkey_t)key_of(new_end[t], key_base, key_shift);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fetch_rows(const int* __restrict__ idx, long long m, long long n,
@@ -1376,7 +1631,8 @@ __global__ __launch_bounds__(256) void k_list_count(const long long* __restrict_
 template <int MODE>
 __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end, const int* __restrict__ user, long long n,
                                                     long long rows_per_block, long long a, long long b,
-                                                    const long long* __restrict__ blk_off, int* __restrict__ queue, long long cap)
+                                                    const long long* __restrict__ blk_off, int* __restrict__ queue, long long cap,
+                                                    lkey_t* __restrict__ key)
 {
     __shared__ int wcount[4];
     __shared__ long long carry_s;
@@ -1396,7 +1652,7 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
         const long long pos = base + prefix_in_ballot(bal);
         if (hit && pos < cap) queue[pos] = (int)r;
         if constexpr (MODE != 0) {
-            if (hit) end[r] = INT64_MIN;
+            if (hit) { end[r] = INT64_MIN; key[r] = 0; } // a tombstone's liveness key is 0 under every base
         }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];

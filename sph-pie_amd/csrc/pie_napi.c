@@ -479,6 +479,144 @@ static napi_value fn_archive_queue(napi_env env, napi_callback_info info)
     return js_int(env, (int64_t)q);
 }
 
+/* ---- native feed serialiser ---------------------------------------------------------------
+ * serializeEvents(idx Int32Array, m, start BigInt64Array, end BigInt64Array, disc Int32Array, perDisc Array) -> Buffer
+ * holding exactly the bytes of JSON.stringify({events: rows.map(eventFromRow)}) for the event shape of
+ * /root/reference/server/calendarFeed.js:66-79 as host/calendarFeed.js builds it from session rows.  perDisc[d] =
+ * [titlePrefixJson (no quotes, already escaped), eventNameJson, colorJson] — the per-discipline constants are computed
+ * once in JS (parseCalendarMetadata), the per-row work (numbers, ISO dates, allDay) happens here.  Returns null when a
+ * row needs something this fast path does not cover (year outside 0000..9999, discipline outside the table): the
+ * caller then uses the JS path. */
+typedef struct { char *p; size_t len, cap; } sbuf;
+static int sb_need(sbuf *b, size_t extra)
+{
+    if (b->len + extra <= b->cap) return 1;
+    size_t nc = b->cap ? b->cap * 2 : 4096;
+    while (nc < b->len + extra) nc *= 2;
+    char *np = (char *)realloc(b->p, nc);
+    if (!np) return 0;
+    b->p = np;
+    b->cap = nc;
+    return 1;
+}
+static int sb_put(sbuf *b, const char *s, size_t n)
+{
+    if (!sb_need(b, n)) return 0;
+    memcpy(b->p + b->len, s, n);
+    b->len += n;
+    return 1;
+}
+#define SB_LIT(b, lit) sb_put((b), (lit), sizeof(lit) - 1)
+static int sb_i64(sbuf *b, int64_t v)
+{
+    char tmp[24];
+    int pos = 24;
+    uint64_t u = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+    do { tmp[--pos] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) tmp[--pos] = '-';
+    return sb_put(b, tmp + pos, (size_t)(24 - pos));
+}
+/* ms since epoch -> "YYYY-MM-DDTHH:mm:ss.sssZ"; returns 0 when the year is outside 0000..9999; *h / *mi = UTC hour, minute */
+static int iso_utc(int64_t ms, char out[25], int *h, int *mi)
+{
+    int64_t days = ms / 86400000, rem = ms % 86400000;
+    if (rem < 0) { rem += 86400000; days -= 1; }
+    int64_t z = days + 719468;
+    const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const int64_t mp = (5 * doy + 2) / 153;
+    const int64_t d = doy - (153 * mp + 2) / 5 + 1;
+    const int64_t m = mp < 10 ? mp + 3 : mp - 9;
+    const int64_t y = yoe + era * 400 + (m <= 2 ? 1 : 0);
+    if (y < 0 || y > 9999) return 0;
+    *h = (int)(rem / 3600000);
+    *mi = (int)(rem / 60000 % 60);
+    const int sec = (int)(rem / 1000 % 60), msec = (int)(rem % 1000), yy = (int)y;
+#define D2(pos, v) (out[pos] = (char)('0' + (v) / 10), out[(pos) + 1] = (char)('0' + (v) % 10))
+    D2(0, yy / 100); D2(2, yy % 100); out[4] = '-'; D2(5, (int)m); out[7] = '-'; D2(8, (int)d); out[10] = 'T';
+    D2(11, *h); out[13] = ':'; D2(14, *mi); out[16] = ':'; D2(17, sec); out[19] = '.';
+    out[20] = (char)('0' + msec / 100); D2(21, msec % 100); out[23] = 'Z'; out[24] = 0;
+#undef D2
+    return 1;
+}
+
+static napi_value fn_serialize_events(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    size_t cap = 0, n1 = 0, n2 = 0, n3 = 0;
+    int32_t *idx = typed(env, argv[0], napi_int32_array, &cap);
+    int64_t m = 0;
+    int64_t *start = typed(env, argv[2], napi_bigint64_array, &n1), *end = typed(env, argv[3], napi_bigint64_array, &n2);
+    int32_t *disc = typed(env, argv[4], napi_int32_array, &n3);
+    uint32_t n_disc = 0;
+    if (!idx || !get_i64(env, argv[1], &m) || m < 0 || (size_t)m > cap || !start || !end || !disc || n1 < (size_t)m ||
+        n2 < (size_t)m || n3 < (size_t)m || napi_get_array_length(env, argv[5], &n_disc) != napi_ok || n_disc > 64) {
+        napi_throw_type_error(env, NULL, "serializeEvents(Int32Array idx, m, BigInt64Array start, BigInt64Array end, Int32Array disc, Array perDisc)");
+        return NULL;
+    }
+    /* per-discipline constants */
+    char *parts[64][3];
+    size_t plen[64][3];
+    memset(parts, 0, sizeof parts);
+    int ok = 1;
+    for (uint32_t dix = 0; dix < n_disc && ok; ++dix) {
+        napi_value row;
+        if (napi_get_element(env, argv[5], dix, &row) != napi_ok) { ok = 0; break; }
+        for (uint32_t k = 0; k < 3 && ok; ++k) {
+            napi_value sv;
+            size_t len = 0;
+            if (napi_get_element(env, row, k, &sv) != napi_ok || napi_get_value_string_utf8(env, sv, NULL, 0, &len) != napi_ok) { ok = 0; break; }
+            parts[dix][k] = (char *)malloc(len + 1);
+            if (!parts[dix][k] || napi_get_value_string_utf8(env, sv, parts[dix][k], len + 1, &plen[dix][k]) != napi_ok) ok = 0;
+        }
+    }
+    sbuf b = {NULL, 0, 0};
+    int covered = ok;
+    if (ok) ok = SB_LIT(&b, "{\"events\":[");
+    for (int64_t i = 0; i < m && ok && covered; ++i) {
+        const int32_t dv = disc[i];
+        if (dv < 0 || (uint32_t)dv >= n_disc) { covered = 0; break; }
+        const int has_end = end[i] != INT64_MIN;
+        char iso_s[25], iso_e[25];
+        int hs = 0, ms_ = 0, he = 0, me = 0;
+        if (!iso_utc(start[i], iso_s, &hs, &ms_) || (has_end && !iso_utc(end[i], iso_e, &he, &me))) { covered = 0; break; }
+        /* allDay heuristic of calendarFeed.js:64 on the UTC clock fields */
+        const int all_day = hs == 0 && ms_ == 0 && (!has_end || he == 0);
+        ok = (i == 0 || SB_LIT(&b, ",")) && SB_LIT(&b, "{\"id\":\"session-") && sb_i64(&b, idx[i]) && SB_LIT(&b, "\",\"title\":\"") &&
+             sb_put(&b, parts[dv][0], plen[dv][0]) && SB_LIT(&b, " session #") && sb_i64(&b, idx[i]) &&
+             SB_LIT(&b, "\",\"description\":\"\",\"location\":\"\",\"start\":\"") && sb_put(&b, iso_s, 24) && SB_LIT(&b, "\",\"end\":\"") &&
+             (has_end ? sb_put(&b, iso_e, 24) : 1) && SB_LIT(&b, "\",\"startTs\":") && sb_i64(&b, start[i]) && SB_LIT(&b, ",\"endTs\":") &&
+             (has_end ? sb_i64(&b, end[i]) : SB_LIT(&b, "null")) && SB_LIT(&b, ",\"allDay\":") &&
+             (all_day ? SB_LIT(&b, "true") : SB_LIT(&b, "false")) && SB_LIT(&b, ",\"eventName\":") &&
+             sb_put(&b, parts[dv][1], plen[dv][1]) && SB_LIT(&b, ",\"showNumber\":") && sb_i64(&b, idx[i]) && SB_LIT(&b, ",\"color\":") &&
+             sb_put(&b, parts[dv][2], plen[dv][2]) && SB_LIT(&b, "}");
+    }
+    if (ok && covered) ok = SB_LIT(&b, "]}");
+    for (uint32_t dix = 0; dix < 64; ++dix)
+        for (int k = 0; k < 3; ++k) free(parts[dix][k]);
+    napi_value out = NULL;
+    if (!ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "serializeEvents: out of memory or bad perDisc table");
+        return NULL;
+    }
+    if (!covered) {
+        free(b.p);
+        napi_get_null(env, &out);
+        return out;
+    }
+    void *copy = NULL;
+    if (napi_create_buffer_copy(env, b.len, b.p, &copy, &out) != napi_ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "cannot create Buffer");
+        return NULL;
+    }
+    free(b.p);
+    return out;
+}
+
 /* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
@@ -524,7 +662,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
         {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
-        {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+        {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

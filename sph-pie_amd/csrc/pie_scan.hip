@@ -91,14 +91,26 @@ struct pie_ctx {
     int cap_users = 0;
     long long *d_start = nullptr, *d_end = nullptr;
     int *d_user = nullptr, *d_disc = nullptr;
+    // derived liveness-key column (see pie_kernels.h): 2 B/row, kept in step with d_end by every writer
+    lkey_t* d_key = nullptr;
+    PayRec* d_pay = nullptr;    // derived payload column (start, user, disc) per row: immutable after a row is written
+    long long key_base = 0;
+    int key_shift = 0;
+    bool key_ok = false;        // d_key covers rows [0, n) under (key_base, key_shift)
+    bool key_dirty = false;     // rows were appended / re-ended since the column was built: a rebuild may fit better
+    bool key_poor = false;      // a keyed scan found too many ambiguous rows and a rebuild would not help: use the `end` column
+    bool key_rebuild = false;   // ... and a rebuild may help: done at the next pie_scan_begin with nothing in flight
+    bool keyed_enabled = true;  // PIE_K1_KEYED=0 turns the keyed form off
+    int k1_keyed = 0x485;       // keyed liveness-first form (bit 0x400), unroll 8
+    long long* d_range = nullptr;
 
     // predicate table
     unsigned long long disc_mask = ~0ull;
     int n_disc = 64;
 
-    // scan plans: [0] streaming form, [1] liveness-first form
-    int plan_blocks[2] = {0, 0};
-    long long plan_rows[2] = {0, 0};
+    // scan plans: [0] streaming form, [1] liveness-first form, [2] keyed liveness-first form
+    int plan_blocks[3] = {0, 0, 0};
+    long long plan_rows[3] = {0, 0, 0};
     int n_tiles = 0;
     int k1_variant = 0x03;    // streaming form: nontemporal loads + late user materialisation
     int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
@@ -186,7 +198,8 @@ void free_slots(pie_ctx* c)
 
 void free_table(pie_ctx* c)
 {
-    dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc);
+    dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay);
+    c->key_ok = false;
     dfree(c->d_blk_off);
     free_slots(c);
     c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0;
@@ -208,7 +221,8 @@ void plan_one(pie_ctx* c, int which, long long want, const char* env)
         long long v = atoll(e);
         if (v > 0) want = v;
     }
-    const long long kBlockTileRows = (long long)kUnitRows * 8 * kK1Waves; // a whole number of wave-tiles for every unroll
+    // a whole number of wave-tiles for every unroll (the keyed form reads 512 rows per wave per load)
+    const long long kBlockTileRows = which == 2 ? (long long)kKeyRowsPerLoad * 8 * kK1Waves : (long long)kUnitRows * 8 * kK1Waves;
     long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
     if (tiles < 1) tiles = 1;
     if (want > tiles) want = tiles;
@@ -223,13 +237,15 @@ void plan_k1(pie_ctx* c)
 {
     plan_one(c, 0, (long long)c->n_cus * 48, "PIE_K1_BLOCKS");
     plan_one(c, 1, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_LIVE");
+    plan_one(c, 2, (long long)c->n_cus * 32, "PIE_K1_BLOCKS_KEYED");
 }
 
-// layout of a slot's span (all parts 64-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
-size_t span_counts_bytes(const pie_ctx* c) { return (((size_t)c->cap_users * 4 + 63) / 64) * 64; }
-size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / kScanTile + 2) * 8 + 63) / 64) * 64; }
+// layout of a slot's span (all parts 128-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
+size_t span_counts_bytes(const pie_ctx* c) { return (((size_t)c->cap_users * 4 + 127) / 128) * 128; }
+size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / kScanTile + 2) * 8 + 127) / 128) * 128; }
 size_t span_parts_bytes() { return (size_t)kPartMax * 4; }
-size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 64 + ((sizeof(Summary) + 63) / 64) * 64; }
+size_t span_stats_bytes() { return (size_t)kSummaryBytes + (size_t)kStatSlots * sizeof(StatSlot); } // Summary (padded) + the K1 row-statistics slots
+size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128 + span_stats_bytes(); }
 
 // Make room for n rows / n_users users.  keep_rows > 0: the first keep_rows rows of the resident columns survive
 // a re-allocation (append path; capacity grows geometrically so appends are amortised O(1) per row).
@@ -259,6 +275,13 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         PIE_HIP(c, hipMalloc(&c->d_end, rows * 8));
         PIE_HIP(c, hipMalloc(&c->d_user, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_disc, rows * 4));
+        // derived columns, rebuilt by build_keys after every (re)allocation; a table too large to carry them (18 B/row)
+        // simply runs without the keyed form
+        if (hipMalloc(&c->d_key, rows * sizeof(lkey_t) + 64) != hipSuccess || hipMalloc(&c->d_pay, rows * sizeof(PayRec)) != hipSuccess) {
+            (void)hipGetLastError();
+            dfree(c->d_key);
+            dfree(c->d_pay);
+        }
         if (keep_rows > 0 && old_s) {
             PIE_HIP(c, hipMemcpyAsync(c->d_start, old_s, keep_rows * 8, hipMemcpyDeviceToDevice, c->stream));
             PIE_HIP(c, hipMemcpyAsync(c->d_end, old_e, keep_rows * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -322,6 +345,52 @@ int validate_users(pie_ctx* c, long long row0 = 0)
     return PIE_OK;
 }
 
+// Liveness-key column for rows [row0, n).  row0 == 0, a re-allocated table, or `rebuild` re-derive (base, shift) from the
+// range of the live `end` values and key every row; otherwise the appended rows are keyed under the current parameters
+// (out-of-range values clamp; the column stays exact, only less selective).
+int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
+{
+    if (!c->d_key || !c->d_pay) { c->key_ok = false; return PIE_OK; }
+    const bool write_pay = !(rebuild && c->key_ok); // a refit of the key leaves the (immutable) payload alone
+    if (c->n == 0) { c->key_ok = true; c->key_base = 0; c->key_shift = 0; c->key_dirty = false; return PIE_OK; }
+    hipStream_t s = c->stream;
+    const int grid = c->n_cus * 8;
+    if (row0 == 0 || !c->key_ok || rebuild) {
+        const long long init[2] = {INT64_MAX, INT64_MIN};
+        long long got[2];
+        PIE_HIP(c, hipMemcpyAsync(c->d_range, init, sizeof init, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_end_range, dim3(grid), dim3(256), 0, s, c->d_end, c->n, c->d_range);
+        PIE_HIP(c, hipGetLastError());
+        PIE_HIP(c, hipMemcpyAsync(got, c->d_range, sizeof got, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+        c->key_base = 0;
+        c->key_shift = 0;
+        if (got[0] <= got[1]) {
+            c->key_base = got[0];
+            const unsigned long long span = (unsigned long long)got[1] - (unsigned long long)got[0];
+            while (c->key_shift < 63 && (span >> c->key_shift) >= (unsigned long long)(kKeyMax - 1u)) c->key_shift++;
+        }
+        row0 = 0;
+        c->key_dirty = false;
+        c->key_poor = false;
+        c->key_rebuild = false;
+    } else {
+        c->key_dirty = true;
+    }
+    hipLaunchKernelGGL(k_build_key, dim3(grid), dim3(256), 0, s, c->d_end, row0, c->n, c->key_base, c->key_shift, c->d_key,
+                       c->d_start, c->d_user, c->d_disc, write_pay ? c->d_pay : (PayRec*)nullptr);
+    PIE_HIP(c, hipGetLastError());
+    c->key_ok = true;
+    return PIE_OK;
+}
+
+unsigned host_key_of(const pie_ctx* c, long long e)
+{
+    if (e < c->key_base) return 0u;
+    const unsigned long long k = ((unsigned long long)e - (unsigned long long)c->key_base) >> c->key_shift;
+    return k >= (unsigned long long)(kKeyMax - 1u) ? kKeyMax : (unsigned)k + 1u;
+}
+
 int resolve_events(pie_ctx* c)
 {
     if (c->ring_used == 0) return PIE_OK;
@@ -362,6 +431,24 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
                        sl.sel_rank, sl.blk_count, sl.sum)
+    if (sl.variant & 0x400) { // keyed liveness-first form
+#define PIE_K1K(UN)                                                                                                  \
+    if (sl.variant & 0x40)                                                                                          \
+        hipLaunchKernelGGL((k_scan_keyed<UN, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,         \
+                           c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask, c->n_users,            \
+                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum);                                    \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k_scan_keyed<UN, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,        \
+                           c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask, c->n_users,            \
+                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum)
+        switch (sl.variant & 0xA0) {
+        case 0x20: PIE_K1K(2); break;
+        case 0x80: PIE_K1K(8); break;
+        default: PIE_K1K(4); break;
+        }
+#undef PIE_K1K
+        return;
+    }
     if (sl.variant == 0x101) { // group-qualified form, used only by pie_archive_queue
         hipLaunchKernelGGL((k_scan_compact<4, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
                            c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
@@ -398,6 +485,10 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n_flight >= 2) return fail(c, PIE_E_STATE, "two scans are already in flight: call pie_scan_finish first");
+    if (c->key_rebuild && c->n_flight == 0) {
+        int rc = build_keys(c, 0, true);
+        if (rc) return rc;
+    }
     Slot& sl = c->slot[c->next_slot];
     hipStream_t s = c->stream;
     sl.ev_index = -1;
@@ -420,10 +511,15 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     const unsigned long long mask = c->n_disc >= 64 ? c->disc_mask : (c->disc_mask & ((1ull << c->n_disc) - 1ull));
     sl.variant = c->k1_variant;
     if (c->d_qual) sl.variant = 0x101;
-    else if (!c->k1_pinned && c->live_frac >= 0) sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+    else if (!c->k1_pinned && c->live_frac >= 0) {
+        sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
+        // few candidates: stream the 2-byte liveness key instead of the 8-byte `end` column
+        if ((sl.variant & 4) && c->keyed_enabled && c->key_ok && !c->key_poor) sl.variant = c->k1_keyed;
+    }
+    if ((sl.variant & 0x400) && !c->key_ok) sl.variant = c->k1_live_first; // pinned keyed form without a key column
     // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
     if (!c->k1_pinned && !c->d_qual && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
-    const int plan = (sl.variant & 4) ? 1 : 0;
+    const int plan = (sl.variant & 0x400) ? 2 : (sl.variant & 4) ? 1 : 0;
     sl.k1_blocks = c->plan_blocks[plan];
     sl.rows_per_block = c->plan_rows[plan];
     sl.have_result = false;
@@ -436,7 +532,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
         sl.tile_pub = reinterpret_cast<unsigned long long*>(base + span_counts_bytes(c));
         sl.part_cursor = reinterpret_cast<int*>(base + span_counts_bytes(c) + span_tiles_bytes(c));
         sl.ctl = reinterpret_cast<ScanCtl*>(base + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes());
-        sl.sum = reinterpret_cast<Summary*>(base + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 64);
+        sl.sum = reinterpret_cast<Summary*>(base + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128);
         c->span_next = (c->span_next + 1) % 3;
     }
     int4* zero_span = reinterpret_cast<int4*>(c->span[c->span_next]);
@@ -454,6 +550,8 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     }
     if (sl.fast) {
         sl.variant = 0x285;
+        sl.k1_blocks = c->plan_blocks[1];
+        sl.rows_per_block = c->plan_rows[1];
         if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e0, s));
         hipLaunchKernelGGL((k_scan_live_first_part<8, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end,
                            c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, c->part_shift,
@@ -549,6 +647,11 @@ int scan_finish(pie_ctx* c)
             return PIE_OK;
         }
     }
+    if ((sl.variant & 0x400) && sl.last.amb > 4096 && sl.last.amb > (unsigned long long)c->n / 64) {
+        // the key column separated this query badly (e.g. `now` beyond the range it was built for)
+        if (c->key_dirty) c->key_rebuild = true;
+        else c->key_poor = true;
+    }
     if (!c->d_qual) {
         c->last_m = (long long)sl.last.m;
         c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
@@ -631,7 +734,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
-                       c->d_blk_off, sl.out_idx, c->cap_rows);
+                       c->d_blk_off, sl.out_idx, c->cap_rows, c->d_key);
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
     PIE_HIP(c, hipStreamSynchronize(s));
@@ -683,6 +786,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     bool ok = (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) == hipSuccess &&
               (e = hipMalloc(&c->d_summary, sizeof(Summary))) == hipSuccess &&
+              (e = hipMalloc(&c->d_range, 16)) == hipSuccess &&
               (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) == hipSuccess;
     for (Slot& s : c->slot) {
         ok = ok && (e = hipHostMalloc(&s.h_sum, sizeof(HostSummary), hipHostMallocMapped)) == hipSuccess &&
@@ -698,6 +802,11 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_K1_VARIANT")) { c->k1_variant = (int)strtol(v, nullptr, 0); c->k1_pinned = true; }
     if (const char* v = getenv("PIE_K1_LIVE_FIRST")) c->k1_live_first = (int)strtol(v, nullptr, 0);
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
+    if (const char* v = getenv("PIE_K1_KEYED")) {
+        const int k = (int)strtol(v, nullptr, 0);
+        c->keyed_enabled = k != 0;
+        if (k & 0x400) c->k1_keyed = k;
+    }
     *ctx_out = c;
     return PIE_OK;
 }
@@ -715,6 +824,7 @@ int pie_ctx_destroy(pie_ctx* c)
         if (s.h_sum) (void)hipHostFree(s.h_sum);
     }
     if (c->d_summary) (void)hipFree(c->d_summary);
+    if (c->d_range) (void)hipFree(c->d_range);
     if (c->h_summary) (void)hipHostFree(c->h_summary);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -754,7 +864,7 @@ int pie_load_columns(pie_ctx* c, const int64_t* start, const int64_t* end, const
     }
     rc = validate_users(c);
     if (rc) { c->n = 0; plan_k1(c); return rc; }
-    return PIE_OK;
+    return build_keys(c, 0);
 }
 
 int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const int32_t* user, const int32_t* disc,
@@ -775,7 +885,7 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
     }
     rc = validate_users(c, old_n);
     if (rc) { c->n = old_n; plan_k1(c); return rc; }
-    return PIE_OK;
+    return build_keys(c, old_n);
 }
 
 int pie_gen_synthetic(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users,
@@ -792,6 +902,8 @@ int pie_gen_synthetic(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t row0, 
                            (long long)n, n_users, n_disc, flags, c->d_start, c->d_end, c->d_user, c->d_disc);
         PIE_HIP(c, hipGetLastError());
     }
+    rc = build_keys(c, 0);
+    if (rc) return rc;
     PIE_HIP(c, hipStreamSynchronize(c->stream));
     return PIE_OK;
 }
@@ -815,6 +927,10 @@ int pie_gen_synthetic_cdf(pie_ctx* c, uint64_t seed, int64_t n_total, int64_t ro
     (void)hipFree(d_cdf);
     if (e != hipSuccess || e2 != hipSuccess)
         return fail(c, PIE_E_HIP, "pie_gen_synthetic_cdf: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    c->key_ok = false; // the user column was rewritten: the payload column has to follow
+    rc = build_keys(c, 0);
+    if (rc) return rc;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
     return PIE_OK;
 }
 
@@ -940,7 +1056,8 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     (void)hipMemcpyAsync(d_rows, rows, k * 4, hipMemcpyHostToDevice, c->stream);
     (void)hipMemcpyAsync(d_new, new_end, k * 8, hipMemcpyHostToDevice, c->stream);
     hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end, d_rows, d_new,
-                       (long long)k, c->n);
+                       (long long)k, c->n, c->d_key, c->key_base, c->key_shift);
+    c->key_dirty = true;
     e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_rows);
     (void)hipFree(d_new);
@@ -1298,7 +1415,7 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
     out->n_big = sl ? sl->last.n_big : 0;
     out->k1_blocks = sl ? (uint32_t)sl->k1_blocks : 0;
     out->k1_variant = sl ? (uint32_t)sl->variant : 0;
-    out->reserved = 0;
+    out->key_ambiguous = (c->res && (c->res->variant & 0x400)) ? (uint32_t)(c->res->last.amb > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->res->last.amb) : 0u;
     out->live = sl ? sl->last.live : 0;
     return PIE_OK;
 }

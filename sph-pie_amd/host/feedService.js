@@ -19,6 +19,48 @@ function createFeedService(store, options){
     return {now, cutoff, res};
   }
 
+  // per-discipline constants of the event object, computed once with the JS mirror of parseCalendarMetadata; a
+  // discipline whose name would make the title parse differently per row (a '#<digits>' of its own) disables the
+  // native serialiser
+  let perDisc = null;
+  function nativeTable(){
+    if(perDisc !== null){ return perDisc; }
+    const table = [];
+    for(const d of disciplineConfig.DISCIPLINES){
+      const probe = calendarFeed.eventFromRow(123456789, 0n, 0n, d.name);
+      if(probe.showNumber !== 123456789){ perDisc = false; return perDisc; }
+      const nameJson = JSON.stringify(d.name);
+      table.push([nameJson.slice(1, nameJson.length - 1), JSON.stringify(probe.eventName), JSON.stringify(probe.color)]);
+    }
+    perDisc = table;
+    return perDisc;
+  }
+
+  // {"events":[...]} as bytes for one slice, by the native serialiser when it covers the rows, else via JSON.stringify
+  function eventsJsonFromSlice(res, lo, hi){
+    const idx = res.idx.subarray(lo, hi);
+    const cols = store.fetchRows(idx);
+    const table = nativeTable();
+    if(table && store.native && typeof store.native.serializeEvents === 'function'){
+      const buf = store.native.serializeEvents(idx, idx.length, cols.start, cols.end, cols.disc, table);
+      if(buf !== null){ return buf; }
+    }
+    const events = [];
+    for(let i = 0; i < idx.length; i++){
+      const d = disciplineConfig.DISCIPLINES[cols.disc[i]];
+      events.push(calendarFeed.eventFromRow(idx[i], cols.start[i], cols.end[i], d ? d.name : 'Session'));
+    }
+    return Buffer.from(JSON.stringify({events}));
+  }
+
+  // response body bytes for one user's feed
+  function eventsJsonForUser(userId, query){
+    const u = store.userIndexOf(userId);
+    if(u < 0){ return Buffer.from('{"events":[]}'); }
+    const {res} = scan(query);
+    return eventsJsonFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]));
+  }
+
   function eventsFromSlice(res, lo, hi){
     const idx = res.idx.subarray(lo, hi);
     const cols = store.fetchRows(idx);
@@ -53,7 +95,7 @@ function createFeedService(store, options){
     return feeds;
   }
 
-  return {scan, eventsForUser, allFeeds};
+  return {scan, eventsForUser, eventsJsonForUser, allFeeds};
 }
 
 module.exports = {createFeedService};

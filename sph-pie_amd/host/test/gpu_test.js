@@ -182,6 +182,38 @@ function get(port, cookie){
     console.error = quiet;
     server.close(); broken.close(); store.close();
   }
+  // ---- 3b. native serialiser: byte-identical to JSON.stringify of the JS-built events, incl. sentinel ends, every
+  //          discipline, midnight (allDay) rows; a year beyond 9999 falls back to the JS path
+  {
+    const cf = require('../calendarFeed');
+    const store = createStore();
+    const native = store.native;
+    const names = dc.DISCIPLINES.map(d => d.name);
+    const n = 500;
+    const idx = new Int32Array(n), s = new BigInt64Array(n), e = new BigInt64Array(n), d = new Int32Array(n);
+    let seed = 12345;
+    const rnd = () => { seed = (Math.imul(seed, 1664525) + 1013904223) >>> 0; return seed / 4294967296; };
+    for(let i = 0; i < n; i++){
+      idx[i] = Math.floor(rnd() * 2e9);
+      let st = 1700000000000 - Math.floor(rnd() * 1e10);
+      if(i % 7 === 0){ st = Math.floor(st / 86400000) * 86400000; }          // midnight UTC
+      s[i] = BigInt(st);
+      e[i] = i % 5 === 0 ? cf.END_NONE : BigInt(i % 7 === 0 && i % 2 === 0 ? st + 86400000 : st + 43200000);
+      d[i] = i % names.length;
+    }
+    s[3] = -5000000000000n; e[3] = -4999999999000n;                          // year 1811
+    const table = names.map(nm => { const p = cf.eventFromRow(1, 0n, 0n, nm); const j = JSON.stringify(nm); return [j.slice(1, j.length - 1), JSON.stringify(p.eventName), JSON.stringify(p.color)]; });
+    const want = JSON.stringify({events: Array.from(idx, (row, i) => cf.eventFromRow(row, s[i], e[i], names[d[i]]))});
+    const got = native.serializeEvents(idx, n, s, e, d, table);
+    eq(got.toString('utf8') === want, true, 'native serialiser bytes');
+    eq(native.serializeEvents(idx, 0, s, e, d, table).toString(), '{"events":[]}');
+    s[0] = 300000000000000n;                                                 // year 11476: not covered -> null
+    eq(native.serializeEvents(idx, n, s, e, d, table), null);
+    d[1] = 99;
+    eq(native.serializeEvents(idx, 2, s.subarray(1), e.subarray(1), d.subarray(1), table), null);
+    store.close();
+  }
+
   // ---- 4. expired-session dispatch queue: device-ordered, drained sequentially, failures summarised
   {
     const {dispatchExpiredSessions} = require('../dispatchQueue');

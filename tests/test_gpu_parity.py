@@ -103,7 +103,8 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
     run_both(gpu_ctx, oracle, cols, U, D, oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)
 
 
-@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45])
+@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
+                                     0x405, 0x425, 0x485, 0x4C5])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
     through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
@@ -133,9 +134,9 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         st = ctx.stats()
         assert st["k1_variant"] == 0x03 and abs(st["live"] / n - 18 / (120 * 24)) < 2e-3
         assert_same(ctx.scan(now, cutoff), want_spec)
-        assert ctx.stats()["k1_variant"] == 0x85
+        assert ctx.stats()["k1_variant"] == 0x485              # keyed liveness-first: streams the 2-byte key column
         assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # still liveness-first (decided from the last scan) ...
-        assert ctx.stats()["k1_variant"] == 0x85 and ctx.stats()["live"] == n
+        assert ctx.stats()["k1_variant"] == 0x485 and ctx.stats()["live"] == n
         assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and back to streaming once everything is live
         assert ctx.stats()["k1_variant"] == 0x03
 
@@ -278,7 +279,7 @@ def test_zipf_corpus_parity(pie, gpu_ctx, oracle):
     want = oracle.scan(*want_cols, U, now, cutoff, 0xFFFFFFFF)
     for _ in range(3):
         assert_same(gpu_ctx.scan(now, cutoff), want)
-    assert gpu_ctx.stats()["k1_variant"] == 0xC5
+    assert gpu_ctx.stats()["k1_variant"] == 0x4C5
 
 
 def test_skewed_users_big_buckets(gpu_ctx, oracle):
@@ -342,6 +343,107 @@ def test_append_rows_equals_bulk_load(gpu_ctx, oracle):
     got = gpu_ctx.scan(INT64_MIN, INT64_MIN)
     want = oracle.scan(s, e, u, d, gpu_ctx.n_users, INT64_MIN, INT64_MIN, mask & 0xFFFFFFFF)
     assert_same(got, want)
+
+
+def test_liveness_key_follows_every_writer_of_end(pie, oracle, monkeypatch):
+    """The keyed table pass reads a derived 2-byte column instead of `end`; every call that changes `end` must keep it in
+    step.  With the keyed form pinned: touch (dead -> live, live -> dead, values far outside the range the key was built
+    for), tombstones from delete_user / prune_before / retention_purge, appends below, inside and beyond the key range —
+    after each the scan equals the oracle on the mirrored columns, at query times inside, below and above the range."""
+    monkeypatch.setenv("PIE_K1_VARIANT", "0x485")
+    rng = np.random.default_rng(2024)
+    n, U, D = 300007, 700, 32
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 1)
+    s, e, u, d = s.copy(), e.copy(), u.copy(), d.copy()
+    now0 = oracle.T0_MS - 6 * 3600 * 1000
+    nows = [now0, oracle.T0_MS - 60 * DAY, INT64_MIN, oracle.T0_MS - 130 * DAY, oracle.T0_MS + 400 * DAY, 2 ** 62, int(e[12345]), int(e[12345]) - 1]
+
+    def check(ctx):
+        for now in nows:
+            assert_same(ctx.scan(now, INT64_MIN), oracle.scan(s, e, u, d, ctx.n_users, now, INT64_MIN, 0xFFFFFFFF))
+            assert ctx.stats()["k1_variant"] == 0x485
+
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        check(ctx)
+        # touch: new ends inside the range, far below, far above, the int64 extremes, tombstones
+        rows = rng.choice(n, 5000, replace=False).astype(np.int32)
+        new_end = rng.integers(oracle.T0_MS - 125 * DAY, oracle.T0_MS + 5 * DAY, rows.size).astype(np.int64)
+        new_end[:50] = INT64_MIN
+        new_end[50:100] = 2 ** 63 - 1
+        new_end[100:150] = oracle.T0_MS + 4000 * DAY
+        new_end[150:200] = -5
+        ctx.set_end(rows, new_end)
+        e[rows] = new_end
+        check(ctx)
+        gone = ctx.delete_user(5)
+        assert np.array_equal(gone, np.nonzero((u == 5) & (e != INT64_MIN))[0])
+        e[gone] = INT64_MIN
+        check(ctx)
+        gone = ctx.prune_before(oracle.T0_MS - 100 * DAY)
+        e[gone] = INT64_MIN
+        check(ctx)
+        gone = ctx.retention_purge(oracle.T0_MS, 3, 0)
+        assert gone.size > 0
+        e[gone] = INT64_MIN
+        check(ctx)
+        # appends: within capacity growth and beyond it, ends below / inside / beyond the key range
+        for k in (1, 777, 400000):
+            s2 = rng.integers(oracle.T0_MS - 10 * DAY, oracle.T0_MS + 300 * DAY, k).astype(np.int64)
+            e2 = s2 + rng.integers(-200 * DAY, 200 * DAY, k)
+            u2 = rng.integers(0, U + 5, k).astype(np.int32)
+            d2 = rng.integers(0, D, k).astype(np.int32)
+            ctx.append_rows(s2, e2, u2, d2, U + 5)
+            s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]), np.concatenate([d, d2])
+            check(ctx)
+
+
+def test_liveness_key_refit_and_fallback(pie, oracle):
+    """Unpinned: (1) rows appended far beyond the range the key column was built for all clamp to the top key, a query in
+    that new range finds them ambiguous, and the column is rebuilt before the next scan, after which the keyed form is
+    selective again; (2) a table whose `end` values are all equal cannot be separated by any key: the scan notices and
+    goes back to streaming the `end` column.  Results equal the oracle at every step."""
+    rng = np.random.default_rng(5)
+    n, U, D = 400000, 500, 32
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        now = oracle.T0_MS - 6 * 3600 * 1000
+        want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+        for _ in range(3):
+            assert_same(ctx.scan(now, INT64_MIN), want)
+        st = ctx.stats()
+        assert st["k1_variant"] == 0x485 and st["key_ambiguous"] < 200
+        # one appended row doubles the table's capacity (and re-derives the key while it is at it) ...
+        ctx.append_rows(s[:1], e[:1], u[:1], d[:1], U)
+        s, e, u, d = np.concatenate([s, s[:1]]), np.concatenate([e, e[:1]]), np.concatenate([u, u[:1]]), np.concatenate([d, d[:1]])
+        # ... so these fit in place, keyed under the old parameters.  A year later: 300 000 new sessions, the old ones long dead
+        k = 300000
+        s2 = (oracle.T0_MS + 365 * DAY + rng.integers(0, 30 * DAY, k)).astype(np.int64)
+        e2 = s2 + 43200000
+        u2, d2 = rng.integers(0, U, k).astype(np.int32), rng.integers(0, D, k).astype(np.int32)
+        ctx.append_rows(s2, e2, u2, d2, U)
+        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]), np.concatenate([d, d2])
+        now = oracle.T0_MS + 365 * DAY + 29 * DAY
+        want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+        seen = []
+        for _ in range(4):
+            assert_same(ctx.scan(now, INT64_MIN), want)
+            st = ctx.stats()
+            seen.append((st["k1_variant"], st["key_ambiguous"]))
+        assert seen[1][0] == 0x485 and seen[1][1] > 250000      # every appended row sat on the clamp key
+        assert seen[3][0] == 0x485 and seen[3][1] < 2000        # rebuilt: selective again
+        # all ends equal: no key can separate a query at that instant
+        e3 = np.full(n, oracle.T0_MS, np.int64)
+        ctx.load_columns(s[:n], e3, u[:n], d[:n], U)
+        want = oracle.scan(s[:n], e3, u[:n], d[:n], U, oracle.T0_MS, INT64_MIN, 0xFFFFFFFF)
+        forms = []
+        for _ in range(4):
+            assert_same(ctx.scan(oracle.T0_MS, INT64_MIN), want)
+            forms.append(ctx.stats()["k1_variant"])
+        assert want[2].size == 0 and forms[1] == 0x485 and forms[2] == 0x85 and forms[3] == 0x85
 
 
 def test_prune_before_is_the_window_complement(gpu_ctx, oracle):
