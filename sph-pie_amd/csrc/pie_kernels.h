@@ -109,7 +109,8 @@ constexpr int kStage = 128;                     // per-wave LDS ring of selected
 constexpr int kTinyMax = 16;
 constexpr int kSmallMax = 512;                  // buckets of 17..512 rows: sorted by ONE wave in LDS, no block barriers
 constexpr int kSegMax = 4096;
-constexpr int kScanTile = 2048;                 // counts per K2 block (256 threads x 8)
+constexpr int kScanTile = 2048;                 // counts per K2 block (256 threads x 8); the fused K2+K4 form uses kOrderTile
+constexpr int kOrderTile = 1024;                // users per block of the fused form: one per thread, 1024-thread blocks
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -233,6 +234,26 @@ __device__ __forceinline__ void stage_rows(bool sel, long long s, int row, int u
     __builtin_amdgcn_wave_barrier();
 }
 
+// Direct bucket slots.  A selected row whose rank inside its user's bucket (the value its histogram atomic returned) is
+// below kTinyMax goes straight to direct[user * kTinyMax + rank]: a fixed-capacity bucket per user that needs no offsets,
+// so for the sparse queries this path is built for nothing is staged, K3 has nothing to scatter and the per-bucket
+// order kernel can run right behind K2.  Only ranks >= kTinyMax (buckets that outgrow 16 rows) take the staged route.
+// direct == nullptr (user tables too large to carry 256 B per user) keeps every row on the staged route.
+__device__ __forceinline__ void emit_row(bool sel, long long s, int row, int u, int rank, BktRec* __restrict__ direct,
+                                         WaveStage& st, SelRec* __restrict__ out, int* __restrict__ out_rank, int* blk_cursor,
+                                         int lane)
+{
+    if (direct && sel && rank < kTinyMax) {
+        BktRec r;
+        r.start = s;
+        r.idx = row;
+        r.pad = 0;
+        direct[(long long)u * kTinyMax + rank] = r;
+        sel = false;
+    }
+    stage_rows(sel, s, row, u, rank, st, out, out_rank, blk_cursor, lane);
+}
+
 template <bool NT, class T>
 __device__ __forceinline__ T stream_load(const T* p)
 {
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct,
     const unsigned char* __restrict__ qual = nullptr)
 {
     static_assert(!(GQ && LATE_U), "the group-qualified predicate needs the user column up front");
@@ -332,8 +353,8 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
             for (int k = 0; k < 2 * UNROLL; ++k) {
                 const int j = k >> 1;
                 const int r = (int)(t + j * kUnitRows + 2 * lane) + (k & 1);
-                stage_rows(p[k], (k & 1) ? s[j].y : s[j].x, r, (k & 1) ? u[j].y : u[j].x, rank[k], st, out, out_rank,
-                           &blk_cursor, lane);
+                emit_row(p[k], (k & 1) ? s[j].y : s[j].x, r, (k & 1) ? u[j].y : u[j].x, rank[k], direct, st, out, out_rank,
+                         &blk_cursor, lane);
             }
         } else {
             // ragged tail of the block's range: one row per lane, bounds-checked
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
                         else { atomicAdd(bad_rows, 1u); sel_row = false; }
                     }
                 }
-                stage_rows(sel_row, sv, (int)r, uv, rk, st, out, out_rank, &blk_cursor, lane);
+                emit_row(sel_row, sv, (int)r, uv, rk, direct, st, out, out_rank, &blk_cursor, lane);
             }
         }
     }
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
         rk = base + grp_prefix;
         lhead = (lhead + cnt) & (kLiveRing - 1);
         lfill -= cnt;
-        stage_rows(p, sv, row, uv, rk, st, out, out_rank, &blk_cursor, lane);
+        emit_row(p, sv, row, uv, rk, direct, st, out, out_rank, &blk_cursor, lane);
     };
     auto push_live = [&](bool live, int row) {
         const unsigned long long b = __ballot(live);
@@ -570,11 +591,12 @@ __global__ __launch_bounds__(256) void k_build_key(const long long* __restrict__
 // payload column (start, user, disc) per candidate.  Output identical to the other forms.
 constexpr int kKeyRowsPerLoad = 8 * kWave; // 512 rows per wave per 16-byte load
 
-template <int UNROLL, bool AGG>
+template <int UNROLL, bool AGG, bool NT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const lkey_t* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
-    SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary)
+    SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
+    BktRec* __restrict__ direct)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
         rk = base + grp_prefix;
         lhead = (lhead + cnt) & (kLiveRing - 1);
         lfill -= cnt;
-        stage_rows(p, sv, row, uv, rk, st, out, out_rank, &blk_cursor, lane);
+        emit_row(p, sv, row, uv, rk, direct, st, out, out_rank, &blk_cursor, lane);
     };
     auto push = [&](bool cand, int entry) {
         const unsigned long long b = __ballot(cand);
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
             u4_t kv[UNROLL];
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j)
-                kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + t + j * kKeyRowsPerLoad + 8 * lane));
+                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(key + t + j * kKeyRowsPerLoad + 8 * lane));
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
                 const int r0 = (int)(t + j * kKeyRowsPerLoad + 8 * lane);
@@ -1068,77 +1090,186 @@ __global__ __launch_bounds__(256) void k_block_prefix(const int* __restrict__ bl
 }
 
 // K2: offsets[u] = exclusive prefix of counts; sort work lists; max bucket; M — in ONE launch.
-// Tiles of 2048 users are claimed by ticket (so a block only ever waits for tiles that are already running,
+// Tiles of 256 * UPT users are claimed by ticket (so a block only ever waits for tiles that are already running,
 // whatever the dispatch order); a tile publishes its sum as one 8-byte {flag, value} granule with an agent-scope
 // store and reads its predecessors' granules with agent-scope loads (no fence needed for a single granule:
 // /opt/skills/guides/cdna_hip_programming.md Guideline 16, form R2).  The last block to finish copies the
 // summary to mapped host memory (seq last, system scope): the host spins on it instead of paying a D2H copy
 // node plus an event wait.  Every block also zeroes its slice of the OTHER slot's histogram span, so the next
 // scan needs no memset.
+//   UPT    users per thread.  8: few, large tiles (any number of users).  1: one user per thread, used with ORDER.
+//   BLOCK  threads per block.  Every block costs two same-address atomics (ticket, done), which serialise at ~11 ns
+//          each; the largest bucket travels inside the tile granules instead of through an atomicMax.
+//   ORDER  also do K4's job for buckets of <= kTinyMax rows, from the direct bucket slots: the thread that owns user u
+//          loads and orders the bucket in registers while the tile sums of its predecessors arrive, and writes
+//          out_idx[offsets[u] ...] as soon as the offset is known.  For a sparse query the whole tail of the scan is
+//          this one kernel.  (The host picks it when the user table has direct slots and few enough tiles for the
+//          all-predecessors look-back.)
 constexpr unsigned long long kTileReady = 1ull << 62;
 
-__global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts, int n_users,
+template <int NS>
+__device__ __forceinline__ void order_bucket_regs(int n, const BktRec* __restrict__ src, int (&res)[NS])
+{
+    long long ks[NS];
+    int ki[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        BktRec r;
+        r.start = INT64_MAX;
+        r.idx = INT32_MAX;
+        if (k < n) r = src[k];
+        ks[k] = r.start;
+        ki[k] = r.idx;
+    }
+#pragma unroll
+    for (int k = 2; k <= NS; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool lt = key_less(ks[l], ki[l], ks[i], ki[i]);
+                    const bool sw = up ? lt : !lt;
+                    const long long s0 = sw ? ks[l] : ks[i], s1 = sw ? ks[i] : ks[l];
+                    const int i0 = sw ? ki[l] : ki[i], i1 = sw ? ki[i] : ki[l];
+                    ks[i] = s0; ks[l] = s1; ki[i] = i0; ki[l] = i1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) res[k] = ki[k];
+}
+
+template <int UPT, bool ORDER, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ counts, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
                                                  Segment* __restrict__ seg_list, Segment* __restrict__ small_list,
                                                  int* __restrict__ big_list,
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
-                                                 unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16)
+                                                 unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
+                                                 const BktRec* __restrict__ direct, BktRec* __restrict__ bkt,
+                                                 int* __restrict__ out_idx)
 {
-    __shared__ long long lds4[4];
-    __shared__ long long wsum[4];
+    static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
+    static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
+    constexpr int kTileUsers = BLOCK * UPT;
+    constexpr int kWaves = BLOCK / kWave;
+    __shared__ long long ldsw[kWaves];
+    __shared__ long long wsum[kWaves];
+    __shared__ unsigned int wmax[kWaves];
+    __shared__ unsigned int wpred[kWaves];
     __shared__ unsigned int tile_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (zero_span) {
         const int4 z = make_int4(0, 0, 0, 0);
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_vec16; i += (long long)gridDim.x * 256) zero_span[i] = z;
+        for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < zero_vec16; i += (long long)gridDim.x * BLOCK) zero_span[i] = z;
     }
     if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
     const int tile = (int)tile_s;
 
-    const int u0 = tile * kScanTile + threadIdx.x * 8;
-    int c[8];
+    const int u0 = tile * kTileUsers + threadIdx.x * UPT;
+    int c[UPT];
     long long tsum = 0;
-    if (u0 + 8 <= n_users) {
-        const int4 a = *reinterpret_cast<const int4*>(counts + u0);
-        const int4 b = *reinterpret_cast<const int4*>(counts + u0 + 4);
-        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    if constexpr (UPT == 8) {
+        if (u0 + 8 <= n_users) {
+            const int4 a = *reinterpret_cast<const int4*>(counts + u0);
+            const int4 b = *reinterpret_cast<const int4*>(counts + u0 + 4);
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
+        }
     } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
+        c[0] = u0 < n_users ? counts[u0] : 0;
     }
+    unsigned int local_max = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tsum += c[k];
+    for (int k = 0; k < UPT; ++k) {
+        tsum += c[k];
+        local_max = max(local_max, (unsigned)c[k]);
+    }
     const long long incl = wave_incl_scan(tsum, lane);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local_max = max(local_max, (unsigned)__shfl_xor((int)local_max, o, kWave));
     if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wmax[wave] = local_max;
     __syncthreads();
-    const long long tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    long long tile_total = 0;
+    unsigned int tile_max = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        tile_total += wsum[w];
+        tile_max = max(tile_max, wmax[w]);
+    }
+    // the granule carries the tile's sum (bits 0..30) and its largest bucket (bits 31..61): both are < 2^31
     if (threadIdx.x == 0)
-        __hip_atomic_store(&tile_pub[tile], kTileReady | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tile_pub[tile], kTileReady | ((unsigned long long)tile_max << 31) | (unsigned long long)tile_total,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ORDER: this thread's bucket, ordered in registers while the predecessors' sums arrive.  Buckets of 2..8 rows go
+    // through one 8-slot network (all lanes together); the rare 9..16-row bucket would drag its whole wave through the
+    // 16-slot network, so those are ranked cooperatively after the offsets are known (below).
+    int res[8];
+    if constexpr (ORDER) {
+        const int n = c[0];
+        const BktRec* src = direct + (long long)u0 * kTinyMax;
+        if (n == 1) res[0] = src[0].idx;
+        else if (n >= 2 && n <= 8) order_bucket_regs<8>(n, src, res);
+    }
+
     // base = sum of the tiles in front of this one
     long long part = 0;
-    for (int t = threadIdx.x; t < tile; t += 256) {
+    unsigned int pred_max = 0;
+    for (int t = threadIdx.x; t < tile; t += BLOCK) {
         unsigned long long v;
         do {
             v = __hip_atomic_load(&tile_pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(v & kTileReady)) __builtin_amdgcn_s_sleep(1);
         } while (!(v & kTileReady));
-        part += (long long)(v & (kTileReady - 1));
+        part += (long long)(v & 0x7FFFFFFFull);
+        pred_max = max(pred_max, (unsigned)((v >> 31) & 0x7FFFFFFFull));
     }
-    const long long base = block_sum_256(part, lds4);
+    // block-wide sum of `part`, block-wide max of `pred_max`
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        part += __shfl_xor(part, o, kWave);
+        pred_max = max(pred_max, (unsigned)__shfl_xor((int)pred_max, o, kWave));
+    }
+    if (lane == 0) { ldsw[wave] = part; wpred[wave] = pred_max; }
+    __syncthreads();
+    long long base = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        base += ldsw[w];
+        pred_max = max(pred_max, wpred[w]);
+    }
 
     long long run = base + incl - tsum;
     for (int w = 0; w < wave; ++w) run += wsum[w];
-    unsigned int local_max = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < UPT; ++k) {
         const int u = u0 + k;
         if (u < n_users) {
             offsets[u] = run;
             const int n = c[k];
-            local_max = max(local_max, (unsigned)n);
+            if constexpr (ORDER) {
+                if (n >= 1 && n <= 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i < n) out_idx[run + i] = res[i];
+                }
+            }
             if (n > kTinyMax) {
+                if constexpr (ORDER) {
+                    // the bucket outgrew its direct slots: its first kTinyMax records join the staged ones in bkt
+#pragma unroll
+                    for (int i = 0; i < kTinyMax; ++i) bkt[run + i] = direct[(long long)u * kTinyMax + i];
+                }
                 if (n <= kSmallMax) {
                     const unsigned slot = atomicAdd(&summary->n_small, 1u);
                     Segment sg;
@@ -1169,13 +1300,35 @@ __global__ __launch_bounds__(256) void k_offsets(const int* __restrict__ counts,
             run += n;
         }
     }
-    if (u0 + 8 >= n_users && u0 < n_users) { // thread holding the last user
+    if constexpr (ORDER) {
+        // buckets of 9..16 rows, one at a time with the whole wave: lane i < n holds record i and counts the records that
+        // sort before it; that count is its place.  (`run` was advanced past this thread's bucket above: UPT == 1.)
+        const int n_mine = c[0];
+        unsigned long long todo = __ballot(u0 < n_users && n_mine > 8 && n_mine <= kTinyMax);
+        while (todo) {
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int nb = __shfl(n_mine, src_lane, kWave);
+            const int ub = __shfl(u0, src_lane, kWave);
+            const long long ob = __shfl(run, src_lane, kWave) - nb;
+            BktRec r;
+            r.start = INT64_MAX;
+            r.idx = INT32_MAX;
+            if (lane < nb) r = direct[(long long)ub * kTinyMax + lane];
+            int before = 0;
+            for (int j = 0; j < nb; ++j) {
+                const long long sj = __shfl(r.start, j, kWave);
+                const int ij = __shfl(r.idx, j, kWave);
+                before += key_less(sj, ij, r.start, r.idx) ? 1 : 0;
+            }
+            if (lane < nb) out_idx[ob + before] = r.idx;
+        }
+    }
+    if (u0 + UPT >= n_users && u0 < n_users) { // thread holding the last user: it sits in the last tile, which has seen every granule
         offsets[n_users] = run;
         __hip_atomic_store(&summary->m, (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&summary->max_count, max(pred_max, tile_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) local_max = max(local_max, (unsigned)__shfl_xor((int)local_max, o, kWave));
-    if (lane == 0 && local_max > 0) atomicMax(&summary->max_count, local_max);
 
     // completion: the last block hands the summary to the host.  Every field was written by device-scope atomics
     // (or the agent-scope store above), each writer's operations are complete before its block's `done` increment
@@ -1244,8 +1397,7 @@ __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel,
 // Register sorting network (bitonic, fully unrolled so every index is a compile-time constant): NS slots,
 // the first n hold the bucket, the rest are +inf padding.
 template <int NS>
-__device__ __forceinline__ void sort_bucket_regs(long long o, int n, const BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx)
+__device__ __forceinline__ void sort_bucket_regs(int n, const BktRec* __restrict__ src, int* __restrict__ dst)
 {
     long long ks[NS];
     int ki[NS];
@@ -1255,7 +1407,7 @@ __device__ __forceinline__ void sort_bucket_regs(long long o, int n, const BktRe
         BktRec r;
         r.start = INT64_MAX;
         r.idx = INT32_MAX;
-        if (in) r = bkt[o + k];
+        if (in) r = src[k];
         ks[k] = r.start;
         ki[k] = r.idx;
     }
@@ -1279,29 +1431,41 @@ __device__ __forceinline__ void sort_bucket_regs(long long o, int n, const BktRe
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-        if (k < n) out_idx[o + k] = ki[k];
+        if (k < n) dst[k] = ki[k];
 }
 
 // K4a: one thread per bucket of <= kTinyMax (16) rows: every load issued at once, sorting network in
 // registers (8 slots for the common case, 16 otherwise).  Keys (start, idx) are unique.
+// With direct slots the bucket is read from direct[u * kTinyMax ...] (src) and written to out_idx[offsets[u] ...]; a
+// bucket that outgrew the slots has its first kTinyMax records copied behind offsets[u] in bkt, where K3 puts the rest.
 __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                 const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+                                                 BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
+                                                 int* __restrict__ out_idx)
 {
     const int n = counts[u];
-    if (n == 0 || n > kTinyMax) return;
+    if (n == 0) return;
     const long long o = offsets[u];
-    if (n == 1) { out_idx[o] = bkt[o].idx; return; }
-    if (n <= 8) sort_bucket_regs<8>(o, n, bkt, out_idx);
-    else sort_bucket_regs<16>(o, n, bkt, out_idx);
+    if (n > kTinyMax) {
+        if (direct) {
+#pragma unroll
+            for (int k = 0; k < kTinyMax; ++k) bkt[o + k] = direct[(long long)u * kTinyMax + k];
+        }
+        return;
+    }
+    const BktRec* src = direct ? direct + (long long)u * kTinyMax : bkt + o;
+    if (n == 1) { out_idx[o] = src[0].idx; return; }
+    if (n <= 8) sort_bucket_regs<8>(n, src, out_idx + o);
+    else sort_bucket_regs<16>(n, src, out_idx + o);
 }
 
 // K4b: one block per segment (<= kSegMax rows): bitonic sort of (start, idx) in LDS.
 // K4 (tiny buckets): one thread per user, buckets of <= 16 rows sorted in registers.
 __global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                   int n_users, const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+                                                   int n_users, BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
+                                                   int* __restrict__ out_idx)
 {
     const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, out_idx);
+    if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, direct, out_idx);
 }
 
 // K4 (segments): buckets of 513..4096 rows, and the 4096-row tiles of bigger buckets: one 1024-thread block each,

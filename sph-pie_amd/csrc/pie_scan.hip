@@ -41,6 +41,7 @@ struct ScanEvents {
 };
 
 constexpr int kEventRing = 2048;
+constexpr size_t kDirectMaxBytes = (size_t)2 << 30; // direct bucket slots (256 B per user) are carried up to 8 M users
 
 // everything one scan owns
 struct Slot {
@@ -56,6 +57,7 @@ struct Slot {
     int* sel_rank = nullptr;
     int* blk_count = nullptr;
     BktRec* bkt = nullptr;
+    BktRec* direct = nullptr;      // kTinyMax direct bucket slots per user (nullptr: user table too large, staged route only)
     int* out_idx = nullptr;
     Segment* seg_list = nullptr;
     Segment* small_list = nullptr;
@@ -101,6 +103,8 @@ struct pie_ctx {
     bool key_poor = false;      // a keyed scan found too many ambiguous rows and a rebuild would not help: use the `end` column
     bool key_rebuild = false;   // ... and a rebuild may help: done at the next pie_scan_begin with nothing in flight
     bool keyed_enabled = true;  // PIE_K1_KEYED=0 turns the keyed form off
+    int order_block = 512;       // threads (= users) per block of the fused K2 + order kernel (PIE_ORDER_BLOCK: 256 / 512 / 1024)
+    bool no_fused_order = false; // PIE_FUSED_ORDER=0: K2 and the tiny-bucket order as two kernels (A/B runs)
     int k1_keyed = 0x485;       // keyed liveness-first form (bit 0x400), unroll 8
     long long* d_range = nullptr;
 
@@ -186,7 +190,7 @@ void free_slots(pie_ctx* c)
         s.counts = nullptr; s.sum = nullptr;
         s.tile_pub = nullptr; s.ctl = nullptr;
         dfree(s.offsets); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
-        dfree(s.bkt); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
+        dfree(s.bkt); dfree(s.direct); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
         s.in_flight = s.have_result = false;
     }
     for (char*& sp : c->span) dfree(sp);
@@ -242,7 +246,7 @@ void plan_k1(pie_ctx* c)
 
 // layout of a slot's span (all parts 128-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
 size_t span_counts_bytes(const pie_ctx* c) { return (((size_t)c->cap_users * 4 + 127) / 128) * 128; }
-size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / kScanTile + 2) * 8 + 127) / 128) * 128; }
+size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / 256 + 2) * 8 + 127) / 128) * 128; } // sized for the smallest tile shape
 size_t span_parts_bytes() { return (size_t)kPartMax * 4; }
 size_t span_stats_bytes() { return (size_t)kSummaryBytes + (size_t)kStatSlots * sizeof(StatSlot); } // Summary (padded) + the K1 row-statistics slots
 size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128 + span_stats_bytes(); }
@@ -300,6 +304,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
             PIE_HIP(c, hipMalloc(&s.bkt, rows * sizeof(BktRec)));
+            if ((size_t)users * kTinyMax * sizeof(BktRec) <= kDirectMaxBytes) PIE_HIP(c, hipMalloc(&s.direct, (size_t)users * kTinyMax * sizeof(BktRec)));
             PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
             PIE_HIP(c, hipMalloc(&s.seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
             PIE_HIP(c, hipMalloc(&s.small_list, ((size_t)users + 16) * sizeof(Segment)));
@@ -421,38 +426,39 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
 #define PIE_K1(UN, NT, LU)                                                                                          \
     hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                       sl.sel_rank, sl.blk_count, sl.sum)
+                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
 #define PIE_K1L(UN, NT)                                                                                             \
     if (sl.variant & 0x40)                                                                                          \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                            c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                           sl.sel_rank, sl.blk_count, sl.sum);                                                      \
+                           sl.sel_rank, sl.blk_count, sl.sum, sl.direct);                                           \
     else                                                                                                            \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                       sl.sel_rank, sl.blk_count, sl.sum)
+                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
     if (sl.variant & 0x400) { // keyed liveness-first form
-#define PIE_K1K(UN)                                                                                                  \
-    if (sl.variant & 0x40)                                                                                          \
-        hipLaunchKernelGGL((k_scan_keyed<UN, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,         \
+#define PIE_K1K(UN, AG, NT)                                                                                          \
+        hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,      \
                            c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask, c->n_users,            \
-                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum);                                    \
-    else                                                                                                            \
-        hipLaunchKernelGGL((k_scan_keyed<UN, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,        \
-                           c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask, c->n_users,            \
-                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum)
+                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
+#define PIE_K1K2(UN)                                                                                                 \
+        do {                                                                                                        \
+            if (sl.variant & 0x40) { if (sl.variant & 1) PIE_K1K(UN, true, true); else PIE_K1K(UN, true, false); }   \
+            else { if (sl.variant & 1) PIE_K1K(UN, false, true); else PIE_K1K(UN, false, false); }                   \
+        } while (0)
         switch (sl.variant & 0xA0) {
-        case 0x20: PIE_K1K(2); break;
-        case 0x80: PIE_K1K(8); break;
-        default: PIE_K1K(4); break;
+        case 0x20: PIE_K1K2(2); break;
+        case 0x80: PIE_K1K2(8); break;
+        default: PIE_K1K2(4); break;
         }
+#undef PIE_K1K2
 #undef PIE_K1K
         return;
     }
     if (sl.variant == 0x101) { // group-qualified form, used only by pie_archive_queue
         hipLaunchKernelGGL((k_scan_compact<4, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
                            c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
-                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, c->d_qual);
+                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct, c->d_qual);
         return;
     }
     switch (sl.variant & ~0x40) {
@@ -480,7 +486,40 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
 #undef PIE_K1L
 }
 
-// Head of a scan: K1 and K2 on the stream.  No host wait.
+// per-bucket order of the buckets of <= kTinyMax rows; with direct slots it depends on K2 only (not on K3, not on the
+// host), so it is queued right behind K2
+void launch_sort_tiny(pie_ctx* c, Slot& sl, hipStream_t s)
+{
+    const int tiny_blocks = (c->n_users + 255) / 256;
+    hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, s, sl.counts, sl.offsets, c->n_users, sl.bkt, sl.direct, sl.out_idx);
+}
+
+// K2 (+ the order of the tiny buckets).  Three shapes: fused (one user per thread; offsets and tiny-bucket order in one
+// kernel) when buckets have direct slots and the tile count suits the all-predecessors look-back; otherwise the
+// 2048-user tiles, followed by the tiny-bucket kernel right away (direct slots) or after K3 (staged route).
+constexpr int kOrderMaxTiles = 2048; // fused form: few enough tiles for the all-predecessors look-back
+void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long zero_vec16)
+{
+    const int ob = c->order_block;
+    const int order_tiles = (c->n_users + ob - 1) / ob;
+    if (sl.direct && order_tiles <= kOrderMaxTiles && !c->no_fused_order) {
+#define PIE_K2O(B)                                                                                                          \
+    hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,   \
+                       sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16, \
+                       sl.direct, sl.bkt, sl.out_idx)
+        if (ob == 256) PIE_K2O(256);
+        else if (ob == 512) PIE_K2O(512);
+        else PIE_K2O(1024);
+#undef PIE_K2O
+        return;
+    }
+    hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,
+                       sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16,
+                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr);
+    if (sl.direct) launch_sort_tiny(c, sl, s);
+}
+
+// Head of a scan: K1 and K2 on the stream (plus the tiny-bucket order kernel when buckets have direct slots).  No host wait.
 int scan_begin(pie_ctx* c, long long now, long long cutoff)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
@@ -575,8 +614,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e0, s));
     launch_k1(c, sl, s, now, cutoff, mask);
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e1, s));
-    hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl, sl.offsets,
-                       sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, (long long)(counts_span(c) / 16));
+    launch_k2(c, sl, s, zero_span, (long long)(counts_span(c) / 16));
     PIE_HIP(c, hipGetLastError());
     sl.in_flight = true;
     c->n_flight++;
@@ -630,8 +668,7 @@ int scan_finish(pie_ctx* c)
             (void)had_events;
             sl.seq = ++c->seq_counter;
             launch_k1(c, sl, a, sl.q_now, sl.q_cutoff, mask);
-            hipLaunchKernelGGL(k_offsets, dim3(c->n_tiles), dim3(256), 0, a, sl.counts, c->n_users, sl.tile_pub, sl.ctl, sl.offsets,
-                               sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, (int4*)nullptr, 0LL);
+            launch_k2(c, sl, a, (int4*)nullptr, 0LL);
             PIE_HIP(c, hipGetLastError());
             PIE_HIP(c, hipStreamSynchronize(a));
             sl.last = sl.h_sum->s;
@@ -658,13 +695,17 @@ int scan_finish(pie_ctx* c)
         c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
     }
 
+    // Without direct slots every record was staged: scatter, then order the tiny buckets.  With them only buckets that
+    // outgrew kTinyMax rows have staged records (and exactly then K2 listed work for the kernels below).
+    const bool staged = sl.direct ? (sl.last.n_small + sl.last.n_seg > 0) : (sl.last.m > 0);
     if (sl.last.m > 0) {
-        int scat_blocks = sl.k1_blocks;
-        if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
-        hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
-                           sl.rows_per_block, sl.offsets, sl.bkt);
-        const int tiny_blocks = (c->n_users + 255) / 256;
-        hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, a, sl.counts, sl.offsets, c->n_users, sl.bkt, sl.out_idx);
+        if (staged) {
+            int scat_blocks = sl.k1_blocks;
+            if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
+            hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
+                               sl.rows_per_block, sl.offsets, sl.bkt);
+        }
+        if (!sl.direct) launch_sort_tiny(c, sl, a);
         if (sl.last.n_seg > 0) {
             const unsigned seg_blocks = sl.last.n_seg < (unsigned)(c->n_cus * 3) ? sl.last.n_seg : (unsigned)(c->n_cus * 3);
             hipLaunchKernelGGL(k_sort_segments, dim3(seg_blocks), dim3(1024), 0, a, sl.seg_list, sl.sum, sl.bkt, sl.out_idx);
@@ -802,6 +843,8 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_K1_VARIANT")) { c->k1_variant = (int)strtol(v, nullptr, 0); c->k1_pinned = true; }
     if (const char* v = getenv("PIE_K1_LIVE_FIRST")) c->k1_live_first = (int)strtol(v, nullptr, 0);
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
+    if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
+    if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);
         c->keyed_enabled = k != 0;

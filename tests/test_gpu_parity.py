@@ -104,7 +104,7 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
 
 
 @pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
-                                     0x405, 0x425, 0x485, 0x4C5])
+                                     0x405, 0x425, 0x484, 0x485, 0x4C5])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
     through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
@@ -185,6 +185,21 @@ def test_partitioned_path_parity(pie, oracle, monkeypatch):
                 assert_same(ctx.scan(now, INT64_MIN), want)
                 engaged += ctx.stats()["k1_variant"] == 0x285
     assert engaged >= 8
+
+
+def test_bucket_routes_by_user_table_size(pie, oracle):
+    """Three routes to the per-user buckets, chosen by the size of the user table: fused offsets + order kernel over the
+    direct bucket slots (<= 524 288 users), direct slots with separate kernels (up to 8 M users), staged records + scatter
+    (beyond).  Sparse and dense queries (buckets of 0..16 rows and of hundreds) give the oracle's bytes on each."""
+    n = 1 << 20
+    with pie.PieScan(0) as ctx:
+        for U in (1, 300, 100000, 524288, 524289, 9000000):
+            flags = 1 if U > 1000 else 0
+            s, e, u, d = oracle.gen(SEED + U, n, 0, n, U, 32, flags)
+            ctx.load_columns(s, e, u, d, U)
+            ctx.set_disciplines(ALL, 32)
+            for now in (oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 50 * DAY, INT64_MIN):
+                assert_same(ctx.scan(now, INT64_MIN), oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF))
 
 
 def test_two_scans_in_flight(pie, oracle):
