@@ -527,14 +527,42 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
 // 2 B/row instead of 8 B/row; correctness never depends on how well base/shift fit the data (a bad fit only makes more
 // rows ambiguous, which the scan reports in Summary::amb so the host can rebuild the column).
 // Every writer of `end` (k_set_end, the tombstoning list kernels, load / append / generate) keeps the key in step.
+//
+// A second, finer-grained key covers only the top of the range: the liveness-first forms are chosen when fewer than a
+// tenth of the rows are live, i.e. when `now` lies above the 90th percentile of `end`, so a 7-bit key in a uint8 whose
+// base sits at that percentile (found from a histogram of the 15-bit keys) separates every such query with 1 B/row.
+// Same key function, same exactness argument, other constants; queries below its base use the 15-bit key.
 typedef unsigned short lkey_t;
+typedef unsigned char fkey_t;
 constexpr unsigned kKeyMax = 32767u;
+constexpr unsigned kFineKeyMax = 127u;
+constexpr int kKeyHistBins = 4096; // histogram of (15-bit key >> 3)
 
-__device__ __forceinline__ unsigned key_of(long long e, long long base, int shift)
+__device__ __forceinline__ unsigned key_of(long long e, long long base, int shift, unsigned kmax = kKeyMax)
 {
     if (e < base) return 0u;
     const unsigned long long k = ((unsigned long long)e - (unsigned long long)base) >> shift;
-    return k >= (unsigned long long)(kKeyMax - 1u) ? kKeyMax : (unsigned)k + 1u;
+    return k >= (unsigned long long)(kmax - 1u) ? kmax : (unsigned)k + 1u;
+}
+
+// histogram of the 15-bit keys of rows [0, n), 8 keys per bin, privatised in LDS
+__global__ __launch_bounds__(1024) void k_key_hist(const lkey_t* __restrict__ key, long long n, unsigned int* __restrict__ hist)
+{
+    __shared__ unsigned int h[kKeyHistBins];
+    for (int i = threadIdx.x; i < kKeyHistBins; i += 1024) h[i] = 0;
+    __syncthreads();
+    for (long long r = (long long)blockIdx.x * 1024 + threadIdx.x; r < n; r += (long long)gridDim.x * 1024) atomicAdd(&h[key[r] >> 3], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kKeyHistBins; i += 1024)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// fine keys of rows [row0, n)
+__global__ __launch_bounds__(256) void k_build_fine_key(const long long* __restrict__ end, long long row0, long long n, long long base,
+                                                        int shift, fkey_t* __restrict__ fkey)
+{
+    for (long long r = row0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x)
+        fkey[r] = (fkey_t)key_of(end[r], base, shift, kFineKeyMax);
 }
 
 // smallest and largest `end` of the rows that are not tombstoned (range[0] = INT64_MAX, range[1] = INT64_MIN going in)
@@ -589,11 +617,13 @@ __global__ __launch_bounds__(256) void k_build_key(const long long* __restrict__
 // (key >= key(now)) with a SWAR compare, and from there on works like k_scan_live_first: candidates queue up in a
 // per-wave LDS ring and are evaluated 64 at a time — `end` only for the ambiguous ones, and one 16-byte record of the
 // payload column (start, user, disc) per candidate.  Output identical to the other forms.
-constexpr int kKeyRowsPerLoad = 8 * kWave; // 512 rows per wave per 16-byte load
+// KT = lkey_t: the 15-bit key, 8 rows per 16-byte load; KT = fkey_t: the 7-bit top-of-range key, 16 rows per load.
+constexpr int kKeyRowsPerLoad = 8 * kWave;      // 512 rows per wave per 16-byte load (2-byte keys)
+constexpr int kFineKeyRowsPerLoad = 16 * kWave; // 1024 rows (1-byte keys)
 
-template <int UNROLL, bool AGG, bool NT>
+template <int UNROLL, bool AGG, bool NT, class KT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
-    const PayRec* __restrict__ pay, const long long* __restrict__ end, const lkey_t* __restrict__ key, long long n,
+    const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
     BktRec* __restrict__ direct)
@@ -604,7 +634,9 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     __shared__ int blk_cursor;
     __shared__ int blk_live;
     __shared__ int blk_amb;
-    constexpr int kTile = kKeyRowsPerLoad * UNROLL;
+    constexpr int kPerLane = 16 / (int)sizeof(KT); // rows per lane per 16-byte load
+    constexpr int kRowsPerLoad = kPerLane * kWave;
+    constexpr int kTile = kRowsPerLoad * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; }
@@ -677,33 +709,49 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
         return true;
     };
 
-    // SWAR: keys are < 2^15, so with bit 15 of each half forced on, subtracting key(now) from both halves at once never
-    // borrows across them, and bit 15 of a half survives exactly when that key >= key(now)
-    const unsigned nk2 = now_key | (now_key << 16);
+    // SWAR: keys are < 2^15 (< 2^7), so with the top bit of each half (byte) forced on, subtracting key(now) from all of
+    // them at once never borrows across, and the top bit of a half (byte) survives exactly when that key >= key(now)
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
+    const unsigned nkr = sizeof(KT) == 2 ? (now_key | (now_key << 16)) : now_key * 0x01010101u;
     for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
         if (t + kTile <= c1) {
             u4_t kv[UNROLL];
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j)
-                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(key + t + j * kKeyRowsPerLoad + 8 * lane));
+                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(key + t + j * kRowsPerLoad + kPerLane * lane));
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) {
-                const int r0 = (int)(t + j * kKeyRowsPerLoad + 8 * lane);
-                const unsigned g0 = ((kv[j].x | 0x80008000u) - nk2) & 0x80008000u, g1 = ((kv[j].y | 0x80008000u) - nk2) & 0x80008000u;
-                const unsigned g2 = ((kv[j].z | 0x80008000u) - nk2) & 0x80008000u, g3 = ((kv[j].w | 0x80008000u) - nk2) & 0x80008000u;
-                // rows 0..3 keep their flags at bits 15/31/47/63, rows 4..7 move to bits 7/23/39/55
-                unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
-                                       (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
-                for (;;) {
-                    const bool has = m != 0;
-                    const int pbit = __ffsll((long long)m) - 1;         // meaningless when !has
-                    const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);   // row within the lane's eight
-                    const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
-                    const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
-                    const int entry = (r0 + q) | (kq == now_key ? (int)0x80000000 : 0);
-                    if (!push(has, entry)) break;
-                    m &= m - 1;
+                const int r0 = (int)(t + j * kRowsPerLoad + kPerLane * lane);
+                const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
+                const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
+                if constexpr (sizeof(KT) == 2) {
+                    // rows 0..3 keep their flags at bits 15/31/47/63, rows 4..7 move to bits 7/23/39/55
+                    unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
+                                           (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
+                    for (;;) {
+                        const bool has = m != 0;
+                        const int pbit = __ffsll((long long)m) - 1;         // meaningless when !has
+                        const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);   // row within the lane's eight
+                        const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
+                        const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
+                        const int entry = (r0 + q) | (kq == now_key ? (int)0x80000000 : 0);
+                        if (!push(has, entry)) break;
+                        m &= m - 1;
+                    }
+                } else {
+                    // byte b of word w is row 4w + b; its flag moves to bit 8b + w
+                    unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
+                    for (;;) {
+                        const bool has = m != 0;
+                        const int pbit = __ffs((int)m) - 1;
+                        const int w = pbit & 7, b = pbit >> 3;
+                        const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
+                        const unsigned kq = (word >> (8 * b)) & 0xFFu;
+                        const int entry = (r0 + 4 * w + b) | (kq == now_key ? (int)0x80000000 : 0);
+                        if (!push(has, entry)) break;
+                        m &= m - 1;
+                    }
                 }
             }
         } else {
@@ -1666,12 +1714,14 @@ __global__ __launch_bounds__(256) void k_pack_results(const long long* __restric
 
 __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, const int* __restrict__ rows,
                                                  const long long* __restrict__ new_end, long long k, long long n,
-                                                 lkey_t* __restrict__ key, long long key_base, int key_shift)
+                                                 lkey_t* __restrict__ key, long long key_base, int key_shift,
+                                                 fkey_t* __restrict__ fkey, long long fkey_base, int fkey_shift)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < k && (unsigned)rows[t] < (unsigned long long)n) {
         end[rows[t]] = new_end[t];
-        key[rows[t]] = (lkey_t)key_of(new_end[t], key_base, key_shift);
+        if (key) key[rows[t]] = (lkey_t)key_of(new_end[t], key_base, key_shift);
+        if (fkey) fkey[rows[t]] = (fkey_t)key_of(new_end[t], fkey_base, fkey_shift, kFineKeyMax);
     }
 }
 
@@ -1796,7 +1846,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end, const int* __restrict__ user, long long n,
                                                     long long rows_per_block, long long a, long long b,
                                                     const long long* __restrict__ blk_off, int* __restrict__ queue, long long cap,
-                                                    lkey_t* __restrict__ key)
+                                                    lkey_t* __restrict__ key, fkey_t* __restrict__ fkey)
 {
     __shared__ int wcount[4];
     __shared__ long long carry_s;
@@ -1816,7 +1866,11 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
         const long long pos = base + prefix_in_ballot(bal);
         if (hit && pos < cap) queue[pos] = (int)r;
         if constexpr (MODE != 0) {
-            if (hit) { end[r] = INT64_MIN; key[r] = 0; } // a tombstone's liveness key is 0 under every base
+            if (hit) { // a tombstone's liveness keys are 0 under every base
+                end[r] = INT64_MIN;
+                if (key) key[r] = 0;
+                if (fkey) fkey[r] = 0;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];

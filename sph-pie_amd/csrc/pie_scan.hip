@@ -96,6 +96,11 @@ struct pie_ctx {
     // derived liveness-key column (see pie_kernels.h): 2 B/row, kept in step with d_end by every writer
     lkey_t* d_key = nullptr;
     PayRec* d_pay = nullptr;    // derived payload column (start, user, disc) per row: immutable after a row is written
+    fkey_t* d_fkey = nullptr;   // 7-bit key of the top of the `end` range (1 B/row), see pie_kernels.h
+    long long fkey_base = 0;
+    int fkey_shift = 0;
+    bool fkey_poor = false;     // a fine-keyed scan found too many ambiguous rows: use the 15-bit key
+    unsigned int* d_hist = nullptr;
     long long key_base = 0;
     int key_shift = 0;
     bool key_ok = false;        // d_key covers rows [0, n) under (key_base, key_shift)
@@ -105,16 +110,16 @@ struct pie_ctx {
     bool keyed_enabled = true;  // PIE_K1_KEYED=0 turns the keyed form off
     int order_block = 512;       // threads (= users) per block of the fused K2 + order kernel (PIE_ORDER_BLOCK: 256 / 512 / 1024)
     bool no_fused_order = false; // PIE_FUSED_ORDER=0: K2 and the tiny-bucket order as two kernels (A/B runs)
-    int k1_keyed = 0x485;       // keyed liveness-first form (bit 0x400), unroll 8
+    int k1_keyed = 0xC85;       // keyed liveness-first form (bit 0x400; 0x800: the 1-byte fine key where the query allows), unroll 8
     long long* d_range = nullptr;
 
     // predicate table
     unsigned long long disc_mask = ~0ull;
     int n_disc = 64;
 
-    // scan plans: [0] streaming form, [1] liveness-first form, [2] keyed liveness-first form
-    int plan_blocks[3] = {0, 0, 0};
-    long long plan_rows[3] = {0, 0, 0};
+    // scan plans: [0] streaming form, [1] liveness-first form, [2] keyed liveness-first form, [3] the same on the 1-byte key
+    int plan_blocks[4] = {0, 0, 0, 0};
+    long long plan_rows[4] = {0, 0, 0, 0};
     int n_tiles = 0;
     int k1_variant = 0x03;    // streaming form: nontemporal loads + late user materialisation
     int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
@@ -202,7 +207,7 @@ void free_slots(pie_ctx* c)
 
 void free_table(pie_ctx* c)
 {
-    dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay);
+    dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
     c->key_ok = false;
     dfree(c->d_blk_off);
     free_slots(c);
@@ -226,7 +231,8 @@ void plan_one(pie_ctx* c, int which, long long want, const char* env)
         if (v > 0) want = v;
     }
     // a whole number of wave-tiles for every unroll (the keyed form reads 512 rows per wave per load)
-    const long long kBlockTileRows = which == 2 ? (long long)kKeyRowsPerLoad * 8 * kK1Waves : (long long)kUnitRows * 8 * kK1Waves;
+    const long long kBlockTileRows = which == 3 ? (long long)kFineKeyRowsPerLoad * 8 * kK1Waves
+                                     : which == 2 ? (long long)kKeyRowsPerLoad * 8 * kK1Waves : (long long)kUnitRows * 8 * kK1Waves;
     long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
     if (tiles < 1) tiles = 1;
     if (want > tiles) want = tiles;
@@ -242,6 +248,7 @@ void plan_k1(pie_ctx* c)
     plan_one(c, 0, (long long)c->n_cus * 48, "PIE_K1_BLOCKS");
     plan_one(c, 1, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_LIVE");
     plan_one(c, 2, (long long)c->n_cus * 32, "PIE_K1_BLOCKS_KEYED");
+    plan_one(c, 3, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_FINE");
 }
 
 // layout of a slot's span (all parts 128-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
@@ -279,12 +286,14 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         PIE_HIP(c, hipMalloc(&c->d_end, rows * 8));
         PIE_HIP(c, hipMalloc(&c->d_user, rows * 4));
         PIE_HIP(c, hipMalloc(&c->d_disc, rows * 4));
-        // derived columns, rebuilt by build_keys after every (re)allocation; a table too large to carry them (18 B/row)
+        // derived columns, rebuilt by build_keys after every (re)allocation; a table too large to carry them (19 B/row)
         // simply runs without the keyed form
-        if (hipMalloc(&c->d_key, rows * sizeof(lkey_t) + 64) != hipSuccess || hipMalloc(&c->d_pay, rows * sizeof(PayRec)) != hipSuccess) {
+        if (hipMalloc(&c->d_key, rows * sizeof(lkey_t) + 64) != hipSuccess || hipMalloc(&c->d_pay, rows * sizeof(PayRec)) != hipSuccess ||
+            hipMalloc(&c->d_fkey, rows * sizeof(fkey_t) + 64) != hipSuccess) {
             (void)hipGetLastError();
             dfree(c->d_key);
             dfree(c->d_pay);
+            dfree(c->d_fkey);
         }
         if (keep_rows > 0 && old_s) {
             PIE_HIP(c, hipMemcpyAsync(c->d_start, old_s, keep_rows * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -355,7 +364,7 @@ int validate_users(pie_ctx* c, long long row0 = 0)
 // (out-of-range values clamp; the column stays exact, only less selective).
 int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
 {
-    if (!c->d_key || !c->d_pay) { c->key_ok = false; return PIE_OK; }
+    if (!c->d_key || !c->d_pay || !c->d_fkey) { c->key_ok = false; return PIE_OK; }
     const bool write_pay = !(rebuild && c->key_ok); // a refit of the key leaves the (immutable) payload alone
     if (c->n == 0) { c->key_ok = true; c->key_base = 0; c->key_shift = 0; c->key_dirty = false; return PIE_OK; }
     hipStream_t s = c->stream;
@@ -385,6 +394,35 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     hipLaunchKernelGGL(k_build_key, dim3(grid), dim3(256), 0, s, c->d_end, row0, c->n, c->key_base, c->key_shift, c->d_key,
                        c->d_start, c->d_user, c->d_disc, write_pay ? c->d_pay : (PayRec*)nullptr);
     PIE_HIP(c, hipGetLastError());
+    if (row0 == 0) {
+        // fine key: base = lower edge of the histogram bin that holds the 90th percentile of the 15-bit keys (tombstones
+        // and rows below the base count as key 0), shift = smallest that keeps the largest `end` under the clamp
+        std::vector<unsigned int> hist(kKeyHistBins);
+        PIE_HIP(c, hipMemsetAsync(c->d_hist, 0, kKeyHistBins * sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_key_hist, dim3(c->n_cus), dim3(1024), 0, s, c->d_key, c->n, c->d_hist);
+        PIE_HIP(c, hipGetLastError());
+        PIE_HIP(c, hipMemcpyAsync(hist.data(), c->d_hist, kKeyHistBins * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+        unsigned long long cum = 0;
+        int bin = 0, top_bin = 0;
+        for (int b = 0; b < kKeyHistBins; ++b)
+            if (hist[b]) top_bin = b;
+        const unsigned long long want = (unsigned long long)((double)c->n * 0.9);
+        for (bin = 0; bin < kKeyHistBins - 1; ++bin) {
+            if (cum + hist[bin] > want) break;
+            cum += hist[bin];
+        }
+        if (bin > top_bin) bin = top_bin;
+        // key k >= 1 covers [base + ((k-1) << shift), base + (k << shift)); bin b holds keys 8b .. 8b+7
+        c->fkey_base = bin == 0 ? c->key_base : (long long)((unsigned long long)c->key_base + (((unsigned long long)bin * 8ull - 1ull) << c->key_shift));
+        const unsigned long long top_edge = (unsigned long long)c->key_base + (((unsigned long long)top_bin * 8ull + 8ull) << c->key_shift);
+        const unsigned long long fspan = top_edge - (unsigned long long)c->fkey_base;
+        c->fkey_shift = 0;
+        while (c->fkey_shift < 63 && (fspan >> c->fkey_shift) >= (unsigned long long)(kFineKeyMax - 1u)) c->fkey_shift++;
+        c->fkey_poor = false;
+    }
+    hipLaunchKernelGGL(k_build_fine_key, dim3(grid), dim3(256), 0, s, c->d_end, row0, c->n, c->fkey_base, c->fkey_shift, c->d_fkey);
+    PIE_HIP(c, hipGetLastError());
     c->key_ok = true;
     return PIE_OK;
 }
@@ -394,6 +432,13 @@ unsigned host_key_of(const pie_ctx* c, long long e)
     if (e < c->key_base) return 0u;
     const unsigned long long k = ((unsigned long long)e - (unsigned long long)c->key_base) >> c->key_shift;
     return k >= (unsigned long long)(kKeyMax - 1u) ? kKeyMax : (unsigned)k + 1u;
+}
+
+unsigned host_fine_key_of(const pie_ctx* c, long long e)
+{
+    if (e < c->fkey_base) return 0u;
+    const unsigned long long k = ((unsigned long long)e - (unsigned long long)c->fkey_base) >> c->fkey_shift;
+    return k >= (unsigned long long)(kFineKeyMax - 1u) ? kFineKeyMax : (unsigned)k + 1u;
 }
 
 int resolve_events(pie_ctx* c)
@@ -438,9 +483,16 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
                        sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
     if (sl.variant & 0x400) { // keyed liveness-first form
 #define PIE_K1K(UN, AG, NT)                                                                                          \
-        hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, c->d_end,      \
-                           c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask, c->n_users,            \
-                           sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
+        do {                                                                                                        \
+            if (sl.variant & 0x800)                                                                                 \
+                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay,  \
+                                   c->d_end, c->d_fkey, c->n, sl.rows_per_block, now, host_fine_key_of(c, now), cutoff, mask, \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay,  \
+                                   c->d_end, c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask,       \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
+        } while (0)
 #define PIE_K1K2(UN)                                                                                                 \
         do {                                                                                                        \
             if (sl.variant & 0x40) { if (sl.variant & 1) PIE_K1K(UN, true, true); else PIE_K1K(UN, true, false); }   \
@@ -553,12 +605,16 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     else if (!c->k1_pinned && c->live_frac >= 0) {
         sl.variant = c->live_frac < kLiveFirstBelow ? c->k1_live_first : c->k1_variant;
         // few candidates: stream the 2-byte liveness key instead of the 8-byte `end` column
-        if ((sl.variant & 4) && c->keyed_enabled && c->key_ok && !c->key_poor) sl.variant = c->k1_keyed;
+        if ((sl.variant & 4) && c->keyed_enabled && c->key_ok && !c->key_poor) {
+            sl.variant = c->k1_keyed & ~0x800;
+            // queries above the fine key's base (every query that few rows survive) stream 1 B/row instead of 2
+            if ((c->k1_keyed & 0x800) && !c->fkey_poor && now >= c->fkey_base) sl.variant |= 0x800;
+        }
     }
     if ((sl.variant & 0x400) && !c->key_ok) sl.variant = c->k1_live_first; // pinned keyed form without a key column
     // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
     if (!c->k1_pinned && !c->d_qual && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
-    const int plan = (sl.variant & 0x400) ? 2 : (sl.variant & 4) ? 1 : 0;
+    const int plan = (sl.variant & 0x800) ? 3 : (sl.variant & 0x400) ? 2 : (sl.variant & 4) ? 1 : 0;
     sl.k1_blocks = c->plan_blocks[plan];
     sl.rows_per_block = c->plan_rows[plan];
     sl.have_result = false;
@@ -687,6 +743,7 @@ int scan_finish(pie_ctx* c)
     if ((sl.variant & 0x400) && sl.last.amb > 4096 && sl.last.amb > (unsigned long long)c->n / 64) {
         // the key column separated this query badly (e.g. `now` beyond the range it was built for)
         if (c->key_dirty) c->key_rebuild = true;
+        else if (sl.variant & 0x800) c->fkey_poor = true;
         else c->key_poor = true;
     }
     if (!c->d_qual) {
@@ -775,7 +832,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
-                       c->d_blk_off, sl.out_idx, c->cap_rows, c->d_key);
+                       c->d_blk_off, sl.out_idx, c->cap_rows, c->d_key, c->d_fkey);
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
     PIE_HIP(c, hipStreamSynchronize(s));
@@ -828,6 +885,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     bool ok = (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) == hipSuccess &&
               (e = hipMalloc(&c->d_summary, sizeof(Summary))) == hipSuccess &&
               (e = hipMalloc(&c->d_range, 16)) == hipSuccess &&
+              (e = hipMalloc(&c->d_hist, kKeyHistBins * sizeof(unsigned int))) == hipSuccess &&
               (e = hipHostMalloc(&c->h_summary, sizeof(Summary), hipHostMallocDefault)) == hipSuccess;
     for (Slot& s : c->slot) {
         ok = ok && (e = hipHostMalloc(&s.h_sum, sizeof(HostSummary), hipHostMallocMapped)) == hipSuccess &&
@@ -868,6 +926,7 @@ int pie_ctx_destroy(pie_ctx* c)
     }
     if (c->d_summary) (void)hipFree(c->d_summary);
     if (c->d_range) (void)hipFree(c->d_range);
+    if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->h_summary) (void)hipHostFree(c->h_summary);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1099,7 +1158,7 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     (void)hipMemcpyAsync(d_rows, rows, k * 4, hipMemcpyHostToDevice, c->stream);
     (void)hipMemcpyAsync(d_new, new_end, k * 8, hipMemcpyHostToDevice, c->stream);
     hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end, d_rows, d_new,
-                       (long long)k, c->n, c->d_key, c->key_base, c->key_shift);
+                       (long long)k, c->n, c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift);
     c->key_dirty = true;
     e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_rows);

@@ -104,7 +104,7 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
 
 
 @pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
-                                     0x405, 0x425, 0x484, 0x485, 0x4C5])
+                                     0x405, 0x425, 0x484, 0x485, 0x4C5, 0xC05, 0xC85, 0xCC5])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
     through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
@@ -134,9 +134,9 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         st = ctx.stats()
         assert st["k1_variant"] == 0x03 and abs(st["live"] / n - 18 / (120 * 24)) < 2e-3
         assert_same(ctx.scan(now, cutoff), want_spec)
-        assert ctx.stats()["k1_variant"] == 0x485              # keyed liveness-first: streams the 2-byte key column
-        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # still liveness-first (decided from the last scan) ...
-        assert ctx.stats()["k1_variant"] == 0x485 and ctx.stats()["live"] == n
+        assert ctx.stats()["k1_variant"] == 0xC85              # keyed liveness-first: streams the 1-byte top-of-range key
+        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # still liveness-first (decided from the last scan), on the
+        assert ctx.stats()["k1_variant"] == 0x485 and ctx.stats()["live"] == n   # 2-byte key: `now` is below the fine key's base
         assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and back to streaming once everything is live
         assert ctx.stats()["k1_variant"] == 0x03
 
@@ -294,7 +294,7 @@ def test_zipf_corpus_parity(pie, gpu_ctx, oracle):
     want = oracle.scan(*want_cols, U, now, cutoff, 0xFFFFFFFF)
     for _ in range(3):
         assert_same(gpu_ctx.scan(now, cutoff), want)
-    assert gpu_ctx.stats()["k1_variant"] == 0x4C5
+    assert gpu_ctx.stats()["k1_variant"] == 0xCC5
 
 
 def test_skewed_users_big_buckets(gpu_ctx, oracle):
@@ -360,12 +360,13 @@ def test_append_rows_equals_bulk_load(gpu_ctx, oracle):
     assert_same(got, want)
 
 
-def test_liveness_key_follows_every_writer_of_end(pie, oracle, monkeypatch):
-    """The keyed table pass reads a derived 2-byte column instead of `end`; every call that changes `end` must keep it in
-    step.  With the keyed form pinned: touch (dead -> live, live -> dead, values far outside the range the key was built
+@pytest.mark.parametrize("form", [0x485, 0xC85])
+def test_liveness_key_follows_every_writer_of_end(pie, oracle, monkeypatch, form):
+    """The keyed table pass reads a derived 2-byte (or, for the top of the range, 1-byte) column instead of `end`; every
+    call that changes `end` must keep both in step.  With a keyed form pinned: touch (dead -> live, live -> dead, values far outside the range the key was built
     for), tombstones from delete_user / prune_before / retention_purge, appends below, inside and beyond the key range —
     after each the scan equals the oracle on the mirrored columns, at query times inside, below and above the range."""
-    monkeypatch.setenv("PIE_K1_VARIANT", "0x485")
+    monkeypatch.setenv("PIE_K1_VARIANT", hex(form))
     rng = np.random.default_rng(2024)
     n, U, D = 300007, 700, 32
     s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 1)
@@ -376,7 +377,7 @@ def test_liveness_key_follows_every_writer_of_end(pie, oracle, monkeypatch):
     def check(ctx):
         for now in nows:
             assert_same(ctx.scan(now, INT64_MIN), oracle.scan(s, e, u, d, ctx.n_users, now, INT64_MIN, 0xFFFFFFFF))
-            assert ctx.stats()["k1_variant"] == 0x485
+            assert ctx.stats()["k1_variant"] == form
 
     with pie.PieScan(0) as ctx:
         ctx.load_columns(s, e, u, d, U)
@@ -430,7 +431,7 @@ def test_liveness_key_refit_and_fallback(pie, oracle):
         for _ in range(3):
             assert_same(ctx.scan(now, INT64_MIN), want)
         st = ctx.stats()
-        assert st["k1_variant"] == 0x485 and st["key_ambiguous"] < 200
+        assert st["k1_variant"] == 0xC85 and st["key_ambiguous"] < 1000
         # one appended row doubles the table's capacity (and re-derives the key while it is at it) ...
         ctx.append_rows(s[:1], e[:1], u[:1], d[:1], U)
         s, e, u, d = np.concatenate([s, s[:1]]), np.concatenate([e, e[:1]]), np.concatenate([u, u[:1]]), np.concatenate([d, d[:1]])
@@ -448,17 +449,17 @@ def test_liveness_key_refit_and_fallback(pie, oracle):
             assert_same(ctx.scan(now, INT64_MIN), want)
             st = ctx.stats()
             seen.append((st["k1_variant"], st["key_ambiguous"]))
-        assert seen[1][0] == 0x485 and seen[1][1] > 250000      # every appended row sat on the clamp key
-        assert seen[3][0] == 0x485 and seen[3][1] < 2000        # rebuilt: selective again
+        assert seen[1][0] == 0xC85 and seen[1][1] > 250000      # every appended row sat on the clamp key
+        assert seen[3][0] == 0xC85 and seen[3][1] < 2000        # rebuilt: selective again
         # all ends equal: no key can separate a query at that instant
         e3 = np.full(n, oracle.T0_MS, np.int64)
         ctx.load_columns(s[:n], e3, u[:n], d[:n], U)
         want = oracle.scan(s[:n], e3, u[:n], d[:n], U, oracle.T0_MS, INT64_MIN, 0xFFFFFFFF)
         forms = []
-        for _ in range(4):
+        for _ in range(5):
             assert_same(ctx.scan(oracle.T0_MS, INT64_MIN), want)
             forms.append(ctx.stats()["k1_variant"])
-        assert want[2].size == 0 and forms[1] == 0x485 and forms[2] == 0x85 and forms[3] == 0x85
+        assert want[2].size == 0 and forms[1:] == [0xC85, 0x485, 0x85, 0x85]   # 1-byte key, 2-byte key, then the column itself
 
 
 def test_prune_before_is_the_window_complement(gpu_ctx, oracle):
