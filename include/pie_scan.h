@@ -137,6 +137,14 @@ int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
  * (and the rare big-bucket merge passes) and returns M.  Results of a finished scan end at the next begin. */
 int pie_scan_begin(pie_ctx *ctx, int64_t now, int64_t cutoff);
 int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
+/* The same pair for the exchange step of a sharded table: the scan also produces its result message
+ * [ off[0..u_pad] | M | rows[0..min(M, idx_cap)) ] (int32 words, the layout of pie_pack_results_device) in caller-owned
+ * device memory dst_i32 (u_pad + 2 + idx_cap words, which must stay valid until the matching finish).
+ * pie_scan_finish_packed: *ready_out = 1 when the message was complete in device memory before the call returned (the
+ * scan's own kernels wrote it: a consumer on any stream, or a peer GPU, may read it at once); 0 when a pack kernel was
+ * enqueued on the context's stream to write it (order the consumer after that stream, e.g. with an event). */
+int pie_scan_begin_packed(pie_ctx *ctx, int64_t now, int64_t cutoff, void *dst_i32, size_t u_pad, size_t idx_cap);
+int pie_scan_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                      size_t *m_out);

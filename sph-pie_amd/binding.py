@@ -58,6 +58,8 @@ _SIGS = [
     ("pie_scan_device", C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]),
     ("pie_scan_begin", C.c_int, [_P, C.c_int64, C.c_int64]),
     ("pie_scan_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    ("pie_scan_begin_packed", C.c_int, [_P, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t]),
+    ("pie_scan_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_copy_results_device", C.c_int, [_P, _P, _P, _P, C.c_size_t]),
@@ -116,6 +118,7 @@ class PieScan:
             raise PieError(rc, text)
         self.n = 0
         self.n_users = 0
+        self._begun = []   # scans begun and not finished, oldest first: True = begun with scan_begin_packed
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -237,11 +240,32 @@ class PieScan:
 
     def scan_begin(self, now, cutoff):
         self._check(self._lib.pie_scan_begin(self._ctx, int(now), int(cutoff)))
+        self._begun.append(False)
 
     def scan_finish(self):
         m = C.c_size_t(0)
+        if self._begun:
+            self._begun.pop(0)
         self._check(self._lib.pie_scan_finish(self._ctx, C.byref(m)))
         return m.value
+
+    def scan_begin_packed(self, now, cutoff, dst_ptr, u_pad, idx_cap):
+        """scan_begin whose scan also writes its result message (layout of pack_results_device) into dst_ptr."""
+        self._check(self._lib.pie_scan_begin_packed(self._ctx, int(now), int(cutoff), dst_ptr, int(u_pad), int(idx_cap)))
+        self._begun.append(True)
+
+    def in_flight_packed(self):
+        """True when the oldest scan in flight was begun with scan_begin_packed."""
+        return bool(self._begun) and self._begun[0]
+
+    def scan_finish_packed(self):
+        """-> (M, ready): ready = the message was complete in device memory on return (no stream ordering needed);
+        otherwise a pack kernel was enqueued on the context's stream."""
+        m, ready = C.c_size_t(0), C.c_int(0)
+        if self._begun:
+            self._begun.pop(0)
+        self._check(self._lib.pie_scan_finish_packed(self._ctx, C.byref(m), C.byref(ready)))
+        return int(m.value), bool(ready.value)
 
     def scan_pipelined(self, k, now, cutoff):
         """k scans of the same query with two in flight: the table pass of scan i+1 overlaps the tail (scatter,

@@ -621,7 +621,11 @@ __global__ __launch_bounds__(256) void k_build_key(const long long* __restrict__
 constexpr int kKeyRowsPerLoad = 8 * kWave;      // 512 rows per wave per 16-byte load (2-byte keys)
 constexpr int kFineKeyRowsPerLoad = 16 * kWave; // 1024 rows (1-byte keys)
 
-template <int UNROLL, bool AGG, bool NT, class KT>
+// PIPE: the evaluation of a batch of 64 candidates is split into three steps that run one batch apart — (A) take the batch
+// off the ring and issue its gathers, (B) one batch later, evaluate the predicate and issue the histogram atomics,
+// (C) one batch later again, take the returned ranks and emit — so neither the gather's nor the atomic's round trip
+// stalls the wave: the key stream keeps flowing in between.
+template <int UNROLL, bool AGG, bool NT, class KT, bool PIPE>
 __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
@@ -656,26 +660,39 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     int lhead = 0, lfill = 0, nlive = 0, namb = 0; // wave-uniform
 
     // evaluate `cnt` queued candidates (cnt <= 64), one per lane; bit 31 of a ring entry marks an ambiguous key
-    auto drain = [&](int cnt) {
-        bool p = false, live = false, amb = false;
+    // step A state (gathers in flight), step B state (atomics in flight); all "have" flags are wave-uniform
+    bool a_have = false, a_valid = false, a_amb = false;
+    int a_row = 0;
+    PayRec a_pay;
+    a_pay.start = 0; a_pay.user = 0; a_pay.disc = 0;
+    long long a_end = 0;
+    bool b_have = false, b_p = false;
+    long long b_sv = 0;
+    int b_row = 0, b_uv = -1, b_base = 0, b_leader = 0, b_prefix = 0;
+
+    auto step_c = [&]() { // ranks are back: emit
+        if (!b_have) return;
+        const int base = __shfl(b_base, b_leader, kWave);
+        emit_row(b_p, b_sv, b_row, b_uv, base + b_prefix, direct, st, out, out_rank, &blk_cursor, lane);
+        b_have = false;
+    };
+    auto step_b = [&]() { // gathers are back: predicate, histogram atomics
+        if (!a_have) return;
+        bool p = false, live = false;
         long long sv = 0;
-        int row = 0, uv = -1, rk = 0;
-        if (lane < cnt) {
-            const int ent = lring[(lhead + lane) & (kLiveRing - 1)];
-            row = ent & 0x7FFFFFFF;
-            amb = ent < 0;
-            const PayRec pr = pay[row]; // issued before the (rare) `end` compare resolves: one gather per candidate
-            live = amb ? (end[row] > now) : true;
-            sv = pr.start;
-            const int dv = pr.disc;
+        int uv = -1;
+        if (a_valid) {
+            live = a_amb ? (a_end > now) : true;
+            sv = a_pay.start;
+            const int dv = a_pay.disc;
             p = live & (sv >= cutoff) & ((unsigned)dv < 64u) & (((mask >> (dv & 63)) & 1ull) != 0);
             if (p) {
-                uv = pr.user;
+                uv = a_pay.user;
                 if ((unsigned)uv >= (unsigned)n_users) { atomicAdd(&summary->bad_rows, 1u); p = false; }
             }
         }
         nlive += __popcll(__ballot(live));
-        namb += __popcll(__ballot(amb));
+        namb += __popcll(__ballot(a_valid && a_amb));
         // wave-aggregated histogram atomics for skewed users (see k_scan_live_first)
         int grp_leader = lane, grp_prefix = 0, grp_size = 1;
         unsigned long long todo = AGG ? __ballot(p) : 0ull;
@@ -692,11 +709,40 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
         }
         int base = 0;
         if (p && grp_leader == lane) base = atomicAdd(&counts[uv], grp_size);
-        base = __shfl(base, grp_leader, kWave);
-        rk = base + grp_prefix;
+        b_have = true;
+        b_p = p;
+        b_sv = sv;
+        b_row = a_row;
+        b_uv = uv;
+        b_base = base;
+        b_leader = grp_leader;
+        b_prefix = grp_prefix;
+        a_have = false;
+    };
+    auto step_a = [&](int cnt) { // take the batch off the ring, issue its gathers
+        a_valid = lane < cnt;
+        a_amb = false;
+        if (a_valid) {
+            const int ent = lring[(lhead + lane) & (kLiveRing - 1)];
+            a_row = ent & 0x7FFFFFFF;
+            a_amb = ent < 0;
+            a_pay = pay[a_row]; // one gather per candidate
+            if (a_amb) a_end = end[a_row];
+        }
+        a_have = true;
         lhead = (lhead + cnt) & (kLiveRing - 1);
         lfill -= cnt;
-        emit_row(p, sv, row, uv, rk, direct, st, out, out_rank, &blk_cursor, lane);
+    };
+    auto drain = [&](int cnt) {
+        if constexpr (PIPE) {
+            step_c();
+            step_b();
+            step_a(cnt);
+        } else {
+            step_a(cnt);
+            step_b();
+            step_c();
+        }
     };
     auto push = [&](bool cand, int entry) {
         const unsigned long long b = __ballot(cand);
@@ -764,6 +810,11 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
         }
     }
     if (lfill > 0) drain(lfill);
+    if constexpr (PIPE) { // run the last batches through the remaining steps
+        step_c();
+        step_b();
+        step_c();
+    }
     if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
     if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
     if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
@@ -1148,12 +1199,19 @@ __global__ __launch_bounds__(256) void k_block_prefix(const int* __restrict__ bl
 //   UPT    users per thread.  8: few, large tiles (any number of users).  1: one user per thread, used with ORDER.
 //   BLOCK  threads per block.  Every block costs two same-address atomics (ticket, done), which serialise at ~11 ns
 //          each; the largest bucket travels inside the tile granules instead of through an atomicMax.
+//   msg    (ORDER only, optional) the scan's result message [off[0..u_pad] | M | rows[0..cap)] as int32, written here as
+//          well, so that a scan whose buckets all fit the direct slots needs no pack kernel before the exchange.
 //   ORDER  also do K4's job for buckets of <= kTinyMax rows, from the direct bucket slots: the thread that owns user u
 //          loads and orders the bucket in registers while the tile sums of its predecessors arrive, and writes
 //          out_idx[offsets[u] ...] as soon as the offset is known.  For a sparse query the whole tail of the scan is
 //          this one kernel.  (The host picks it when the user table has direct slots and few enough tiles for the
 //          all-predecessors look-back.)
 constexpr unsigned long long kTileReady = 1ull << 62;
+
+// One word of the result message a scan writes for the exchange step (see k_pack_results for the layout).  The
+// consumer is another queue (or another GPU, over xGMI) that starts as soon as the host has seen the scan's summary, so
+// the words are written through to memory instead of waiting in this XCD's L2 for the end of the kernel.
+__device__ __forceinline__ void msg_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 template <int NS>
 __device__ __forceinline__ void order_bucket_regs(int n, const BktRec* __restrict__ src, int (&res)[NS])
@@ -1200,7 +1258,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
                                                  const BktRec* __restrict__ direct, BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx)
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
@@ -1211,6 +1269,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     __shared__ unsigned int wmax[kWaves];
     __shared__ unsigned int wpred[kWaves];
     __shared__ unsigned int tile_s;
+    __shared__ long long total_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (zero_span) {
         const int4 z = make_int4(0, 0, 0, 0);
@@ -1306,10 +1365,14 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             offsets[u] = run;
             const int n = c[k];
             if constexpr (ORDER) {
+                if (msg) msg_store(msg + u, (int)run);
                 if (n >= 1 && n <= 8) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (i < n) out_idx[run + i] = res[i];
+                        if (i < n) {
+                            out_idx[run + i] = res[i];
+                            if (msg && run + i < msg_cap) msg_store(msg + u_pad + 2 + run + i, res[i]);
+                        }
                 }
             }
             if (n > kTinyMax) {
@@ -1369,13 +1432,25 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                 const int ij = __shfl(r.idx, j, kWave);
                 before += key_less(sj, ij, r.start, r.idx) ? 1 : 0;
             }
-            if (lane < nb) out_idx[ob + before] = r.idx;
+            if (lane < nb) {
+                out_idx[ob + before] = r.idx;
+                if (msg && ob + before < msg_cap) msg_store(msg + u_pad + 2 + ob + before, r.idx);
+            }
         }
     }
     if (u0 + UPT >= n_users && u0 < n_users) { // thread holding the last user: it sits in the last tile, which has seen every granule
         offsets[n_users] = run;
         __hip_atomic_store(&summary->m, (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&summary->max_count, max(pred_max, tile_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total_s = run;
+    }
+    if constexpr (ORDER) {
+        // message tail, by the last tile: off[u] = M for the padding users n_users .. u_pad, then the M word
+        if (msg && tile == (int)gridDim.x - 1) {
+            __syncthreads();
+            const long long m_all = total_s;
+            for (int u = n_users + threadIdx.x; u <= u_pad + 1; u += BLOCK) msg_store(msg + u, (int)m_all);
+        }
     }
 
     // completion: the last block hands the summary to the host.  Every field was written by device-scope atomics

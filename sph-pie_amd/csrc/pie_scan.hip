@@ -58,6 +58,10 @@ struct Slot {
     int* blk_count = nullptr;
     BktRec* bkt = nullptr;
     BktRec* direct = nullptr;      // kTinyMax direct bucket slots per user (nullptr: user table too large, staged route only)
+    int* msg = nullptr;            // this scan's result message (caller-owned device memory), or nullptr
+    int msg_u_pad = 0;
+    long long msg_cap = 0;
+    bool msg_by_k2 = false;        // K2 wrote the message (fused route)
     int* out_idx = nullptr;
     Segment* seg_list = nullptr;
     Segment* small_list = nullptr;
@@ -482,16 +486,21 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
                        sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
     if (sl.variant & 0x400) { // keyed liveness-first form
-#define PIE_K1K(UN, AG, NT)                                                                                          \
+#define PIE_K1K3(UN, AG, NT, PP)                                                                                     \
         do {                                                                                                        \
             if (sl.variant & 0x800)                                                                                 \
-                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay,  \
+                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_fkey, c->n, sl.rows_per_block, now, host_fine_key_of(c, now), cutoff, mask, \
                                    c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
             else                                                                                                    \
-                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay,  \
+                hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask,       \
                                    c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
+        } while (0)
+#define PIE_K1K(UN, AG, NT)                                                                                          \
+        do {                                                                                                        \
+            if (sl.variant & 0x10) PIE_K1K3(UN, AG, NT, true);                                                       \
+            else PIE_K1K3(UN, AG, NT, false);                                                                        \
         } while (0)
 #define PIE_K1K2(UN)                                                                                                 \
         do {                                                                                                        \
@@ -504,6 +513,7 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
         default: PIE_K1K2(4); break;
         }
 #undef PIE_K1K2
+#undef PIE_K1K3
 #undef PIE_K1K
         return;
     }
@@ -558,21 +568,23 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
 #define PIE_K2O(B)                                                                                                          \
     hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,   \
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16, \
-                       sl.direct, sl.bkt, sl.out_idx)
+                       sl.direct, sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap)
         if (ob == 256) PIE_K2O(256);
         else if (ob == 512) PIE_K2O(512);
         else PIE_K2O(1024);
 #undef PIE_K2O
+        sl.msg_by_k2 = sl.msg != nullptr;
         return;
     }
     hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16,
-                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr);
+                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0LL);
+    sl.msg_by_k2 = false;
     if (sl.direct) launch_sort_tiny(c, sl, s);
 }
 
 // Head of a scan: K1 and K2 on the stream (plus the tiny-bucket order kernel when buckets have direct slots).  No host wait.
-int scan_begin(pie_ctx* c, long long now, long long cutoff)
+int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, int msg_u_pad = 0, long long msg_cap = 0)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n_flight >= 2) return fail(c, PIE_E_STATE, "two scans are already in flight: call pie_scan_finish first");
@@ -619,6 +631,10 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff)
     sl.rows_per_block = c->plan_rows[plan];
     sl.have_result = false;
     if (c->res == &sl) c->res = nullptr;
+    sl.msg = msg;
+    sl.msg_u_pad = msg_u_pad;
+    sl.msg_cap = msg_cap;
+    sl.msg_by_k2 = false;
 
     // this scan's histogram span (zeroed by the previous scan's K2, or by the load) and the one K2 will zero
     {
@@ -1229,6 +1245,34 @@ int pie_scan_finish(pie_ctx* c, size_t* m_out)
     int rc = scan_finish(c);
     if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
     return rc;
+}
+
+int pie_scan_begin_packed(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32, size_t u_pad, size_t idx_cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    return scan_begin(c, now, cutoff, (int*)dst_i32, (int)u_pad, (long long)idx_cap);
+}
+
+int pie_scan_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (ready_out) *ready_out = 0;
+    PIE_HIP(c, hipSetDevice(c->device));
+    Slot* slp = oldest_in_flight(c);
+    if (!slp) return fail(c, PIE_E_STATE, "pie_scan_finish_packed without pie_scan_begin_packed");
+    if (!slp->msg) return fail(c, PIE_E_STATE, "the oldest scan in flight was not begun with pie_scan_begin_packed");
+    int rc = scan_finish(c);
+    if (rc) return rc;
+    Slot& sl = *c->res;
+    if (m_out) *m_out = (size_t)sl.last.m;
+    // K2 wrote the whole message iff it ran the fused form and no bucket outgrew the direct slots
+    if (sl.msg_by_k2 && sl.last.n_small + sl.last.n_seg == 0) {
+        if (ready_out) *ready_out = 1;
+        return PIE_OK;
+    }
+    return pie_pack_results_device(c, sl.msg, (size_t)sl.msg_u_pad, (size_t)sl.msg_cap);
 }
 
 int pie_read_results(pie_ctx* c, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)

@@ -38,7 +38,9 @@ def partition_by_user_hash(start, end, user, disc, n_users, world):
 
 
 class HipShardBackend:
-    """Scans the local shard with the HIP library and packs the result message on this rank's GPU."""
+    """Scans the local shard with the HIP library; the scan itself writes the result message on this rank's GPU."""
+
+    direct_message = True   # scan_begin takes the message buffer; scan_finish_packed returns (M, ready)
 
     def __init__(self, ctx: PieScan, device):
         self.ctx = ctx
@@ -46,33 +48,58 @@ class HipShardBackend:
         # the scan runs on the library's own stream; it is wrapped here so torch events can be recorded on it
         self.result_stream = torch.cuda.ExternalStream(self.ctx.aux_stream(), device=self.device)
 
-    def scan_begin(self, now, cutoff):
-        """Enqueue the table pass + offsets kernel; returns immediately."""
-        self.ctx.scan_begin(now, cutoff)
+    def scan_begin(self, now, cutoff, dst=None, u_pad=0, cap=0):
+        """Enqueue the table pass + offsets kernel; returns immediately.  With dst (int32 device tensor of
+        u_pad + 2 + cap words) the scan writes its result message there as it goes."""
+        if dst is None:
+            self.ctx.scan_begin(now, cutoff)
+        else:
+            self.ctx.scan_begin_packed(now, cutoff, dst.data_ptr(), u_pad, cap)
 
     def scan_finish_packed(self, dst, u_pad, cap):
-        """Wait for the scan's summary, enqueue its tail, then write the message into dst (int32, device) with one
-        kernel launch.  -> M (host int)."""
+        """Wait for the oldest scan's summary.  -> (M, ready): ready = the message is already complete in device memory
+        (written by the scan's own kernels); otherwise a pack kernel was enqueued on result_stream to write it."""
+        if self.ctx.in_flight_packed():
+            return self.ctx.scan_finish_packed()
         m = self.ctx.scan_finish()
         self.ctx.pack_results_device(dst.data_ptr(), u_pad, cap)
-        return m
+        return m, False
+
+
+class _Buffers:
+    """Three message / gather buffers of one capacity; scan i of a pipelined run uses set i % 3."""
+
+    def __init__(self, world, u_pad, cap, device, cuda):
+        self.cap, self.u_pad = cap, u_pad
+        L = self.L = u_pad + 2 + cap
+        self.msg = [torch.zeros(L, dtype=torch.int32, device=device) for _ in range(3)]
+        self.out = [torch.zeros(world * L, dtype=torch.int32, device=device) for _ in range(3)]
+        self.len_host = [torch.zeros(world, dtype=torch.int32, pin_memory=cuda) for _ in range(3)]
+        # strided view of the M word of every rank's message, made once
+        self.len_dev = [o.view(world, L)[:, u_pad + 1] for o in self.out]
+        self.busy = [False, False, False]   # a gather that reads msg[p] / writes out[p] has been issued and not collected
+        if cuda:
+            self.ev_packed = [torch.cuda.Event() for _ in range(3)]
+            self.ev_done = [torch.cuda.Event() for _ in range(3)]
+            # the zero fills above ran on torch's stream; the scans write these buffers from the library's own stream
+            torch.cuda.current_stream(device).synchronize()
 
 
 class _Ticket:
-    __slots__ = ("parity", "m", "cap", "u_pad", "issued")
+    __slots__ = ("bufs", "parity", "m", "ready", "issued", "query")
 
 
 class ShardedFeeds:
     """Per-rank driver: scan the local shard, all-gather the packed messages.
 
-    `backend.scan_begin(now, cutoff)` / `backend.scan_finish_packed(dst, u_pad, cap) -> M` fill an int32 tensor on
-    `backend.device` (the GPU for nccl/RCCL, the CPU for gloo).  Pipeline stages:
-        begin            enqueue the scan (no host wait)
-        finish_and_pack  wait for its summary, enqueue tail + pack, mark the message ready          -> ticket
+    `backend.scan_begin(now, cutoff[, dst, u_pad, cap])` / `backend.scan_finish_packed(dst, u_pad, cap) -> M | (M, ready)`
+    fill an int32 tensor on `backend.device` (the GPU for nccl/RCCL, the CPU for gloo).  Pipeline stages:
+        begin            enqueue the scan (no host wait); the scan writes its message as it goes
+        finish_and_pack  wait for the oldest begun scan's summary                                    -> ticket
         exchange         issue the all-gather of that message on the side stream (GPU-async)
         collect          wait for the side stream only; hand out the gathered views
-    run_steps() interleaves them so that the host work of exchange(i) happens while the GPU scans step i+1.
-    Two message / result buffers alternate."""
+    run_steps() keeps two scans queued on the GPU while the host issues and collects gathers, so neither the host work
+    nor the gather sits between two table passes.  Three message / result buffer sets rotate."""
 
     def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
@@ -80,17 +107,16 @@ class ShardedFeeds:
         self.n_users_local = int(n_users_local)
         self.device = torch.device(getattr(backend, "device", "cpu"))
         self.cuda = self.device.type == "cuda"
+        self.direct = bool(getattr(backend, "direct_message", False))
         # offsets are padded to the largest shard's user count so the gather has one fixed size
         self.u_pad = self._all_max(self.n_users_local)
         self.cap = cap  # capacity of one rank's row list in the message; negotiated on first use
-        self.parity = 0
-        self.msg = self.out = None
+        self.bufs = None
+        self.step = 0       # scans begun so far: picks the buffer set
+        self.begun = []     # tickets of scans begun and not finished, oldest first
         if self.cuda:
             self.comm_stream = torch.cuda.Stream(self.device)
             self.rs = getattr(backend, "result_stream", None) or torch.cuda.current_stream(self.device)
-            self.ev_packed = [torch.cuda.Event(), torch.cuda.Event()]
-            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self.busy = [False, False]   # a gather that reads msg[p] / writes out[p] has been issued and not collected
 
     # ---- helpers
     def _all_max(self, value):
@@ -105,78 +131,90 @@ class ShardedFeeds:
         # it is detected by every rank from the gathered lengths and costs one collective re-negotiation
         return max(1024, int(need * 1.06) + 64)
 
-    def _alloc(self):
-        L = self.u_pad + 2 + self.cap
-        self.msg = [torch.zeros(L, dtype=torch.int32, device=self.device) for _ in range(2)]
-        self.out = [torch.zeros(self.world * L, dtype=torch.int32, device=self.device) for _ in range(2)]
-        self.len_host = [torch.zeros(self.world, dtype=torch.int32, pin_memory=self.cuda) for _ in range(2)]
-        # strided view of the M word of every rank's message, made once
-        self.len_dev = [o.view(self.world, L)[:, self.u_pad + 1] for o in self.out]
-        self.busy = [False, False]
+    def _buffers(self):
+        if self.bufs is None or self.bufs.cap != self.cap:
+            # scans begun earlier keep their own (old) set alive through their tickets
+            self.bufs = _Buffers(self.world, self.u_pad, self.cap, self.device, self.cuda)
+        return self.bufs
 
     # ---- pipeline stages
     def begin(self, now, cutoff):
-        self._query = (now, cutoff)
-        self.backend.scan_begin(now, cutoff)
+        t = _Ticket()
+        t.query, t.issued, t.m, t.ready = (now, cutoff), False, 0, False
+        if self.cap is None:
+            t.bufs, t.parity = None, 0          # first use: a probe scan learns M
+            self.backend.scan_begin(now, cutoff)
+        else:
+            t.bufs, t.parity = self._buffers(), self.step % 3
+            self.step += 1
+            if t.bufs.busy[t.parity]:
+                raise RuntimeError("collect() the ticket issued three steps ago before its buffers are used again")
+            if self.direct:
+                self.backend.scan_begin(now, cutoff, t.bufs.msg[t.parity], self.u_pad, t.bufs.cap)
+            else:
+                self.backend.scan_begin(now, cutoff)
+        self.begun.append(t)
+
+    def _finish(self, t, dst, cap):
+        r = self.backend.scan_finish_packed(dst, self.u_pad, cap)
+        return r if isinstance(r, tuple) else (r, False)
 
     def finish_and_pack(self):
-        if self.cap is None:
-            # first use: learn M, agree on a capacity, and redo this scan with real buffers
+        t = self.begun.pop(0)
+        if t.bufs is None:
+            # the probe: learn M, agree on a capacity, and redo this scan with real buffers
+            if self.begun:
+                raise RuntimeError("the first scan negotiates the message capacity: finish it before beginning another")
             probe = torch.zeros(self.u_pad + 2, dtype=torch.int32, device=self.device)
-            self.cap = self._grow(self._all_max(self.backend.scan_finish_packed(probe, self.u_pad, 0)))
-            self.backend.scan_begin(*self._query)
-        if self.msg is None or self.msg[0].numel() != self.u_pad + 2 + self.cap:
-            self._alloc()
-        p = self.parity
-        self.parity ^= 1
-        if self.busy[p]:
-            raise RuntimeError("collect() the ticket issued two steps ago before packing into its buffers again")
-        t = _Ticket()
-        t.parity, t.cap, t.u_pad, t.issued = p, self.cap, self.u_pad, False
-        t.m = self.backend.scan_finish_packed(self.msg[p], self.u_pad, self.cap)
-        if self.cuda:
-            self.ev_packed[p].record(self.rs)
+            m, _ = self._finish(t, probe, 0)
+            self.cap = self._grow(self._all_max(m))
+            self.begin(*t.query)
+            t = self.begun.pop(0)
+        p = t.parity
+        t.m, t.ready = self._finish(t, t.bufs.msg[p], t.bufs.cap)
+        if self.cuda and not t.ready:
+            t.bufs.ev_packed[p].record(self.rs)
         return t
 
     def exchange(self, t):
-        p = t.parity
+        b, p = t.bufs, t.parity
         t.issued = True
-        self.busy[p] = True
+        b.busy[p] = True
         if not self.collective:
-            self.out[p].copy_(self.msg[p])
+            b.out[p].copy_(b.msg[p])
             return
         if self.cuda:
             prev = torch.cuda.current_stream(self.device)
             torch.cuda.set_stream(self.comm_stream)
             try:
-                self.comm_stream.wait_event(self.ev_packed[p])
-                dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group)  # stream-ordered, host-async
-                self.len_host[p].copy_(self.len_dev[p], non_blocking=True)
-                self.ev_done[p].record(self.comm_stream)
+                if not t.ready:
+                    self.comm_stream.wait_event(b.ev_packed[p])
+                dist.all_gather_into_tensor(b.out[p], b.msg[p], group=self.group)  # stream-ordered, host-async
+                b.len_host[p].copy_(b.len_dev[p], non_blocking=True)
+                b.ev_done[p].record(self.comm_stream)
             finally:
                 torch.cuda.set_stream(prev)
         else:
-            dist.all_gather_into_tensor(self.out[p], self.msg[p], group=self.group)
+            dist.all_gather_into_tensor(b.out[p], b.msg[p], group=self.group)
 
     def collect(self, t):
         """-> dict(offsets [world, U_pad+1] int32, lengths [world], rows [world, cap] int32) or None when a rank's row
         list outgrew the message capacity (every rank sees the same lengths, so every rank gets None, the capacity has
         been raised, and the caller resubmits).  Feed(r, u) = rows[r, offsets[r,u] : offsets[r,u+1]]."""
-        p = t.parity
-        L = t.u_pad + 2 + t.cap
+        b, p = t.bufs, t.parity
         if self.cuda and self.collective:
-            self.ev_done[p].synchronize()   # waits for the side stream only, never for the scan stream
+            b.ev_done[p].synchronize()   # waits for the side stream only, never for the scan stream
         else:
             if self.cuda:
                 torch.cuda.current_stream(self.device).synchronize()
-            self.len_host[p].copy_(self.len_dev[p])
-        self.busy[p] = False
-        g = self.out[p].view(self.world, L)
-        need = int(self.len_host[p].max())
-        if need > t.cap:
+            b.len_host[p].copy_(b.len_dev[p])
+        b.busy[p] = False
+        g = b.out[p].view(self.world, b.L)
+        need = int(b.len_host[p].max())
+        if need > b.cap:
             self.cap = max(self.cap, self._grow(need))
             return None
-        return {"offsets": g[:, : t.u_pad + 1], "lengths": self.len_host[p].clone(), "rows": g[:, t.u_pad + 2:]}
+        return {"offsets": g[:, : b.u_pad + 1], "lengths": b.len_host[p].clone(), "rows": g[:, b.u_pad + 2:]}
 
     def submit(self, now, cutoff):
         """One whole step without overlap: scan, pack, issue the gather.  -> ticket for collect()."""
@@ -193,8 +231,9 @@ class ShardedFeeds:
                 return res
 
     def run_steps(self, k, now, cutoff):
-        """k steps of the same query, software-pipelined: while the GPU runs the table pass of step i+1 the host
-        issues the gather of step i, and collects it one step later.  Every gather is collected before returning.
+        """k steps of the same query, software-pipelined: scan i+1 is queued on the GPU before the host waits for scan i,
+        the gather of step i is issued while scan i+1 runs, and collected one step later.  Every scan begun is finished
+        and every gather collected before returning.
         -> last collected result (None if a message overflowed: the capacity has been raised, call again)."""
         last, flying = None, None
         if k <= 0:
@@ -205,15 +244,20 @@ class ShardedFeeds:
             if k == 0:
                 return last
         self.begin(now, cutoff)
+        overflow = False
         for i in range(k):
-            t = self.finish_and_pack()       # waits for scan i's summary, queues its tail + pack
-            if i + 1 < k:
-                self.begin(now, cutoff)      # the next table pass is queued right behind them ...
-            self.exchange(t)                 # ... and runs while the host issues this step's gather
-            if flying is not None:           # gather of step i-1: issued a whole table pass ago
+            if i + 1 < k and not overflow:
+                self.begin(now, cutoff)      # the next table pass is queued right behind this one
+            t = self.finish_and_pack()       # waits for scan i's summary; its message is (being) written
+            self.exchange(t)                 # gather of step i, on the side stream, while scan i+1 runs
+            if flying is not None:           # gather of step i-1: issued a whole scan ago
                 last = self.collect(flying)
+                overflow = overflow or last is None
             flying = t
-        return self.collect(flying)
+            if overflow and not self.begun:
+                break
+        last_flying = self.collect(flying)
+        return None if overflow or last_flying is None else last_flying
 
 
 def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device="cpu", group=None):

@@ -104,7 +104,7 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
 
 
 @pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
-                                     0x405, 0x425, 0x484, 0x485, 0x4C5, 0xC05, 0xC85, 0xCC5])
+                                     0x405, 0x425, 0x484, 0x485, 0x4C5, 0xC05, 0xC85, 0xCC5, 0x495, 0xC95, 0xCD5])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
     through PIE_K1_VARIANT gives the oracle's bytes, on ragged sizes, all-live and none-live tables."""
@@ -200,6 +200,52 @@ def test_bucket_routes_by_user_table_size(pie, oracle):
             ctx.set_disciplines(ALL, 32)
             for now in (oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 50 * DAY, INT64_MIN):
                 assert_same(ctx.scan(now, INT64_MIN), oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF))
+
+
+def test_scan_written_message_equals_the_pack_kernel(pie, oracle):
+    """Exchange step: pie_scan_begin_packed / pie_scan_finish_packed.  For a query whose buckets all fit the direct slots
+    the scan's own kernels write the message [off[0..u_pad] | M | rows[0..cap)] (ready = True, no pack kernel, no event);
+    otherwise the pack kernel is enqueued (ready = False).  Either way the words equal what pack_results_device writes
+    from the finished result, also with a row capacity below M and with padding users."""
+    import torch
+    n, U, D = 1 << 20, 60000, 32
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
+    dev = torch.device("cuda", 0)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        cases = [(oracle.T0_MS - 6 * 3600 * 1000, True), (oracle.T0_MS - 6 * 3600 * 1000, True),   # ~0.1 rows per user
+                 (oracle.T0_MS - 30 * DAY, True),                                                      # ~4 per user: buckets of 9..16 too
+                 (INT64_MIN, False)]                                                                   # ~17 per user: staged records
+        for now, want_ready in cases:
+            want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+            m = want[2].size
+            for u_pad, cap in [(U, m + 7), (U + 123, m), (U + 1, max(m // 2, 1))]:
+                msg = torch.full((u_pad + 2 + cap,), -7, dtype=torch.int32, device=dev)
+                ref = torch.full((u_pad + 2 + cap,), -7, dtype=torch.int32, device=dev)
+                ctx.scan_begin_packed(now, INT64_MIN, msg.data_ptr(), u_pad, cap)
+                got_m, ready = ctx.scan_finish_packed()
+                assert got_m == m and ready == want_ready
+                ctx.pack_results_device(ref.data_ptr(), u_pad, cap)
+                ctx.synchronize()
+                torch.cuda.synchronize()
+                a, b = msg.cpu().numpy(), ref.cpu().numpy()
+                k = min(m, cap)
+                assert np.array_equal(a[: u_pad + 2 + k], b[: u_pad + 2 + k])
+                assert np.array_equal(a[: U + 1], want[1].astype(np.int32)) and a[u_pad + 1] == m
+                assert np.array_equal(a[u_pad + 2: u_pad + 2 + k], want[2][:k])
+                assert np.all(a[u_pad + 2 + k:] == -7)          # nothing written past the capacity
+        # two in flight
+        now = oracle.T0_MS - 6 * 3600 * 1000
+        want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+        m = want[2].size
+        bufs = [torch.zeros(U + 2 + m, dtype=torch.int32, device=dev) for _ in range(3)]
+        ctx.scan_begin_packed(now, INT64_MIN, bufs[0].data_ptr(), U, m)
+        for i in range(1, 6):
+            ctx.scan_begin_packed(now, INT64_MIN, bufs[i % 3].data_ptr(), U, m)
+            assert ctx.scan_finish_packed() == (m, True)
+            assert np.array_equal(bufs[(i - 1) % 3].cpu().numpy()[U + 2:], want[2])
+        assert ctx.scan_finish_packed() == (m, True)
 
 
 def test_two_scans_in_flight(pie, oracle):
