@@ -204,7 +204,7 @@ def main():
         if variant & 0x400:
             kname = "k_scan_keyed"
         if args.mode == "expired":
-            kname = "k_expired_stage"
+            kname = "k_expired_stage" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed"
         traffic = None
         tpath = os.path.join(REPO, "profiles", "k1_traffic.json")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist) == \

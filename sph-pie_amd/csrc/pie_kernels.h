@@ -2039,6 +2039,83 @@ __global__ __launch_bounds__(kK1Threads) void k_expired_stage(const long long* _
     if (lane == 0) wave_count[blockIdx.x * kK1Waves + wave] = w0 < n ? fill : 0;
 }
 
+// The same stage on the 2-byte liveness key (pie_kernels.h, "liveness-key column"): with kp = key(prev_now) and
+// kn = key(now), a row with kp < key < kn is a hit without looking at `end` (key(end) > key(prev) => end > prev,
+// key(end) < key(now) => end < now), a row with key == kp or key == kn needs the full compare, every other row is a
+// miss.  2 B/row instead of 8 B/row; output identical (each lane holds eight consecutive rows, so lane order is row order).
+template <int UNROLL>
+__global__ __launch_bounds__(kK1Threads) void k_expired_stage_keyed(const lkey_t* __restrict__ key, const long long* __restrict__ end,
+                                                                    long long n, long long rows_per_block, long long prev_now,
+                                                                    long long now, unsigned kp, unsigned kn,
+                                                                    int* __restrict__ stage, int* __restrict__ wave_count)
+{
+    constexpr int kTile = kKeyRowsPerLoad * UNROLL;
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const long long rows_per_wave = rows_per_block / kK1Waves; // a multiple of kTile (block range is 4096-aligned, UNROLL <= 2)
+    const long long w0 = (long long)blockIdx.x * rows_per_block + (long long)wave * rows_per_wave;
+    long long w1 = w0 + rows_per_wave;
+    if (w1 > n) w1 = n;
+    int fill = 0; // wave-uniform
+    int* out = stage + w0;
+    const unsigned kp2 = kp | (kp << 16), kn2 = (kn | (kn << 16)) | 0x80008000u;
+    auto is_hit = [&](unsigned k, long long r) -> bool {
+        if (k > kp && k < kn) return true;
+        if (k != kp && k != kn) return false;
+        const long long ev = end[r];
+        return (ev <= now) & (ev > prev_now);
+    };
+    for (long long t = w0; t < w1; t += kTile) {
+        if (t + kTile <= w1) {
+            u4_t kv[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                kv[j] = stream_load<true>(reinterpret_cast<const u4_t*>(key + t + j * kKeyRowsPerLoad + 8 * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                // candidates: kp <= key <= kn, per 16-bit half (keys < 2^15: neither subtraction borrows across halves)
+                const unsigned w[4] = {kv[j].x, kv[j].y, kv[j].z, kv[j].w};
+                unsigned cand = 0; // bit q = row q of this lane's eight
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned g = ((w[i] | 0x80008000u) - kp2) & (kn2 - w[i]) & 0x80008000u;
+                    cand |= (((g >> 15) & 1u) | ((g >> 30) & 2u)) << (2 * i);
+                }
+                if (__ballot(cand != 0) == 0) continue;
+                const long long r0 = t + j * kKeyRowsPerLoad + 8 * lane;
+                unsigned hits = 0;
+                for (unsigned m = cand; m; m &= m - 1) {
+                    const int q = __ffs((int)m) - 1;
+                    const unsigned ww = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w); // no dynamic register indexing
+                    const unsigned k = (ww >> ((q & 1) * 16)) & 0xFFFFu;
+                    if (is_hit(k, r0 + q)) hits |= 1u << q;
+                }
+                // order-preserving placement: exclusive prefix of the per-lane hit counts
+                const int c = __popc(hits);
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int v = __shfl_up(incl, o, kWave);
+                    if (lane >= o) incl += v;
+                }
+                int pos = fill + incl - c;
+                for (unsigned m = hits; m; m &= m - 1) out[pos++] = (int)r0 + (__ffs((int)m) - 1);
+                fill += __shfl(incl, kWave - 1, kWave);
+            }
+        } else {
+            for (long long r0 = t; r0 < w1; r0 += kWave) {
+                const long long r = r0 + lane;
+                const bool h = r < w1 && is_hit(key[r], r);
+                const unsigned long long b = __ballot(h);
+                if (h) out[fill + prefix_in_ballot(b)] = (int)r;
+                fill += __popcll(b);
+            }
+        }
+    }
+    if (lane == 0) wave_count[blockIdx.x * kK1Waves + wave] = w0 < n ? fill : 0;
+}
+
 __global__ __launch_bounds__(256) void k_expired_gather(const int* __restrict__ stage, const int* __restrict__ wave_count,
                                                         const long long* __restrict__ wave_off, int n_waves,
                                                         long long rows_per_wave, int* __restrict__ queue, long long cap)

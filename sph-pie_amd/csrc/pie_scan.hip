@@ -1410,8 +1410,12 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
         c->ring.push_back(e);
     }
     if (prof) PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e0, s));
-    hipLaunchKernelGGL(k_expired_stage<8>, dim3(blocks), dim3(kK1Threads), 0, s, c->d_end, c->n, rpb, (long long)prev_now,
-                       (long long)now, st.out_idx, q.blk_count);
+    if (c->key_ok && c->keyed_enabled && !getenv("PIE_EXPIRED_ON_END"))
+        hipLaunchKernelGGL(k_expired_stage_keyed<2>, dim3(blocks), dim3(kK1Threads), 0, s, c->d_key, c->d_end, c->n, rpb,
+                           (long long)prev_now, (long long)now, host_key_of(c, prev_now), host_key_of(c, now), st.out_idx, q.blk_count);
+    else
+        hipLaunchKernelGGL(k_expired_stage<8>, dim3(blocks), dim3(kK1Threads), 0, s, c->d_end, c->n, rpb, (long long)prev_now,
+                           (long long)now, st.out_idx, q.blk_count);
     if (prof) PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e1, s));
     hipLaunchKernelGGL(k_block_prefix_wide, dim3(1), dim3(1024), 0, s, q.blk_count, n_waves, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_expired_gather, dim3(blocks < c->n_cus * 8 ? blocks : c->n_cus * 8), dim3(256), 0, s, st.out_idx,

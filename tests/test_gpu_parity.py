@@ -613,13 +613,34 @@ def test_column_files_round_trip(pie, gpu_ctx, oracle, tmp_path):
     assert gpu_ctx.n == 0
 
 
-def test_expired_queue_parity(gpu_ctx, oracle):
+@pytest.mark.parametrize("on_end", [False, True])
+def test_expired_queue_parity(gpu_ctx, oracle, monkeypatch, on_end):
+    """prev < end <= now -> ascending row list, on the 2-byte liveness key (rows strictly between the two keys need no
+    compare, rows on either boundary key do) and, with PIE_EXPIRED_ON_END, on the `end` column itself: window edges
+    at exact `end` values, windows inside one key bucket, empty and inverted windows, after touches and tombstones."""
+    if on_end:
+        monkeypatch.setenv("PIE_EXPIRED_ON_END", "1")
+    rng = np.random.default_rng(11)
     for n, flags in [(1, 0), (257, 1), (100003, 1), (1 << 20, 0)]:
         s, e, u, d = oracle.gen(SEED, n, 0, n, 100, 32, flags)
+        e = e.copy()
         gpu_ctx.load_columns(s, e, u, d, 100)
-        for prev, now in [(oracle.T0_MS - 50 * DAY, oracle.T0_MS - 20 * DAY), (INT64_MIN, 2 ** 62), (5, 4),
-                          (oracle.T0_MS - 6 * 3600 * 1000 - 60000, oracle.T0_MS - 6 * 3600 * 1000)]:
+        k = int(e[n // 2])
+        windows = [(oracle.T0_MS - 50 * DAY, oracle.T0_MS - 20 * DAY), (INT64_MIN, 2 ** 62), (5, 4),
+                   (oracle.T0_MS - 6 * 3600 * 1000 - 60000, oracle.T0_MS - 6 * 3600 * 1000),
+                   (k - 1, k), (k, k + 1), (k, k), (k - 1000, k + 1000), (INT64_MIN, k), (k, 2 ** 63 - 1)]
+        for prev, now in windows:
             assert np.array_equal(gpu_ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now))
+        if n > 1000:
+            rows = rng.choice(n, 500, replace=False).astype(np.int32)
+            new_end = rng.integers(oracle.T0_MS - 200 * DAY, oracle.T0_MS + 200 * DAY, rows.size).astype(np.int64)
+            new_end[:20] = INT64_MIN
+            gpu_ctx.set_end(rows, new_end)
+            e[rows] = new_end
+            gone = gpu_ctx.delete_user(7)
+            e[gone] = INT64_MIN
+            for prev, now in windows:
+                assert np.array_equal(gpu_ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now))
 
 
 def test_config2_parity_1e7(gpu_ctx, oracle):
