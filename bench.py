@@ -245,6 +245,35 @@ def main():
                 "k1_blocks": st["k1_blocks"],
             },
         }
+        if world == 1 and args.mode == "scan" and not gather:
+            # D2H of counts/offsets and of idx, reported beside the headline (results normally stay in HBM
+            # for the exchange step / the host serialiser's fetch); pinned host buffers, synchronous calls, 20 reps
+            h_counts = torch.empty(U, dtype=torch.int32).pin_memory()
+            h_offsets = torch.empty(U + 1, dtype=torch.int64).pin_memory()
+            h_idx = torch.empty(max(int(m), 1), dtype=torch.int32).pin_memory()
+            reps = 20
+            ctx.scan_device(now, cutoff)
+            ctx.read_results_into(h_counts.data_ptr(), h_offsets.data_ptr(), h_idx.data_ptr(), h_idx.numel())  # first use of the buffers
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ctx.scan_device(now, cutoff)
+            t2 = time.perf_counter()
+            for _ in range(reps):
+                ctx.scan_device(now, cutoff)
+                ctx.read_results_into(h_counts.data_ptr(), h_offsets.data_ptr())
+            t3 = time.perf_counter()
+            for _ in range(reps):
+                ctx.read_results_into(None, None, h_idx.data_ptr(), h_idx.numel())
+            t4 = time.perf_counter()
+            line["d2h"] = {
+                "one_scan_synchronous_ms": (t2 - t1) * 1e3 / reps,
+                "one_scan_plus_counts_offsets_to_host_ms": (t3 - t2) * 1e3 / reps,
+                "idx_to_host_ms": (t4 - t3) * 1e3 / reps, "idx_bytes": int(m) * 4, "counts_offsets_bytes": U * 4 + (U + 1) * 8,
+                "note": "one scan at a time (no run-ahead), host-synchronous, pinned buffers; not part of value",
+            }
+            nonempty = int((h_counts > 0).sum())
+            line["config"]["nonempty_feeds_rank0"] = nonempty
+            line["nonempty_feeds_per_sec"] = nonempty / (ms_per_step * 1e-3)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, U, D, now, cutoff, mask, flags)
         os.write(result_fd, (json.dumps(line) + "\n").encode())

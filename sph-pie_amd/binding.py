@@ -233,6 +233,12 @@ class PieScan:
         self._check(self._lib.pie_read_results(self._ctx, _ptr(counts), _ptr(offsets), _ptr(idx), self.n, C.byref(m)))
         return counts, offsets, idx[: m.value].copy()
 
+    def read_results_into(self, counts_ptr=None, offsets_ptr=None, idx_ptr=None, idx_cap=0):
+        """pie_read_results into caller-owned host memory (raw addresses, e.g. of pinned buffers).  -> M."""
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_read_results(self._ctx, counts_ptr, offsets_ptr, idx_ptr, int(idx_cap), C.byref(m)))
+        return m.value
+
     def scan_device(self, now, cutoff):
         m = C.c_size_t(0)
         self._check(self._lib.pie_scan_device(self._ctx, int(now), int(cutoff), C.byref(m)))
