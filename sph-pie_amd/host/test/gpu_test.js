@@ -2,6 +2,8 @@
 // GPU checks of the Node host over the N-API addon: run on an MI355X box with TZ=UTC.
 //  1. sessionStore (device-backed) replays the G1-G4 fixture recorded from the real reference module
 //     (tests/golden/sessionstore_g1_g4.json) and must answer exactly as the reference did.
+//  1b. the same store replays the G5 call trace (tests/golden/sessionstore_g5_trace.json: 1 345 recorded calls into the
+//      real module) and must give every answer the reference gave, plus per-user feeds from the device at every census.
 //  2. scanFeeds() on the synthetic corpus equals the reference-faithful JS restatement (oracle/ref_faithful.js).
 //  3. GET /api/calendar end to end: cookie auth, 401 / 403 / 423, {events} sorted by startTs.
 process.env.TZ = 'UTC';
@@ -94,6 +96,50 @@ function get(port, cookie){
         eq(Number(store.fetchRows(Int32Array.of(t.row)).end[0]), t.after.expiresAt, 'device end after touch');
       }
     }
+    store.close();
+  }
+
+  // ---- 1b. G5: a recorded call sequence of the real module, replayed call for call on the device-backed store
+  {
+    const trace = JSON.parse(fs.readFileSync(path.join(REPO, 'tests', 'golden', 'sessionstore_g5_trace.json'), 'utf8'));
+    const store = createStore();
+    const tokens = [], userOfRow = [];
+    const pub = r => (r === null ? null : {userId: r.userId, createdAt: r.createdAt, expiresAt: r.expiresAt});
+    for(const op of trace.ops){
+      fakeNow = op.now;
+      if(op.op === 'create'){
+        const made = store.createSession(op.user);
+        eq(made.expiresAt, op.expiresAt);
+        tokens.push(made.token); userOfRow.push(op.user);
+      } else if(op.op === 'get'){
+        eq(pub(store.getSession(tokens[op.tok])), op.result, 'G5 get');
+      } else if(op.op === 'touch'){
+        const r = store.touchSession(tokens[op.tok]);
+        eq(r === null ? null : {userId: r.userId, expiresAt: r.expiresAt}, op.result, 'G5 touch');
+      } else if(op.op === 'del'){
+        eq(store.deleteSession(tokens[op.tok]), undefined);
+      } else if(op.op === 'delUser'){
+        eq(store.deleteSessionsForUser(op.user), undefined);
+      } else if(op.op === 'purge'){
+        eq(store.purgeExpiredSessions(), undefined);
+      } else if(op.op === 'census'){
+        const live = [];
+        tokens.forEach((t, i) => { if(store.getSession(t) !== null){ live.push(i); } });
+        eq(live, op.live, 'G5 census now=' + op.now);
+        // the batched device scan agrees: selected rows == live rows, grouped per user in row order
+        if(tokens.length){
+          const res = store.scanFeeds({now: op.now});
+          eq(Array.from(res.idx.subarray(0, res.m)).sort((a, b) => a - b), op.live, 'G5 device census');
+          const ids = store.userIds();
+          for(let u = 0; u < ids.length; u++){
+            const rows = Array.from(res.idx.subarray(Number(res.offsets[u]), Number(res.offsets[u + 1])));
+            assert.deepStrictEqual(rows, op.live.filter(r => userOfRow[r] === ids[u]));
+          }
+          checks++;
+        }
+      }
+    }
+    eq(tokens.length, trace.sessions);
     store.close();
   }
 

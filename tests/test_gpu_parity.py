@@ -74,6 +74,15 @@ def test_golden_sessionstore_vectors(gpu_ctx, oracle):
         assert int(e2[0]) == t["after"]["expiresAt"]
 
 
+def test_g5_reference_trace_on_the_device(gpu_ctx):
+    """The recorded call sequence of the real sessionStore.js (tests/golden/sessionstore_g5_trace.json) replayed on the
+    device table through the C ABI: appends one row at a time, touches, tombstones, user deletes, purges via the expired
+    queue, and the batched scan at every census — every answer equals the reference's."""
+    from trace_replay import DeviceTable, load_trace, replay
+    trace = load_trace(GOLDEN)
+    assert replay(trace, DeviceTable(gpu_ctx, len(trace["users"]))) == len(trace["ops"])
+
+
 def test_hand_derived_vectors(gpu_ctx):
     h = json.load(open(os.path.join(GOLDEN, "hand_derived_h1_h5.json")))
     for case in h["scan_cases"]:

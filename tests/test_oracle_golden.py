@@ -201,3 +201,12 @@ def test_add_months_matches_js_date_vectors(oracle):
     # a fixed zone offset shifts the local calendar day: 2025-01-31T20:00Z is Feb 1 in UTC+05:30
     assert oracle.add_months(1738353600000, 1, 330 * 60000) == 1738353600000 + 28 * 86400000
     assert oracle.add_months(1738353600000, 1, 0) == 1738353600000 + 31 * 86400000   # Jan 31 + 1 month = "Feb 31" = Mar 3
+
+
+def test_g5_reference_trace_on_the_oracle(oracle):
+    """1 345 recorded calls into the real sessionStore.js (create / get / touch / delete / delete-by-user / purge / census,
+    same-millisecond sessions, lookups after death) replayed on numpy columns with the oracle's predicates: every answer
+    the reference gave, and at every census the per-user feeds of the batched scan."""
+    from trace_replay import OracleTable, load_trace, replay
+    trace = load_trace(GOLDEN)
+    assert replay(trace, OracleTable(oracle, len(trace["users"]))) == len(trace["ops"]) > 1300
