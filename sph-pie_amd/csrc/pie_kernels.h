@@ -1,17 +1,22 @@
 // pie_kernels.h — device kernels of the session-scan -> per-user feed path, written for gfx950 (CDNA4):
-// 64-lane wavefronts, SoA columns streamed with 16-B / 8-B per-lane loads, per-wave ballot + mbcnt prefix
-// compaction staged in LDS, one pass over the 24 B/row table.  Integer only — no MFMA on this path.
+// 64-lane wavefronts, columns streamed with 16-B per-lane loads, per-wave ballot + mbcnt prefix compaction staged in
+// LDS, one pass over the table.  Integer only — no MFMA on this path.
 //
 // Pipeline of one scan (all on one stream):
-//   K1  k_scan_compact   read 4 columns once, predicate, histogram counts[user], compact selected rows
-//   K2  k_offsets        one launch: exclusive scan of counts -> offsets[U+1] (tile sums published with
-//                        agent-scope granules, tiles claimed by ticket), work lists for K4, summary to the
-//                        host through mapped memory, and the zeroing of the other slot's histogram
-//   K3  k_scatter        selected records -> per-user buckets (slot = offsets[u] + atomic rank)
-//   K4  k_sort_tiny      buckets of <= 16 rows: one thread each, bitonic network in registers
-//       k_sort_small     17..512 rows: one wave each, bitonic in registers + cross-lane exchanges (launched if any)
-//       k_sort_segments  513..4096 rows and 4096-row tiles of big buckets: one 1024-thread block each, LDS bitonic
-//   K4c k_merge_pass     big buckets only: log2(n/4096) rank-merge passes
+//   K1  the table pass: predicate, histogram counts[user] (the returning atomic is the row's rank in its bucket),
+//       selected rows -> direct[user * 16 + rank] for rank < 16, else staged into the block's private region
+//         k_scan_keyed       few rows live: streams a 1- or 2-byte liveness key, one 16-B payload gather per candidate
+//         k_scan_live_first  the same idea on the 8-byte `end` column (tables without the derived columns)
+//         k_scan_compact     many rows live: streams the predicate columns, late user materialisation
+//   K2  k_offsets          one launch: exclusive scan of counts -> offsets[U+1] (tile granules with agent-scope
+//                          stores, tiles claimed by ticket), in its fused form also the order of every bucket of
+//                          <= 16 rows and the exchange message; work lists for K4, summary to the host through mapped
+//                          memory, and the zeroing of the next scan's histogram span
+//   K3  k_scatter          staged records -> bkt[offsets[u] + rank]          (only if a bucket outgrew 16 rows)
+//   K4  k_sort_tiny        buckets of <= 16 rows, one thread each             (unfused K2 only)
+//       k_sort_small       17..512 rows: one wave each, bitonic in registers + cross-lane exchanges
+//       k_sort_segments    513..4096 rows and 4096-row tiles of big buckets: one 1024-thread block each, LDS bitonic
+//   K4c k_merge_pass       big buckets only: log2(n/4096) rank-merge passes
 // Order inside a bucket is (start asc, row index asc): ORDER BY start_ts ASC
 // (/root/reference/server/storage/sqlProvider.js:276) with the tie rule of SURVEY.md §8 a-D.
 #pragma once
@@ -102,15 +107,11 @@ constexpr int kWave = 64;
 constexpr int kK1Threads = 256;
 constexpr int kK1Waves = kK1Threads / kWave;
 constexpr int kUnitRows = 2 * kWave;            // one int64x2 load per lane
-constexpr int kUnroll = 4;                      // units per wave-tile
-constexpr int kWaveTileRows = kUnitRows * kUnroll; // 512 rows per wave per iteration
-constexpr int kBlockTileRows = kWaveTileRows * kK1Waves;
 constexpr int kStage = 128;                     // per-wave LDS ring of selected records
 constexpr int kTinyMax = 16;
 constexpr int kSmallMax = 512;                  // buckets of 17..512 rows: sorted by ONE wave in LDS, no block barriers
 constexpr int kSegMax = 4096;
-constexpr int kScanTile = 2048;                 // counts per K2 block (256 threads x 8); the fused K2+K4 form uses kOrderTile
-constexpr int kOrderTile = 1024;                // users per block of the fused form: one per thread, 1024-thread blocks
+constexpr int kScanTile = 2048;                 // counts per K2 block of the unfused form (256 threads x 8)
 
 // ------------------------------------------------------------------------------------------------ helpers
 

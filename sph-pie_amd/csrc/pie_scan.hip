@@ -1,17 +1,21 @@
 // pie_scan.hip — C ABI (include/pie_scan.h) over the HIP kernels of pie_kernels.h.  gfx950 only.
 // There is no CPU path in this library: every entry point either runs on the GPU or returns an error.
 //
-// One stream, two slots.  A scan is one bandwidth-bound kernel (K1, the table pass) followed by a chain of short
-// latency-bound kernels (K2 offsets, K3 scatter, K4 per-bucket order), all on ONE stream: co-running the chain
-// with the next table pass on other streams was measured and rejected (the chain's dependent loads crawl under
-// a saturated HBM and every cross-queue dependency costs ~15 us: profiles/r01_d_two_stream_timeline.txt).
+// One stream, two slots.  A scan is one bandwidth-bound kernel (K1, the table pass) followed by short latency-bound
+// work (K2: offsets + the order of every small bucket; K3 scatter / K4 order only for buckets that outgrew their 16
+// direct slots), all on ONE stream: co-running the tail with the next table pass on other streams was measured and
+// rejected (its dependent loads crawl under a saturated HBM and every cross-queue dependency costs ~15 us:
+// profiles/r01_d_two_stream_timeline.txt).
 // The big per-scan buffers exist twice (two SLOTS) and the small histogram "spans" three times, rotating: K2 of
 // every scan zeroes the span the NEXT scan will use (whose consumers are two scans old), so no memset and no
 // event sits between kernels — a marker packet between two kernels costs ~6 us here, a plain kernel boundary ~0.
 // pie_scan_begin enqueues K1+K2 and returns; pie_scan_finish spins on the summary that K2's last block writes to
-// mapped host memory, then enqueues K3/K4 sized from it.  With begin(i+1) called before finish(i) the stream
-// always holds the next table pass, so the host's round trip (summary -> K3/K4 launch) is off the critical path:
-//   stream:  K1(i) K2(i) | K1(i+1) K2(i+1) | K3(i) K4(i) consumers(i) | K1(i+2) K2(i+2) | K3(i+1) ...
+// mapped host memory, then enqueues K3/K4 sized from it if any bucket needs them.  With begin(i+1) called before
+// finish(i) the stream always holds the next table pass, so the host's round trip is off the critical path:
+//   stream:  K1(i) K2(i) | K1(i+1) K2(i+1) | [K3(i) K4(i)] consumers(i) | K1(i+2) K2(i+2) | ...
+// The table carries three derived columns (2-byte and 1-byte liveness keys, 16-byte payload records; pie_kernels.h)
+// that every writer of `end` keeps in step; the scan form is chosen per scan from what the previous scan observed
+// (live fraction, ambiguous keys, hot buckets) — see scan_begin.
 #include "../../include/pie_scan.h"
 #include "pie_kernels.h"
 
@@ -235,14 +239,14 @@ void plan_one(pie_ctx* c, int which, long long want, const char* env)
         if (v > 0) want = v;
     }
     // a whole number of wave-tiles for every unroll (the keyed form reads 512 rows per wave per load)
-    const long long kBlockTileRows = which == 3 ? (long long)kFineKeyRowsPerLoad * 8 * kK1Waves
+    const long long block_tile_rows = which == 3 ? (long long)kFineKeyRowsPerLoad * 8 * kK1Waves
                                      : which == 2 ? (long long)kKeyRowsPerLoad * 8 * kK1Waves : (long long)kUnitRows * 8 * kK1Waves;
-    long long tiles = (c->n + kBlockTileRows - 1) / kBlockTileRows;
+    long long tiles = (c->n + block_tile_rows - 1) / block_tile_rows;
     if (tiles < 1) tiles = 1;
     if (want > tiles) want = tiles;
     if (want < 1) want = 1;
     const long long tiles_per_block = (tiles + want - 1) / want;
-    c->plan_rows[which] = tiles_per_block * kBlockTileRows;
+    c->plan_rows[which] = tiles_per_block * block_tile_rows;
     c->plan_blocks[which] = (int)((c->n + c->plan_rows[which] - 1) / c->plan_rows[which]);
     if (c->plan_blocks[which] < 1) c->plan_blocks[which] = 1;
 }
@@ -735,9 +739,7 @@ int scan_finish(pie_ctx* c)
             PIE_HIP(c, hipMemsetAsync(sl.counts, 0, counts_span(c), a));
             sl.fast = false;
             sl.variant = c->k1_live_first;
-            const bool had_events = sl.ev_index >= 0;
             sl.ev_index = -1; // the events of the discarded attempt stay as they are (they timed real launches)
-            (void)had_events;
             sl.seq = ++c->seq_counter;
             launch_k1(c, sl, a, sl.q_now, sl.q_cutoff, mask);
             launch_k2(c, sl, a, (int4*)nullptr, 0LL);
