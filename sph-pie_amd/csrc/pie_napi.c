@@ -617,6 +617,91 @@ static napi_value fn_serialize_events(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* serializeICal(idx Int32Array, m, start BigInt64Array, end BigInt64Array, disc Int32Array, summaries Array<string>,
+ *               dtstampMs) -> Buffer with exactly the bytes of host/calendarFeed.js toICalendar(rows.map(eventFromRow)):
+ * the iCalendar (RFC 5545) form of the feed — new functionality, the reference only consumes .ics.  summaries[d] = the
+ * escaped SUMMARY prefix of discipline d ("<name> session #" follows the row number).  Returns null when a row is
+ * outside what this fast path covers (year outside 0000..9999, unknown discipline, a SUMMARY line that would need
+ * folding): the caller then uses the JS path. */
+static int ics_utc(int64_t ms, char out[17])
+{
+    char iso[25];
+    int h, mi;
+    int64_t sec_ms = ms - (((ms % 1000) + 1000) % 1000); /* floor to the second, also for negative ms */
+    if (!iso_utc(sec_ms, iso, &h, &mi)) return 0;
+    /* YYYY-MM-DDTHH:mm:ss.sssZ -> YYYYMMDDTHHMMSSZ */
+    memcpy(out, iso, 4); memcpy(out + 4, iso + 5, 2); memcpy(out + 6, iso + 8, 2);
+    out[8] = 'T';
+    memcpy(out + 9, iso + 11, 2); memcpy(out + 11, iso + 14, 2); memcpy(out + 13, iso + 17, 2);
+    out[15] = 'Z';
+    out[16] = 0;
+    return 1;
+}
+
+static napi_value fn_serialize_ical(napi_env env, napi_callback_info info)
+{
+    ARGS(7)
+    size_t cap = 0, n1 = 0, n2 = 0, n3 = 0;
+    int32_t *idx = typed(env, argv[0], napi_int32_array, &cap);
+    int64_t m = 0, stamp_ms = 0;
+    int64_t *start = typed(env, argv[2], napi_bigint64_array, &n1), *end = typed(env, argv[3], napi_bigint64_array, &n2);
+    int32_t *disc = typed(env, argv[4], napi_int32_array, &n3);
+    uint32_t n_disc = 0;
+    if (!idx || !get_i64(env, argv[1], &m) || m < 0 || (size_t)m > cap || !start || !end || !disc || n1 < (size_t)m ||
+        n2 < (size_t)m || n3 < (size_t)m || napi_get_array_length(env, argv[5], &n_disc) != napi_ok || n_disc > 64 ||
+        !get_i64(env, argv[6], &stamp_ms)) {
+        napi_throw_type_error(env, NULL, "serializeICal(Int32Array idx, m, BigInt64Array start, BigInt64Array end, Int32Array disc, Array summaries, dtstampMs)");
+        return NULL;
+    }
+    char *sum[64];
+    size_t sum_len[64];
+    memset(sum, 0, sizeof sum);
+    int ok = 1, covered = 1;
+    for (uint32_t d = 0; d < n_disc && ok; ++d) {
+        napi_value sv;
+        size_t len = 0;
+        if (napi_get_element(env, argv[5], d, &sv) != napi_ok || napi_get_value_string_utf8(env, sv, NULL, 0, &len) != napi_ok) { ok = 0; break; }
+        sum[d] = (char *)malloc(len + 1);
+        if (!sum[d] || napi_get_value_string_utf8(env, sv, sum[d], len + 1, &sum_len[d]) != napi_ok) ok = 0;
+        /* "SUMMARY:" + prefix + up to 10 digits must stay within 75 octets, or the line would need folding */
+        if (ok && 8 + sum_len[d] + 10 > 75) covered = 0;
+    }
+    char stamp[17];
+    if (ok && !ics_utc(stamp_ms, stamp)) covered = 0;
+    sbuf b = {NULL, 0, 0};
+    if (ok && covered) ok = SB_LIT(&b, "BEGIN:VCALENDAR\r\nVERSION:2.0\r\nPRODID:-//sph-pie_amd//session feed//EN\r\nCALSCALE:GREGORIAN\r\n");
+    for (int64_t i = 0; i < m && ok && covered; ++i) {
+        const int32_t dv = disc[i];
+        char ds[17], de[17];
+        const int has_end = end[i] != INT64_MIN;
+        if (dv < 0 || (uint32_t)dv >= n_disc || !ics_utc(start[i], ds) || (has_end && !ics_utc(end[i], de))) { covered = 0; break; }
+        ok = SB_LIT(&b, "BEGIN:VEVENT\r\nUID:session-") && sb_i64(&b, idx[i]) && SB_LIT(&b, "\r\nDTSTAMP:") && sb_put(&b, stamp, 16) &&
+             SB_LIT(&b, "\r\nDTSTART:") && sb_put(&b, ds, 16) && (has_end ? (SB_LIT(&b, "\r\nDTEND:") && sb_put(&b, de, 16)) : 1) &&
+             SB_LIT(&b, "\r\nSUMMARY:") && sb_put(&b, sum[dv], sum_len[dv]) && sb_i64(&b, idx[i]) && SB_LIT(&b, "\r\nEND:VEVENT\r\n");
+    }
+    if (ok && covered) ok = SB_LIT(&b, "END:VCALENDAR\r\n");
+    for (uint32_t d = 0; d < 64; ++d) free(sum[d]);
+    napi_value out = NULL;
+    if (!ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "serializeICal: out of memory or bad summaries table");
+        return NULL;
+    }
+    if (!covered) {
+        free(b.p);
+        napi_get_null(env, &out);
+        return out;
+    }
+    void *copy = NULL;
+    if (napi_create_buffer_copy(env, b.len, b.p, &copy, &out) != napi_ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "cannot create Buffer");
+        return NULL;
+    }
+    free(b.p);
+    return out;
+}
+
 /* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
@@ -662,7 +747,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
         {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
-        {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+        {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

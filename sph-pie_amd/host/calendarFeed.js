@@ -102,4 +102,57 @@ async function fetchCalendarFeed(feedSource){
   }
 }
 
-module.exports = {fetchCalendarFeed, getCalendarCutoffTimestamp, parseCalendarMetadata, eventFromRow, windowAndDedup, orderEvents, END_NONE};
+// ---- iCalendar text (RFC 5545) for a list of events.  NEW functionality: the reference only CONSUMES .ics
+// (node-ical, calendarFeed.js:46); there is no producer to mirror.  The fields are chosen so that the reference's
+// own consumer loop (calendarFeed.js:52-80) maps each VEVENT back to the event it came from: UID -> id,
+// SUMMARY -> title, DTSTART / DTEND (UTC date-times) -> start / end, DESCRIPTION / LOCATION when non-empty.
+// iCalendar date-times carry whole seconds, so startTs / endTs come back floored to the second.
+const ICS_PRODID = '-//sph-pie_amd//session feed//EN';
+
+function icsEscape(text){
+  return String(text).replace(/\\/g, '\\\\').replace(/;/g, '\\;').replace(/,/g, '\\,').replace(/\r\n|\n|\r/g, '\\n');
+}
+
+// content lines longer than 75 octets are folded: CRLF + one space (RFC 5545 3.1); never inside a UTF-8 sequence
+function icsFold(line){
+  const bytes = Buffer.from(line, 'utf8');
+  if(bytes.length <= 75){ return line; }
+  const parts = [];
+  let at = 0, room = 75;
+  while(at < bytes.length){
+    let end = Math.min(at + room, bytes.length);
+    while(end < bytes.length && (bytes[end] & 0xC0) === 0x80){ end--; }
+    parts.push(bytes.slice(at, end).toString('utf8'));
+    at = end;
+    room = 74;                                       // continuation lines start with a space
+  }
+  return parts.join('\r\n ');
+}
+
+function icsUtc(ms){
+  const iso = new Date(Math.floor(ms / 1000) * 1000).toISOString();     // YYYY-MM-DDTHH:mm:ss.000Z
+  return iso.slice(0, 4) + iso.slice(5, 7) + iso.slice(8, 10) + 'T' + iso.slice(11, 13) + iso.slice(14, 16) + iso.slice(17, 19) + 'Z';
+}
+
+// events: objects of the calendarFeed.js:66-79 shape.  options.dtstamp (ms) fixes DTSTAMP (default: now).
+function toICalendar(events, options){
+  const stamp = icsUtc(options && options.dtstamp !== undefined ? options.dtstamp : Date.now());
+  const lines = ['BEGIN:VCALENDAR', 'VERSION:2.0', 'PRODID:' + ICS_PRODID, 'CALSCALE:GREGORIAN'];
+  for(const ev of (Array.isArray(events) ? events : [])){
+    if(!ev || !Number.isFinite(ev.startTs)){ continue; }
+    lines.push('BEGIN:VEVENT');
+    lines.push(icsFold('UID:' + icsEscape(ev.id)));
+    lines.push('DTSTAMP:' + stamp);
+    lines.push('DTSTART:' + icsUtc(ev.startTs));
+    if(ev.endTs !== null && ev.endTs !== undefined && Number.isFinite(ev.endTs)){ lines.push('DTEND:' + icsUtc(ev.endTs)); }
+    lines.push(icsFold('SUMMARY:' + icsEscape(ev.title)));
+    if(ev.description){ lines.push(icsFold('DESCRIPTION:' + icsEscape(ev.description))); }
+    if(ev.location){ lines.push(icsFold('LOCATION:' + icsEscape(ev.location))); }
+    lines.push('END:VEVENT');
+  }
+  lines.push('END:VCALENDAR');
+  return lines.join('\r\n') + '\r\n';
+}
+
+module.exports = {fetchCalendarFeed, getCalendarCutoffTimestamp, parseCalendarMetadata, eventFromRow, windowAndDedup, orderEvents, END_NONE,
+  toICalendar, icsEscape, icsFold, icsUtc, ICS_PRODID};

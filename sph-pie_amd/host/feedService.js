@@ -53,6 +53,32 @@ function createFeedService(store, options){
     return Buffer.from(JSON.stringify({events}));
   }
 
+  // the same slice as iCalendar text (new functionality, see calendarFeed.toICalendar): native writer when it covers
+  // the rows, else the JS emitter over the event objects
+  function icsFromSlice(res, lo, hi, dtstamp){
+    const idx = res.idx.subarray(lo, hi);
+    const cols = store.fetchRows(idx);
+    const stamp = dtstamp === undefined ? Date.now() : dtstamp;
+    if(store.native && typeof store.native.serializeICal === 'function'){
+      const summaries = disciplineConfig.DISCIPLINES.map(d => calendarFeed.icsEscape(d.name + ' session #'));
+      const buf = store.native.serializeICal(idx, idx.length, cols.start, cols.end, cols.disc, summaries, stamp);
+      if(buf !== null){ return buf; }
+    }
+    const events = [];
+    for(let i = 0; i < idx.length; i++){
+      const d = disciplineConfig.DISCIPLINES[cols.disc[i]];
+      events.push(calendarFeed.eventFromRow(idx[i], cols.start[i], cols.end[i], d ? d.name : 'Session'));
+    }
+    return Buffer.from(calendarFeed.toICalendar(events, {dtstamp: stamp}), 'utf8');
+  }
+
+  function icsForUser(userId, query, dtstamp){
+    const u = store.userIndexOf(userId);
+    if(u < 0){ return Buffer.from(calendarFeed.toICalendar([], {dtstamp: dtstamp === undefined ? Date.now() : dtstamp}), 'utf8'); }
+    const {res} = scan(query);
+    return icsFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]), dtstamp);
+  }
+
   // response body bytes for one user's feed
   function eventsJsonForUser(userId, query){
     const u = store.userIndexOf(userId);
@@ -95,7 +121,7 @@ function createFeedService(store, options){
     return feeds;
   }
 
-  return {scan, eventsForUser, eventsJsonForUser, allFeeds};
+  return {scan, eventsForUser, eventsJsonForUser, icsForUser, allFeeds};
 }
 
 module.exports = {createFeedService};

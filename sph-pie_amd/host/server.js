@@ -56,7 +56,7 @@ function createServer(options){
     return user;
   }
 
-  function handleCalendar(req, res){
+  function handleCalendar(req, res, asIcs){
     const user = authenticate(req);
     if(user && user.needsPasswordReset){
       return sendJson(res, 423, {error: 'Password reset required'});
@@ -69,6 +69,12 @@ function createServer(options){
       return sendJson(res, 403, {error: 'Insufficient permissions'});
     }
     const query = options.query ? options.query(req, user) : undefined;
+    if(asIcs){
+      // NEW route (the reference has no .ics producer): the same feed, same auth, as iCalendar text
+      const body = feeds.icsForUser(user.id, query);
+      res.writeHead(200, {'Content-Type': 'text/calendar; charset=utf-8', 'Content-Length': body.length});
+      return res.end(body);
+    }
     if(typeof feeds.eventsJsonForUser === 'function'){
       // body bytes straight from the native serialiser (same bytes as JSON.stringify({events}))
       const body = feeds.eventsJsonForUser(user.id, query);
@@ -83,7 +89,10 @@ function createServer(options){
     try{
       const path = (req.url || '').split('?')[0];
       if(req.method === 'GET' && path === '/api/calendar'){
-        return handleCalendar(req, res);
+        return handleCalendar(req, res, false);
+      }
+      if(req.method === 'GET' && path === '/api/calendar.ics'){
+        return handleCalendar(req, res, true);
       }
       if(req.method === 'GET' && path === '/api/health'){
         // existing keys of /root/reference/server/index.js:132-144 kept (status, storage, storageMeta); the device

@@ -75,6 +75,75 @@ eq([ev.startTs, ev.endTs, ev.allDay, ev.eventName, ev.showNumber, ev.id], [17000
 const noEnd = cf.eventFromRow(1, 1699920000000n, cf.END_NONE, 'Audio');
 eq([noEnd.end, noEnd.endTs, noEnd.allDay], ['', null, true]);
 
+// ---- iCalendar emitter (new functionality).  Round trip: events -> .ics text -> a minimal RFC 5545 reader (unfold,
+//      split, unescape: what node-ical hands the reference) -> the reference's consumer loop restated
+//      (/root/reference/server/calendarFeed.js:52-80: id from uid, title from summary, start/end Dates, the allDay
+//      rule of :64, metadata of :65) -> the events we started from, with timestamps floored to the second.
+function icsRead(text){
+  const lines = text.replace(/\r\n[ \t]/g, '').split('\r\n');
+  const unesc = v => v.replace(/\\(.)/g, (m, ch) => (ch === 'n' || ch === 'N' ? '\n' : ch));
+  const toDate = v => new Date(Date.UTC(+v.slice(0, 4), +v.slice(4, 6) - 1, +v.slice(6, 8), +v.slice(9, 11), +v.slice(11, 13), +v.slice(13, 15)));
+  const entries = [];
+  let cur = null;
+  for(const line of lines){
+    if(line === 'BEGIN:VEVENT'){ cur = {type: 'VEVENT'}; continue; }
+    if(line === 'END:VEVENT'){ entries.push(cur); cur = null; continue; }
+    if(!cur){ continue; }
+    const at = line.indexOf(':');
+    const key = line.slice(0, at), val = line.slice(at + 1);
+    if(key === 'UID'){ cur.uid = unesc(val); }
+    else if(key === 'SUMMARY'){ cur.summary = unesc(val); }
+    else if(key === 'DESCRIPTION'){ cur.description = unesc(val); }
+    else if(key === 'LOCATION'){ cur.location = unesc(val); }
+    else if(key === 'DTSTART'){ cur.start = toDate(val); }
+    else if(key === 'DTEND'){ cur.end = toDate(val); }
+  }
+  return entries;
+}
+function consumeLikeTheReference(entries){
+  const events = [];
+  for(const entry of entries){
+    if(!entry || entry.type !== 'VEVENT'){ continue; }
+    const start = entry.start instanceof Date ? entry.start : null;
+    const end = entry.end instanceof Date ? entry.end : null;
+    if(!start){ continue; }
+    const id = typeof entry.uid === 'string' && entry.uid ? entry.uid : (entry.summary || 'event') + '-' + start.getTime();
+    const allDay = start.getUTCHours() === 0 && start.getUTCMinutes() === 0 && (!end || end.getUTCHours() === 0);
+    const meta = cf.parseCalendarMetadata(typeof entry.summary === 'string' ? entry.summary : '');
+    events.push({id, title: typeof entry.summary === 'string' ? entry.summary : 'Untitled event',
+      description: typeof entry.description === 'string' ? entry.description : '', location: typeof entry.location === 'string' ? entry.location : '',
+      start: start.toISOString(), end: end ? end.toISOString() : '', startTs: start.getTime(), endTs: end ? end.getTime() : null,
+      allDay, eventName: meta.eventName, showNumber: meta.showNumber, color: meta.color});
+  }
+  return events;
+}
+{
+  const src = [
+    cf.eventFromRow(5, 1700000000123n, 1700043200999n, 'Show Control'),
+    cf.eventFromRow(77, 1699920000000n, cf.END_NONE, 'Drones'),                    // midnight UTC, no end: allDay
+    cf.eventFromRow(2000000000, -5000000000000n, -4999999999000n, '4D'),           // 1811; title starts with a digit
+    {id: 'a;b,c\\d', title: 'Eagles #12, late; "x"\nsecond line ' + 'é'.repeat(70), description: 'desc, with; stuff', location: 'Hall 4',
+      startTs: 1700000000000, endTs: null}
+  ];
+  const text = cf.toICalendar(src, {dtstamp: 1700000000000});
+  ok(text.startsWith('BEGIN:VCALENDAR\r\nVERSION:2.0\r\n') && text.endsWith('END:VCALENDAR\r\n'));
+  ok(text.split('\r\n').every(l => Buffer.byteLength(l, 'utf8') <= 75), 'folded to 75 octets');
+  ok(!/[^\r]\n/.test(text), 'CRLF only');
+  const back = consumeLikeTheReference(icsRead(text));
+  eq(back.length, src.length);
+  const floorS = ms => Math.floor(ms / 1000) * 1000;
+  src.forEach((ev, i) => {
+    const startTs = floorS(ev.startTs), endTs = ev.endTs === null ? null : floorS(ev.endTs);
+    const meta = cf.parseCalendarMetadata(ev.title);
+    eq(back[i], {id: ev.id, title: ev.title, description: ev.description || '', location: ev.location || '',
+      start: new Date(startTs).toISOString(), end: endTs === null ? '' : new Date(endTs).toISOString(), startTs, endTs,
+      allDay: new Date(startTs).getUTCHours() === 0 && new Date(startTs).getUTCMinutes() === 0 && (endTs === null || new Date(endTs).getUTCHours() === 0),
+      eventName: meta.eventName, showNumber: meta.showNumber, color: meta.color}, 'ics round trip ' + i);
+  });
+  eq(cf.toICalendar([], {dtstamp: 0}), 'BEGIN:VCALENDAR\r\nVERSION:2.0\r\nPRODID:' + cf.ICS_PRODID + '\r\nCALSCALE:GREGORIAN\r\nEND:VCALENDAR\r\n');
+  eq(cf.toICalendar([{id: 'x', title: 't', startTs: NaN}], {dtstamp: 0}).indexOf('VEVENT'), -1);   // non-finite start: not emitted
+}
+
 // ---- fetchCalendarFeed never rejects
 (async () => {
   eq(await cf.fetchCalendarFeed(''), []);

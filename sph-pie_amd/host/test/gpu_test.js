@@ -211,6 +211,18 @@ function get(port, cookie){
     eq(lead.body.events[0].endTs - lead.body.events[0].startTs, store.SESSION_TTL_MS);
     eq((await get(port, ck(cookies['u-crew']))).body.events.length, 2);
     eq((await get(port, ck(cookies['u-admin']))).body.events.length, 1);
+    // the same feed as iCalendar text (new route, same auth): one VEVENT per event, same order, UIDs = event ids
+    const icsGet = cookie => new Promise((resolve, reject) => {
+      http.get({host: '127.0.0.1', port, path: '/api/calendar.ics', headers: cookie ? {cookie} : {}}, res => {
+        let b = ''; res.on('data', c => { b += c; }); res.on('end', () => resolve({status: res.statusCode, type: res.headers['content-type'], body: b}));
+      }).on('error', reject);
+    });
+    eq((await icsGet(null)).status, 401);
+    eq((await icsGet(ck(cookies['u-audio']))).status, 403);
+    const ics = await icsGet(ck(cookies['u-lead']));
+    eq([ics.status, ics.type], [200, 'text/calendar; charset=utf-8']);
+    eq(ics.body.split('\r\n').filter(l => l.startsWith('UID:')).map(l => l.slice(4)), lead.body.events.map(e => e.id));
+    eq(ics.body.split('\r\n').filter(l => l.startsWith('SUMMARY:')).map(l => l.slice(8)), lead.body.events.map(e => e.title));
     const health = await new Promise((resolve, reject) => {
       http.get({host: '127.0.0.1', port, path: '/api/health'}, res => { let b = ''; res.on('data', c => { b += c; }); res.on('end', () => resolve(JSON.parse(b))); }).on('error', reject);
     });
@@ -253,8 +265,16 @@ function get(port, cookie){
     const got = native.serializeEvents(idx, n, s, e, d, table);
     eq(got.toString('utf8') === want, true, 'native serialiser bytes');
     eq(native.serializeEvents(idx, 0, s, e, d, table).toString(), '{"events":[]}');
+    // the iCalendar form: native bytes == the JS emitter over the same events
+    const summaries = names.map(nm => cf.icsEscape(nm + ' session #'));
+    const icsWant = cf.toICalendar(Array.from(idx, (row, i) => cf.eventFromRow(row, s[i], e[i], names[d[i]])), {dtstamp: 1700000000999});
+    const icsGot = native.serializeICal(idx, n, s, e, d, summaries, 1700000000999);
+    eq(icsGot.toString('utf8') === icsWant, true, 'native iCal bytes');
+    eq(native.serializeICal(idx, 0, s, e, d, summaries, 0).toString(), cf.toICalendar([], {dtstamp: 0}));
+    eq(native.serializeICal(idx, 3, s, e, d, names.map(() => 'x'.repeat(70)), 0), null);   // would need folding -> JS path
     s[0] = 300000000000000n;                                                 // year 11476: not covered -> null
     eq(native.serializeEvents(idx, n, s, e, d, table), null);
+    eq(native.serializeICal(idx, n, s, e, d, summaries, 0), null);
     d[1] = 99;
     eq(native.serializeEvents(idx, 2, s.subarray(1), e.subarray(1), d.subarray(1), table), null);
     store.close();
