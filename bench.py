@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--order", choices=["random", "clustered"], default="random")
     ap.add_argument("--users-dist", choices=["uniform", "zipf"], default="uniform", help="zipf: Zipf(1.1) over the shard's users")
     ap.add_argument("--variant", choices=["auth", "interval"], default="auth")
-    ap.add_argument("--query", choices=["spec", "wide"], default="spec",
+    ap.add_argument("--query", choices=["spec", "wide", "future"], default="spec",
                     help="spec: now=T0-6h, cutoff=T0-61d, 16/32 disciplines (SURVEY.md §8d); wide: ~25%% selected")
     ap.add_argument("--cpu-sample-rows", type=int, default=2 * 10 ** 7)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -127,8 +127,12 @@ def main():
     flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0)
     if args.query == "spec":
         now, cutoff, mask = T0_MS - 6 * 3600 * 1000, T0_MS - 61 * DAY, 0x5555555555555555
+    elif args.query == "future":   # nothing is live: the table pass with no candidate rows (pure key streaming)
+        now, cutoff, mask = T0_MS + DAY, T0_MS - 61 * DAY, 0x5555555555555555
     else:
         now, cutoff, mask = T0_MS - 100 * DAY, T0_MS - 61 * DAY, 0x5555555555555555
+    if os.environ.get("PIE_BENCH_MASK"):   # experiments: another discipline mask (changes M, not the candidate rows)
+        mask = int(os.environ["PIE_BENCH_MASK"], 0)
     mask &= (1 << D) - 1 if D < 64 else 2 ** 64 - 1
 
     pie.build_hip()
