@@ -232,6 +232,7 @@ def test_scan_written_message_equals_the_pack_kernel(pie, oracle):
             for u_pad, cap in [(U, m + 7), (U + 123, m), (U + 1, max(m // 2, 1))]:
                 msg = torch.full((u_pad + 2 + cap,), -7, dtype=torch.int32, device=dev)
                 ref = torch.full((u_pad + 2 + cap,), -7, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()   # the fills ran on torch's stream, the scan writes from the library's own
                 ctx.scan_begin_packed(now, INT64_MIN, msg.data_ptr(), u_pad, cap)
                 got_m, ready = ctx.scan_finish_packed()
                 assert got_m == m and ready == want_ready
@@ -249,6 +250,7 @@ def test_scan_written_message_equals_the_pack_kernel(pie, oracle):
         want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
         m = want[2].size
         bufs = [torch.zeros(U + 2 + m, dtype=torch.int32, device=dev) for _ in range(3)]
+        torch.cuda.synchronize()
         ctx.scan_begin_packed(now, INT64_MIN, bufs[0].data_ptr(), U, m)
         for i in range(1, 6):
             ctx.scan_begin_packed(now, INT64_MIN, bufs[i % 3].data_ptr(), U, m)

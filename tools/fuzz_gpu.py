@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Differential fuzz on the GPU box: random tables, mutations, queries and scan forms against the CPU oracle, for a time
+budget.  usage: python tools/fuzz_gpu.py [seconds] [seed]   (prints the failing case's seed and stops at the first mismatch)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import oracle_py as oracle  # noqa: E402  (the checker)
+import sph_pie_amd as pie  # noqa: E402
+import torch  # noqa: E402
+
+INT64_MIN = -(2 ** 63)
+T0, DAY = oracle.T0_MS, 86400 * 1000
+FORMS = [None, None, None, 0x03, 0x01, 0x85, 0xC5, 0x485, 0x4C5, 0xC85, 0xCC5, 0xC95, 0x425, 0xC05]
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+t_end = time.time() + budget
+cases = scans = 0
+dev = torch.device("cuda", 0)
+
+
+def same(got, want, what):
+    for name, a, b in zip(("counts", "offsets", "idx"), got, want):
+        if a.dtype != b.dtype or not np.array_equal(a, b):
+            raise AssertionError("%s: %s differs" % (what, name))
+
+
+case_seed = seed0
+while time.time() < t_end:
+    case_seed += 1
+    rng = np.random.default_rng(case_seed)
+    form = FORMS[int(rng.integers(len(FORMS)))]
+    if form is None:
+        os.environ.pop("PIE_K1_VARIANT", None)
+    else:
+        os.environ["PIE_K1_VARIANT"] = hex(form)
+    n = int(rng.choice([1, 7, 300, 5000, 70001, 300000, 1 << 20]))
+    U = int(rng.choice([1, 3, 50, 1000, 40000, 600000]))
+    D = int(rng.choice([1, 7, 32, 64]))
+    flags = int(rng.integers(4))
+    what = "seed %d form %s n %d U %d D %d flags %d" % (case_seed, form, n, U, D, flags)
+    try:
+        s, e, u, d = [c.copy() for c in oracle.gen(int(rng.integers(1, 2 ** 60)), n, 0, n, U, D, flags)]
+        if rng.random() < 0.3:   # heavy head user
+            u = np.where(rng.random(n) < 0.5, int(rng.integers(U)), u).astype(np.int32)
+        if rng.random() < 0.3:   # many equal ends / starts
+            e = (e // (3600 * 1000)) * (3600 * 1000)
+            s = (s // (3600 * 1000)) * (3600 * 1000)
+        mask = int(rng.integers(0, 2 ** 63)) | (int(rng.integers(0, 2)) << 63)
+        if rng.random() < 0.3:
+            mask = 2 ** 64 - 1
+        m_eff = mask if D >= 64 else mask & ((1 << D) - 1)
+        with pie.PieScan(0) as ctx:
+            ctx.load_columns(s, e, u, d, U)
+            ctx.set_disciplines(mask, D)
+            for rnd in range(int(rng.integers(2, 7))):
+                # a mutation now and then
+                r = rng.random()
+                if r < 0.2 and n > 1:
+                    rows = rng.choice(n, min(n, 200), replace=False).astype(np.int32)
+                    ne = rng.integers(T0 - 200 * DAY, T0 + 50 * DAY, rows.size).astype(np.int64)
+                    ne[: rows.size // 8] = INT64_MIN
+                    ctx.set_end(rows, ne)
+                    e[rows] = ne
+                elif r < 0.3:
+                    gone = ctx.delete_user(int(rng.integers(U)))
+                    e[gone] = INT64_MIN
+                elif r < 0.4 and n < 400000:
+                    k = int(rng.integers(1, 3000))
+                    s2 = rng.integers(T0 - 150 * DAY, T0 + 300 * DAY, k).astype(np.int64)
+                    e2 = s2 + rng.integers(-50 * DAY, 50 * DAY, k)
+                    u2, d2 = rng.integers(0, U, k).astype(np.int32), rng.integers(0, D, k).astype(np.int32)
+                    ctx.append_rows(s2, e2, u2, d2, U)
+                    s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]), np.concatenate([d, d2])
+                    n = s.size
+                # a query: recent, mid, extreme, exactly on a value
+                q = rng.random()
+                now = int(T0 - rng.integers(0, 20 * 3600 * 1000)) if q < 0.5 else int(T0 - rng.integers(0, 130 * DAY)) if q < 0.8 else \
+                    int(rng.choice([INT64_MIN, 2 ** 62, int(e[int(rng.integers(n))]), int(e[int(rng.integers(n))]) - 1]))
+                cutoff = int(rng.choice([INT64_MIN, T0 - 61 * DAY, int(s[int(rng.integers(n))])]))
+                want = oracle.scan(s, e, u, d, U, now, cutoff, m_eff)
+                reps = int(rng.integers(1, 4))   # repeats let the adaptive forms engage
+                for _ in range(reps):
+                    same(ctx.scan(now, cutoff), want, what + " scan now %d cutoff %d" % (now, cutoff))
+                    scans += 1
+                if rng.random() < 0.4:   # the scan-written exchange message
+                    m = want[2].size
+                    u_pad, cap = U + int(rng.integers(0, 5)), int(rng.choice([m, m + 3, max(m // 2, 1)]))
+                    msg = torch.full((u_pad + 2 + cap,), -7, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()   # the fill ran on torch's stream, the scan writes from the library's
+                    ctx.scan_begin_packed(now, cutoff, msg.data_ptr(), u_pad, cap)
+                    got_m, _ = ctx.scan_finish_packed()
+                    ctx.synchronize()
+                    a = msg.cpu().numpy()
+                    k = min(m, cap)
+                    ok = got_m == m and np.array_equal(a[: U + 1], want[1].astype(np.int32)) and np.all(a[U + 1: u_pad + 2] == m) and \
+                        np.array_equal(a[u_pad + 2: u_pad + 2 + k], want[2][:k]) and np.all(a[u_pad + 2 + k:] == -7)
+                    if not ok:
+                        bad = np.nonzero(a[: U + 1] != want[1].astype(np.int32))[0][:5]
+                        raise AssertionError(what + " message now %d cutoff %d u_pad %d cap %d: got_m %d m %d, first bad offsets %s, pad %s, rows %s, variant %s"
+                                             % (now, cutoff, u_pad, cap, got_m, m, bad.tolist(), a[U + 1: u_pad + 2].tolist(), a[u_pad + 2:].tolist()[:8], hex(ctx.stats()["k1_variant"])))
+                    scans += 1
+                if rng.random() < 0.3:
+                    prev = int(now - rng.integers(0, 3 * DAY)) if now > INT64_MIN + 4 * DAY else INT64_MIN
+                    if not np.array_equal(ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now)):
+                        raise AssertionError(what + " expired (%d, %d]" % (prev, now))
+        cases += 1
+    except Exception as exc:  # noqa: BLE001
+        print("FAIL %s: %r" % (what, exc), flush=True)
+        sys.exit(1)
+    if cases % 20 == 0:
+        print("ok: %d cases, %d scans, %.0f s left" % (cases, scans, t_end - time.time()), flush=True)
+print("fuzz ok: %d cases, %d scans in %.0f s (first seed %d)" % (cases, scans, budget, seed0 + 1))
