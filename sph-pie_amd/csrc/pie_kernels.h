@@ -58,6 +58,8 @@ struct Summary {
     unsigned int n_small;       // entries in the small-segment list (17..256 rows: one wave each)
     unsigned int pad;
     unsigned long long amb;     // keyed table pass: rows whose liveness key equalled the query's (full `end` compare needed)
+    unsigned int n_hot;         // users whose bucket exceeded the hot threshold (candidates for the next scan's hot set)
+    unsigned int pad2;
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -121,6 +123,17 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ int prefix_in_ballot(unsigned long long b)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+}
+
+// Histogram index of a user.  The per-user counters K1 adds to are NOT laid out in user order: 32 consecutive users
+// would share one 128-byte line, and the atomics of popular neighbours (ids handed out together, a popularity-sorted id
+// space) then serialise on that line as if they hit one address.  Transposed instead: user u -> (u mod 32) * T + u / 32,
+// T = ceil(U / 32), so consecutive users sit T counters apart.  K2 reads the histogram through the same map and
+// writes the per-user counts the callers see in plain user order.
+__device__ __forceinline__ int hist_index(int u, int n_users)
+{
+    const int t = (n_users + 31) >> 5;
+    return (u & 31) * t + (u >> 5);
 }
 
 // Row predicate of SURVEY.md §8 a-D:
@@ -240,11 +253,32 @@ __device__ __forceinline__ void stage_rows(bool sel, long long s, int row, int u
 // so for the sparse queries this path is built for nothing is staged, K3 has nothing to scatter and the per-bucket
 // order kernel can run right behind K2.  Only ranks >= kTinyMax (buckets that outgrow 16 rows) take the staged route.
 // direct == nullptr (user tables too large to carry 256 B per user) keeps every row on the staged route.
+// Hot users.  A user who owns a large share of the selected rows (a Zipf head) turns the histogram into same-address
+// atomics, which serialise at ~11 ns each however they are aggregated per wave.  For up to kHotMax such users (the big
+// buckets of the previous scan; the ids travel as kernel arguments, i.e. in SGPRs) the wave-aggregated forms count
+// per BLOCK in LDS instead: a hot row takes its rank inside the block from an LDS counter and is staged with the rank
+// flagged (bit 31), the block adds its per-user totals to counts[] once at the end and records the bases it got, and
+// K3 places the record at offsets[user] + base(block, user) + rank-in-block.  Hot rows never use the direct slots.
+constexpr int kHotMax = 32;
+constexpr int kHotFlag = (int)0x80000000;
+struct HotSet {
+    int n;
+    int user[kHotMax];
+};
+__device__ __forceinline__ int hot_slot_of(const HotSet& hot, int u)
+{
+    int slot = -1;
+#pragma unroll
+    for (int k = 0; k < kHotMax; ++k)
+        if (k < hot.n && u == hot.user[k]) slot = k;
+    return slot;
+}
+
 __device__ __forceinline__ void emit_row(bool sel, long long s, int row, int u, int rank, BktRec* __restrict__ direct,
                                          WaveStage& st, SelRec* __restrict__ out, int* __restrict__ out_rank, int* blk_cursor,
                                          int lane)
 {
-    if (direct && sel && rank < kTinyMax) {
+    if (direct && sel && (unsigned)rank < (unsigned)kTinyMax) { // flagged (hot) ranks are negative: never direct
         BktRec r;
         r.start = s;
         r.idx = row;
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
                 const int uu = (k & 1) ? u[k >> 1].y : u[k >> 1].x;
                 rank[k] = 0;
                 if (p[k]) {
-                    if ((unsigned)uu < (unsigned)n_users) rank[k] = atomicAdd(&counts[uu], 1);
+                    if ((unsigned)uu < (unsigned)n_users) rank[k] = atomicAdd(&counts[hist_index(uu, n_users)], 1);
                     else { atomicAdd(bad_rows, 1u); p[k] = false; }
                 }
             }
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
                     }
                     if (sel_row) {
                         uv = user[r];
-                        if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[uv], 1);
+                        if ((unsigned)uv < (unsigned)n_users) rk = atomicAdd(&counts[hist_index(uv, n_users)], 1);
                         else { atomicAdd(bad_rows, 1u); sel_row = false; }
                     }
                 }
@@ -407,17 +441,20 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct)
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct,
+    HotSet hot, int* __restrict__ blk_hot_base)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
     __shared__ int live_ring[kK1Waves][kLiveRing];
     __shared__ int blk_cursor;
     __shared__ int blk_live;
+    __shared__ int blk_hot_cnt[kHotMax];
     constexpr int kTile = kUnitRows * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; }
+    if (AGG && threadIdx.x < kHotMax) blk_hot_cnt[threadIdx.x] = 0;
     __syncthreads();
 
     const long long c0 = (long long)blockIdx.x * rows_per_block;
@@ -453,13 +490,22 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
         // users) otherwise hammers a few addresses with same-address atomics, which serialise (K1 4.5x slower).
         // The grouping loop is pure ALU (one pass per distinct user in the batch) and runs once per 64 LIVE rows.
         // AGG is chosen by the host when the previous scan saw one bucket holding > 1/64 of the selected rows.
+        // hot users first: rank inside the block from an LDS counter, flagged; they take no part in the grouping below
+        bool hotrow = false;
+        int hot_rank = 0;
+        if constexpr (AGG) {
+            const int hs = p ? hot_slot_of(hot, uv) : -1;
+            hotrow = hs >= 0;
+            if (hotrow) hot_rank = atomicAdd(&blk_hot_cnt[hs], 1) | kHotFlag;
+        }
+        const bool pg = p && !hotrow;
         int grp_leader = lane, grp_prefix = 0, grp_size = 1;
-        unsigned long long todo = AGG ? __ballot(p) : 0ull;
+        unsigned long long todo = AGG ? __ballot(pg) : 0ull;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int u_lead = __shfl(uv, leader, kWave);
-            const unsigned long long same = __ballot(p && uv == u_lead);
-            if (p && uv == u_lead) {
+            const unsigned long long same = __ballot(pg && uv == u_lead);
+            if (pg && uv == u_lead) {
                 grp_leader = leader;
                 grp_prefix = prefix_in_ballot(same);
                 grp_size = __popcll(same);
@@ -467,9 +513,9 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
             todo &= ~same;
         }
         int base = 0;
-        if (p && grp_leader == lane) base = atomicAdd(&counts[uv], grp_size);
+        if (pg && grp_leader == lane) base = atomicAdd(&counts[hist_index(uv, n_users)], grp_size);
         base = __shfl(base, grp_leader, kWave);
-        rk = base + grp_prefix;
+        rk = hotrow ? hot_rank : base + grp_prefix;
         lhead = (lhead + cnt) & (kLiveRing - 1);
         lfill -= cnt;
         emit_row(p, sv, row, uv, rk, direct, st, out, out_rank, &blk_cursor, lane);
@@ -513,6 +559,12 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     if (threadIdx.x == 0) {
         blk_count[blockIdx.x] = blk_cursor;
         add_row_stats(summary, blk_live, 0);
+    }
+    if constexpr (AGG) { // one histogram atomic per (block, hot user); K3 needs the base it returned
+        if ((int)threadIdx.x < hot.n) {
+            const int cnt = blk_hot_cnt[threadIdx.x];
+            blk_hot_base[(long long)blockIdx.x * kHotMax + threadIdx.x] = cnt ? atomicAdd(&counts[hist_index(hot.user[threadIdx.x], n_users)], cnt) : 0;
+        }
     }
 }
 
@@ -631,7 +683,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
-    BktRec* __restrict__ direct)
+    BktRec* __restrict__ direct, HotSet hot, int* __restrict__ blk_hot_base)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -639,12 +691,14 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     __shared__ int blk_cursor;
     __shared__ int blk_live;
     __shared__ int blk_amb;
+    __shared__ int blk_hot_cnt[kHotMax];
     constexpr int kPerLane = 16 / (int)sizeof(KT); // rows per lane per 16-byte load
     constexpr int kRowsPerLoad = kPerLane * kWave;
     constexpr int kTile = kRowsPerLoad * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; }
+    if (AGG && threadIdx.x < kHotMax) blk_hot_cnt[threadIdx.x] = 0;
     __syncthreads();
 
     const long long c0 = (long long)blockIdx.x * rows_per_block;
@@ -694,14 +748,23 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
         }
         nlive += __popcll(__ballot(live));
         namb += __popcll(__ballot(a_valid && a_amb));
-        // wave-aggregated histogram atomics for skewed users (see k_scan_live_first)
+        // hot users: rank inside the block from an LDS counter, flagged (see HotSet); the rest: wave-aggregated
+        // histogram atomics for skewed users (see k_scan_live_first)
+        bool hotrow = false;
+        int hot_rank = 0;
+        if constexpr (AGG) {
+            const int hs = p ? hot_slot_of(hot, uv) : -1;
+            hotrow = hs >= 0;
+            if (hotrow) hot_rank = atomicAdd(&blk_hot_cnt[hs], 1) | kHotFlag;
+        }
+        const bool pg = p && !hotrow;
         int grp_leader = lane, grp_prefix = 0, grp_size = 1;
-        unsigned long long todo = AGG ? __ballot(p) : 0ull;
+        unsigned long long todo = AGG ? __ballot(pg) : 0ull;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int u_lead = __shfl(uv, leader, kWave);
-            const unsigned long long same = __ballot(p && uv == u_lead);
-            if (p && uv == u_lead) {
+            const unsigned long long same = __ballot(pg && uv == u_lead);
+            if (pg && uv == u_lead) {
                 grp_leader = leader;
                 grp_prefix = prefix_in_ballot(same);
                 grp_size = __popcll(same);
@@ -709,7 +772,8 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
             todo &= ~same;
         }
         int base = 0;
-        if (p && grp_leader == lane) base = atomicAdd(&counts[uv], grp_size);
+        if (pg && grp_leader == lane) base = atomicAdd(&counts[hist_index(uv, n_users)], grp_size);
+        if (hotrow) { base = hot_rank; grp_leader = lane; grp_prefix = 0; } // step C adds nothing to a flagged rank
         b_have = true;
         b_p = p;
         b_sv = sv;
@@ -823,6 +887,12 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     if (threadIdx.x == 0) {
         blk_count[blockIdx.x] = blk_cursor;
         add_row_stats(summary, blk_live, blk_amb);
+    }
+    if constexpr (AGG) { // one histogram atomic per (block, hot user); K3 needs the base it returned
+        if ((int)threadIdx.x < hot.n) {
+            const int cnt = blk_hot_cnt[threadIdx.x];
+            blk_hot_base[(long long)blockIdx.x * kHotMax + threadIdx.x] = cnt ? atomicAdd(&counts[hist_index(hot.user[threadIdx.x], n_users)], cnt) : 0;
+        }
     }
 }
 
@@ -1250,8 +1320,33 @@ __device__ __forceinline__ void order_bucket_regs(int n, const BktRec* __restric
     for (int k = 0; k < NS; ++k) res[k] = ki[k];
 }
 
+// One slot of a device-side list for every lane that calls this (call it from inside the branch that selected the
+// lanes): one atomicAdd per wave instead of one per lane — thousands of single appends to one counter serialise.
+__device__ __forceinline__ unsigned wave_list_slot(unsigned int* counter, unsigned take = 1u)
+{
+    const unsigned long long active = __ballot(1);
+    const int leader = __ffsll((long long)active) - 1;
+    // per-lane `take` (tiles of a big bucket): inclusive scan over the active lanes by a loop over them (rare path)
+    unsigned before = 0, total = 0;
+    if (take == 1u && __ballot(take != 1u) == 0) {
+        before = (unsigned)prefix_in_ballot(active);
+        total = (unsigned)__popcll(active);
+    } else {
+        for (unsigned long long m = active; m; m &= m - 1) {
+            const int l = __ffsll((long long)m) - 1;
+            const unsigned t = (unsigned)__shfl((int)take, l, kWave);
+            if (l < lane_id()) before += t;
+            total += t;
+        }
+    }
+    unsigned base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, total);
+    base = (unsigned)__shfl((int)base, leader, kWave);
+    return base + before;
+}
+
 template <int UPT, bool ORDER, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ counts, int n_users,
+__global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
                                                  Segment* __restrict__ seg_list, Segment* __restrict__ small_list,
@@ -1259,7 +1354,8 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
                                                  const BktRec* __restrict__ direct, BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap)
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, HotSet hot,
+                                                 int hot_thr, int* __restrict__ hot_list)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
@@ -1283,17 +1379,11 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     const int u0 = tile * kTileUsers + threadIdx.x * UPT;
     int c[UPT];
     long long tsum = 0;
-    if constexpr (UPT == 8) {
-        if (u0 + 8 <= n_users) {
-            const int4 a = *reinterpret_cast<const int4*>(counts + u0);
-            const int4 b = *reinterpret_cast<const int4*>(counts + u0 + 4);
-            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-        } else {
+    // the histogram is read through hist_index (transposed layout); counts_ord gets the same numbers in user order
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = (u0 + k < n_users) ? counts[u0 + k] : 0;
-        }
-    } else {
-        c[0] = u0 < n_users ? counts[u0] : 0;
+    for (int k = 0; k < UPT; ++k) {
+        c[k] = (u0 + k < n_users) ? counts[hist_index(u0 + k, n_users)] : 0;
+        if (u0 + k < n_users) counts_ord[u0 + k] = c[k];
     }
     unsigned int local_max = 0;
 #pragma unroll
@@ -1319,12 +1409,18 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
         __hip_atomic_store(&tile_pub[tile], kTileReady | ((unsigned long long)tile_max << 31) | (unsigned long long)tile_total,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+    // users of this scan's hot set (block-level histogram in K1): all their rows took the staged route, whatever the
+    // bucket size turns out to be, so they are never read from the direct slots and always listed for K3 + K4
+    bool is_hot[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) is_hot[k] = hot.n > 0 && hot_slot_of(hot, u0 + k) >= 0;
+
     // ORDER: this thread's bucket, ordered in registers while the predecessors' sums arrive.  Buckets of 2..8 rows go
     // through one 8-slot network (all lanes together); the rare 9..16-row bucket would drag its whole wave through the
     // 16-slot network, so those are ranked cooperatively after the offsets are known (below).
     int res[8];
     if constexpr (ORDER) {
-        const int n = c[0];
+        const int n = is_hot[0] ? 0 : c[0]; // a hot user's rows were staged, not stored in its direct slots
         const BktRec* src = direct + (long long)u0 * kTinyMax;
         if (n == 1) res[0] = src[0].idx;
         else if (n >= 2 && n <= 8) order_bucket_regs<8>(n, src, res);
@@ -1367,7 +1463,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             const int n = c[k];
             if constexpr (ORDER) {
                 if (msg) msg_store(msg + u, (int)run);
-                if (n >= 1 && n <= 8) {
+                if (n >= 1 && n <= 8 && !is_hot[k]) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if (i < n) {
@@ -1376,21 +1472,23 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                         }
                 }
             }
-            if (n > kTinyMax) {
+            if (n > kTinyMax || (is_hot[k] && n > 0)) {
                 if constexpr (ORDER) {
                     // the bucket outgrew its direct slots: its first kTinyMax records join the staged ones in bkt
+                    if (!is_hot[k]) {
 #pragma unroll
-                    for (int i = 0; i < kTinyMax; ++i) bkt[run + i] = direct[(long long)u * kTinyMax + i];
+                        for (int i = 0; i < kTinyMax; ++i) bkt[run + i] = direct[(long long)u * kTinyMax + i];
+                    }
                 }
                 if (n <= kSmallMax) {
-                    const unsigned slot = atomicAdd(&summary->n_small, 1u);
+                    const unsigned slot = wave_list_slot(&summary->n_small);
                     Segment sg;
                     sg.pos = run;
                     sg.len = n;
                     sg.flags = 0;
                     small_list[slot] = sg;
                 } else if (n <= kSegMax) {
-                    const unsigned slot = atomicAdd(&summary->n_seg, 1u);
+                    const unsigned slot = wave_list_slot(&summary->n_seg);
                     Segment sg;
                     sg.pos = run;
                     sg.len = n;
@@ -1398,7 +1496,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                     seg_list[slot] = sg;
                 } else {
                     const int tiles = (n + kSegMax - 1) / kSegMax;
-                    const unsigned slot = atomicAdd(&summary->n_seg, (unsigned)tiles);
+                    const unsigned slot = wave_list_slot(&summary->n_seg, (unsigned)tiles);
                     for (int t = 0; t < tiles; ++t) {
                         Segment sg;
                         sg.pos = run + (long long)t * kSegMax;
@@ -1406,8 +1504,12 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                         sg.flags = 1;
                         seg_list[slot + t] = sg;
                     }
-                    big_list[atomicAdd(&summary->n_big, 1u)] = u;
+                    big_list[wave_list_slot(&summary->n_big)] = u;
                 }
+            }
+            if (hot_thr > 0 && n > hot_thr) { // candidate for the next scan's hot set (see HotSet)
+                const unsigned hs = wave_list_slot(&summary->n_hot);
+                if (hs < (unsigned)kHotMax) hot_list[hs] = u;
             }
             run += n;
         }
@@ -1416,7 +1518,24 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
         // buckets of 9..16 rows, one at a time with the whole wave: lane i < n holds record i and counts the records that
         // sort before it; that count is its place.  (`run` was advanced past this thread's bucket above: UPT == 1.)
         const int n_mine = c[0];
-        unsigned long long todo = __ballot(u0 < n_users && n_mine > 8 && n_mine <= kTinyMax);
+        const bool mid = u0 < n_users && n_mine > 8 && n_mine <= kTinyMax && !is_hot[0];
+        unsigned long long todo = __ballot(mid);
+        if (__popcll(todo) > 6) {
+            // many such buckets in this wave (users of similar weight sit together): one pass of the 16-slot network
+            // for all of them beats ranking them one after the other
+            if (mid) {
+                const long long ob = run - n_mine;
+                int r16[kTinyMax];
+                order_bucket_regs<kTinyMax>(n_mine, direct + (long long)u0 * kTinyMax, r16);
+#pragma unroll
+                for (int i = 0; i < kTinyMax; ++i)
+                    if (i < n_mine) {
+                        out_idx[ob + i] = r16[i];
+                        if (msg && ob + i < msg_cap) msg_store(msg + u_pad + 2 + ob + i, r16[i]);
+                    }
+            }
+            todo = 0;
+        }
         while (todo) {
             const int src_lane = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -1477,6 +1596,8 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             out.n_small = __hip_atomic_load(&summary->n_small, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.pad = 0;
             out.amb = amb;
+            out.n_hot = __hip_atomic_load(&summary->n_hot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.pad2 = 0;
             host->s = out;
             __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1492,7 +1613,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
 __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel, const int* __restrict__ sel_rank,
                                                  const int* __restrict__ blk_count, int nb, long long rows_per_block,
                                                  const long long* __restrict__ offsets,
-                                                 BktRec* __restrict__ bkt)
+                                                 BktRec* __restrict__ bkt, HotSet hot, const int* __restrict__ blk_hot_base)
 {
     for (int b = blockIdx.x; b < nb; b += gridDim.x) {
         const long long base = (long long)b * rows_per_block;
@@ -1506,7 +1627,9 @@ __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel,
                 rec = sel[base + i];
                 rank = sel_rank[base + i];
             }
-            const long long pos = offsets[rec.user] + rank;
+            long long pos = offsets[rec.user];
+            if (rank < 0) pos += blk_hot_base[(long long)b * kHotMax + hot_slot_of(hot, rec.user)] + (rank & 0x7FFFFFFF); // hot user: block base + rank in block
+            else pos += rank;
             BktRec out;
             out.start = rec.start;
             out.idx = rec.idx;
@@ -1564,10 +1687,11 @@ __device__ __forceinline__ void sort_bucket_regs(int n, const BktRec* __restrict
 // bucket that outgrew the slots has its first kTinyMax records copied behind offsets[u] in bkt, where K3 puts the rest.
 __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ counts, const long long* __restrict__ offsets,
                                                  BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
-                                                 int* __restrict__ out_idx)
+                                                 int* __restrict__ out_idx, const HotSet& hot)
 {
     const int n = counts[u];
     if (n == 0) return;
+    if (direct && hot.n > 0 && hot_slot_of(hot, u) >= 0) return; // hot user: rows staged, bucket listed for K3 + K4 by K2
     const long long o = offsets[u];
     if (n > kTinyMax) {
         if (direct) {
@@ -1586,10 +1710,10 @@ __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ 
 // K4 (tiny buckets): one thread per user, buckets of <= 16 rows sorted in registers.
 __global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ counts, const long long* __restrict__ offsets,
                                                    int n_users, BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
-                                                   int* __restrict__ out_idx)
+                                                   int* __restrict__ out_idx, HotSet hot)
 {
     const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, direct, out_idx);
+    if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, direct, out_idx, hot);
 }
 
 // K4 (segments): buckets of 513..4096 rows, and the 4096-row tiles of bigger buckets: one 1024-thread block each,

@@ -49,7 +49,8 @@ constexpr size_t kDirectMaxBytes = (size_t)2 << 30; // direct bucket slots (256 
 
 // everything one scan owns
 struct Slot {
-    int* counts = nullptr;         // the span this scan uses: counts[cap_users] | tile_pub[] | ScanCtl | Summary
+    int* counts = nullptr;         // the span this scan uses: histogram (transposed user order, see hist_index) | tile_pub[] | ScanCtl | Summary
+    int* counts_ord = nullptr;     // per-user counts in user order, written by K2: what every consumer after K2 reads
     unsigned long long* tile_pub = nullptr;
     ScanCtl* ctl = nullptr;
     Summary* sum = nullptr;
@@ -62,6 +63,9 @@ struct Slot {
     int* blk_count = nullptr;
     BktRec* bkt = nullptr;
     BktRec* direct = nullptr;      // kTinyMax direct bucket slots per user (nullptr: user table too large, staged route only)
+    int* blk_hot_base = nullptr;   // per (K1 block, hot user): the base its block-level histogram atomic returned
+    int* hot_list = nullptr;       // K2's output: users whose bucket exceeded the hot threshold (<= kHotMax kept)
+    HotSet hot{};                  // hot users of THIS scan (K1 and K3 must agree)
     int* msg = nullptr;            // this scan's result message (caller-owned device memory), or nullptr
     int msg_u_pad = 0;
     long long msg_cap = 0;
@@ -134,6 +138,9 @@ struct pie_ctx {
     bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
     double live_frac = -1;    // live fraction seen by the last finished scan of this table (-1: none yet)
     bool hot_bucket = false;  // the last finished scan had one bucket with > 1/64 of the selected rows
+    HotSet hot{};             // users whose buckets were "big" in a recent scan: block-level histogram in the aggregated forms
+    unsigned hot_seen = 0;    // size of the hot list the set was read from
+    unsigned hot_age = 0;     // finished scans since the set was read
     long long last_m = -1;    // M of the last finished feed scan of this table (-1: none yet)
     int part_shift = -1;      // users per partition = 1 << part_shift (-1: too many users for the fast path)
     int n_parts = 0;
@@ -202,8 +209,8 @@ void free_slots(pie_ctx* c)
     for (Slot& s : c->slot) {
         s.counts = nullptr; s.sum = nullptr;
         s.tile_pub = nullptr; s.ctl = nullptr;
-        dfree(s.offsets); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
-        dfree(s.bkt); dfree(s.direct); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
+        dfree(s.offsets); dfree(s.counts_ord); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
+        dfree(s.bkt); dfree(s.direct); dfree(s.blk_hot_base); dfree(s.hot_list); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
         s.in_flight = s.have_result = false;
     }
     for (char*& sp : c->span) dfree(sp);
@@ -260,7 +267,7 @@ void plan_k1(pie_ctx* c)
 }
 
 // layout of a slot's span (all parts 128-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
-size_t span_counts_bytes(const pie_ctx* c) { return (((size_t)c->cap_users * 4 + 127) / 128) * 128; }
+size_t span_counts_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users + 32) * 4 + 127) / 128) * 128; } // +32: the transposed histogram rounds U up to a multiple of 32
 size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / 256 + 2) * 8 + 127) / 128) * 128; } // sized for the smallest tile shape
 size_t span_parts_bytes() { return (size_t)kPartMax * 4; }
 size_t span_stats_bytes() { return (size_t)kSummaryBytes + (size_t)kStatSlots * sizeof(StatSlot); } // Summary (padded) + the K1 row-statistics slots
@@ -316,10 +323,13 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         c->cap_users = users; // counts_span() below reads it
         for (Slot& s : c->slot) {
             PIE_HIP(c, hipMalloc(&s.offsets, ((size_t)users + 1) * 8));
+            PIE_HIP(c, hipMalloc(&s.counts_ord, ((size_t)users + 1) * 4));
             // +256: K3 fetches a region's first 256 records before it knows the count
             PIE_HIP(c, hipMalloc(&s.sel, (rows + 256) * sizeof(SelRec)));
             PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
+            PIE_HIP(c, hipMalloc(&s.blk_hot_base, (size_t)(max_blocks + 8) * kHotMax * 4));
+            PIE_HIP(c, hipMalloc(&s.hot_list, (size_t)kHotMax * 4));
             PIE_HIP(c, hipMalloc(&s.bkt, rows * sizeof(BktRec)));
             if ((size_t)users * kTinyMax * sizeof(BktRec) <= kDirectMaxBytes) PIE_HIP(c, hipMalloc(&s.direct, (size_t)users * kTinyMax * sizeof(BktRec)));
             PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
@@ -336,6 +346,9 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
     c->live_frac = -1;
     c->hot_bucket = false;
+    c->hot.n = 0;
+    c->hot_seen = 0;
+    c->hot_age = 0;
     c->last_m = -1;
     c->fast_enabled = c->fast_env;
     c->part_shift = -1;
@@ -484,22 +497,24 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
     if (sl.variant & 0x40)                                                                                          \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                            c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                           sl.sel_rank, sl.blk_count, sl.sum, sl.direct);                                           \
+                           sl.sel_rank, sl.blk_count, sl.sum, sl.direct, sl.hot, sl.blk_hot_base);                  \
     else                                                                                                            \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
+                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct, sl.hot, sl.blk_hot_base)
     if (sl.variant & 0x400) { // keyed liveness-first form
 #define PIE_K1K3(UN, AG, NT, PP)                                                                                     \
         do {                                                                                                        \
             if (sl.variant & 0x800)                                                                                 \
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_fkey, c->n, sl.rows_per_block, now, host_fine_key_of(c, now), cutoff, mask, \
-                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct,     \
+                                   sl.hot, sl.blk_hot_base);                                                        \
             else                                                                                                    \
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask,       \
-                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);    \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct,     \
+                                   sl.hot, sl.blk_hot_base);                                                        \
         } while (0)
 #define PIE_K1K(UN, AG, NT)                                                                                          \
         do {                                                                                                        \
@@ -557,7 +572,7 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
 void launch_sort_tiny(pie_ctx* c, Slot& sl, hipStream_t s)
 {
     const int tiny_blocks = (c->n_users + 255) / 256;
-    hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, s, sl.counts, sl.offsets, c->n_users, sl.bkt, sl.direct, sl.out_idx);
+    hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, s, sl.counts_ord, sl.offsets, c->n_users, sl.bkt, sl.direct, sl.out_idx, sl.hot);
 }
 
 // K2 (+ the order of the tiny buckets).  Three shapes: fused (one user per thread; offsets and tiny-bucket order in one
@@ -566,13 +581,16 @@ void launch_sort_tiny(pie_ctx* c, Slot& sl, hipStream_t s)
 constexpr int kOrderMaxTiles = 2048; // fused form: few enough tiles for the all-predecessors look-back
 void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long zero_vec16)
 {
+    // a bucket is "hot" when it holds more than 1/256 of the rows the previous scan selected (and enough of them that
+    // same-address histogram atomics hurt): such users are reported for the next scan's hot set
+    const int hot_thr = (c->last_m >= 65536 && !c->d_qual) ? (int)std::min<long long>(c->last_m / 256, 0x7FFFFFFF) : 0;
     const int ob = c->order_block;
     const int order_tiles = (c->n_users + ob - 1) / ob;
     if (sl.direct && order_tiles <= kOrderMaxTiles && !c->no_fused_order) {
 #define PIE_K2O(B)                                                                                                          \
-    hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,   \
+    hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,   \
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16, \
-                       sl.direct, sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap)
+                       sl.direct, sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap, sl.hot, hot_thr, sl.hot_list)
         if (ob == 256) PIE_K2O(256);
         else if (ob == 512) PIE_K2O(512);
         else PIE_K2O(1024);
@@ -580,9 +598,9 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
         sl.msg_by_k2 = sl.msg != nullptr;
         return;
     }
-    hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, c->n_users, sl.tile_pub, sl.ctl,
+    hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16,
-                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0LL);
+                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0LL, sl.hot, hot_thr, sl.hot_list);
     sl.msg_by_k2 = false;
     if (sl.direct) launch_sort_tiny(c, sl, s);
 }
@@ -630,6 +648,8 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     if ((sl.variant & 0x400) && !c->key_ok) sl.variant = c->k1_live_first; // pinned keyed form without a key column
     // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
     if (!c->k1_pinned && !c->d_qual && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
+    sl.hot.n = 0;
+    if ((sl.variant & 0x44) == 0x44 && !c->d_qual) sl.hot = c->hot; // aggregated forms only; K1 and K3 of this scan share it
     const int plan = (sl.variant & 0x800) ? 3 : (sl.variant & 0x400) ? 2 : (sl.variant & 4) ? 1 : 0;
     sl.k1_blocks = c->plan_blocks[plan];
     sl.rows_per_block = c->plan_rows[plan];
@@ -676,7 +696,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
         unsigned tail_blocks = (unsigned)((c->n_parts + tail_waves - 1) / tail_waves);
         if (tail_blocks > (unsigned)c->n_cus) tail_blocks = (unsigned)c->n_cus;
         hipLaunchKernelGGL(k_tail_partitions, dim3(tail_blocks), dim3(kTailThreads), 0, s, sl.part_cursor, sl.part_rec, c->n_parts,
-                           c->part_shift, c->n_users, sl.counts, sl.offsets, sl.out_idx, sl.sum,
+                           c->part_shift, c->n_users, sl.counts_ord, sl.offsets, sl.out_idx, sl.sum,
                            reinterpret_cast<unsigned int*>(sl.blk_count), zero_span, (long long)(counts_span(c) / 16));
         hipLaunchKernelGGL(k_publish_summary, dim3(1), dim3(256), 0, s, sl.sum, reinterpret_cast<unsigned int*>(sl.blk_count),
                            (int)tail_blocks, sl.h_sum_dev, sl.seq);
@@ -768,6 +788,18 @@ int scan_finish(pie_ctx* c)
         c->last_m = (long long)sl.last.m;
         c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
         c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+        // hot set = the users K2 reported (bucket > 1/256 of the previous M), re-read only when their number changed
+        // or every 64 scans (the read waits for the stream, so it must stay rare); a stale set is still exact
+        const unsigned n_hot = sl.last.n_hot < (unsigned)kHotMax ? sl.last.n_hot : (unsigned)kHotMax;
+        c->hot_age++;
+        if (n_hot == 0) { c->hot.n = 0; c->hot_seen = 0; }
+        else if (n_hot != c->hot_seen || c->hot_age >= 64) {
+            PIE_HIP(c, hipMemcpyAsync(c->hot.user, sl.hot_list, (size_t)n_hot * 4, hipMemcpyDeviceToHost, a));
+            PIE_HIP(c, hipStreamSynchronize(a));
+            c->hot.n = (int)n_hot;
+            c->hot_seen = n_hot;
+            c->hot_age = 0;
+        }
     }
 
     // Without direct slots every record was staged: scatter, then order the tiny buckets.  With them only buckets that
@@ -778,7 +810,7 @@ int scan_finish(pie_ctx* c)
             int scat_blocks = sl.k1_blocks;
             if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
             hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
-                               sl.rows_per_block, sl.offsets, sl.bkt);
+                               sl.rows_per_block, sl.offsets, sl.bkt, sl.hot, sl.blk_hot_base);
         }
         if (!sl.direct) launch_sort_tiny(c, sl, a);
         if (sl.last.n_seg > 0) {
@@ -806,7 +838,7 @@ int scan_finish(pie_ctx* c)
             const unsigned gx = (unsigned)((sl.last.max_count + 255u) / 256u);
             const unsigned gy = sl.last.n_big < 65535u ? sl.last.n_big : 65535u;
             hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, a, sl.big_list,
-                               (int)sl.last.n_big, sl.counts, sl.offsets, w, src, dst, idx_only);
+                               (int)sl.last.n_big, sl.counts_ord, sl.offsets, w, src, dst, idx_only);
             in_bkt = !in_bkt;
         }
     }
@@ -1286,7 +1318,7 @@ int pie_read_results(pie_ctx* c, int32_t* counts_out, int64_t* offsets_out, int3
     hipStream_t a = c->stream;
     const size_t m = (size_t)sl.last.m;
     if (m_out) *m_out = m;
-    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, sl.counts, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, a));
+    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, a));
     if (offsets_out) PIE_HIP(c, hipMemcpyAsync(offsets_out, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, a));
     if (idx_out && m > idx_cap) {
         PIE_HIP(c, hipStreamSynchronize(a));
@@ -1312,7 +1344,7 @@ int pie_result_device_ptrs(pie_ctx* c, void** counts_dev, void** offsets_dev, vo
 {
     if (!c) return PIE_E_INVAL;
     if (!c->res || !c->res->have_result) return fail(c, PIE_E_STATE, "no scan result on this context");
-    if (counts_dev) *counts_dev = c->res->counts;
+    if (counts_dev) *counts_dev = c->res->counts_ord;
     if (offsets_dev) *offsets_dev = c->res->offsets;
     if (idx_dev) *idx_dev = c->res->out_idx;
     return PIE_OK;
@@ -1325,7 +1357,7 @@ int pie_copy_results_device(pie_ctx* c, void* counts_dst, void* offsets_dst, voi
     PIE_HIP(c, hipSetDevice(c->device));
     Slot& sl = *c->res;
     hipStream_t a = c->stream;
-    if (counts_dst) PIE_HIP(c, hipMemcpyAsync(counts_dst, sl.counts, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, a));
+    if (counts_dst) PIE_HIP(c, hipMemcpyAsync(counts_dst, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, a));
     if (offsets_dst)
         PIE_HIP(c, hipMemcpyAsync(offsets_dst, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, a));
     size_t m = (size_t)sl.last.m;
@@ -1509,7 +1541,7 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
     c->d_qual = nullptr;
     if (rc) { cleanup(); return rc; }
     Slot& sl = *c->res;
-    PIE_TRY(hipMemcpyAsync(h_counts.data(), sl.counts, U * 4, hipMemcpyDeviceToHost, s));
+    PIE_TRY(hipMemcpyAsync(h_counts.data(), sl.counts_ord, U * 4, hipMemcpyDeviceToHost, s));
     PIE_TRY(hipStreamSynchronize(s));
     // 4. lay the groups out in first-appearance order
     std::vector<long long> grp_off(order.size() + 1);

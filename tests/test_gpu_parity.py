@@ -352,6 +352,13 @@ def test_zipf_corpus_parity(pie, gpu_ctx, oracle):
     for _ in range(3):
         assert_same(gpu_ctx.scan(now, cutoff), want)
     assert gpu_ctx.stats()["k1_variant"] == 0xCC5
+    # by now the head users form the hot set (block-level histogram, rows staged with block-relative ranks).  A query
+    # that leaves them only a handful of rows still runs with that (stale) hot set once: their small buckets must come
+    # through the staged route too, not from the direct slots
+    for now2 in (oracle.T0_MS + 11 * 3600 * 1000 + 1800 * 1000, oracle.T0_MS + 11 * 3600 * 1000 + 1800 * 1000, now):
+        want2 = oracle.scan(*want_cols, U, now2, cutoff, 0xFFFFFFFF)
+        assert_same(gpu_ctx.scan(now2, cutoff), want2)
+    assert 0 < oracle.scan(*want_cols, U, oracle.T0_MS + 11 * 3600 * 1000 + 1800 * 1000, cutoff, 0xFFFFFFFF)[0][0] <= 4096
 
 
 def test_skewed_users_big_buckets(gpu_ctx, oracle):
