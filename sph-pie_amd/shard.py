@@ -287,3 +287,47 @@ def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device
     merged = np.concatenate(lists) if lists else np.zeros(0, np.int64)
     merged.sort(kind="stable")   # k-way merge of ascending lists; ids are unique
     return merged
+
+
+def gather_archive_queues(local_queue, local_group_of_row, local_to_global_rows, rank, world, device="cpu", group=None):
+    """Multi-GPU form of the archive dispatch queue (the reference's own chain
+    /root/reference/server/storage/sqlProvider.js:758-816): groups are users, the table is sharded by user hash, so every
+    group lives whole on one rank and `pie_archive_queue` on each shard already yields that shard's qualifying groups,
+    each group's rows in table order, groups in order of first appearance WITHIN the shard.  The global queue orders the
+    groups by first appearance in the WHOLE table (Map insertion order, :769-789): one all-gather of the per-rank lists
+    (global row ids + group lengths, padded), then a merge of the groups by the global id of their first row.
+    local_queue: local rows as returned by the shard's archive queue; local_group_of_row: the shard's group (user) column;
+    local_to_global_rows: the shard's row map (ascending).  -> np.int64 array of global rows, identical on every rank."""
+    q = np.asarray(local_queue, np.int64)
+    glob = np.asarray(local_to_global_rows, np.int64)[q]
+    grp = np.asarray(local_group_of_row)[q] if q.size else np.zeros(0, np.int64)
+    # group boundaries inside the local queue: a group's rows are contiguous there
+    starts = np.nonzero(np.r_[True, grp[1:] != grp[:-1]])[0] if q.size else np.zeros(0, np.int64)
+    lens = np.diff(np.r_[starts, q.size]) if q.size else np.zeros(0, np.int64)
+    dev = torch.device(device)
+    dims = torch.tensor([glob.size, lens.size], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
+    cap_rows, cap_groups = int(dims[0]), int(dims[1])
+    msg = torch.full((2 + cap_rows + cap_groups,), -1, dtype=torch.int64, device=dev)
+    msg[0], msg[1] = glob.size, lens.size
+    if glob.size:
+        msg[2:2 + glob.size] = torch.from_numpy(glob).to(dev)
+        msg[2 + cap_rows:2 + cap_rows + lens.size] = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    if world > 1:
+        out = torch.empty(world * msg.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, msg, group=group)
+    else:
+        out = msg
+    out = out.view(world, msg.numel()).cpu().numpy()
+    groups = []   # (global id of the group's first row, its rows)
+    for r in range(world):
+        n_rows, n_groups = int(out[r, 0]), int(out[r, 1])
+        rows_r = out[r, 2:2 + n_rows]
+        lens_r = out[r, 2 + cap_rows:2 + cap_rows + n_groups]
+        at = 0
+        for ln in lens_r:
+            groups.append((int(rows_r[at]), rows_r[at:at + int(ln)]))
+            at += int(ln)
+    groups.sort(key=lambda g: g[0])
+    return np.concatenate([g[1] for g in groups]) if groups else np.zeros(0, np.int64)

@@ -86,6 +86,14 @@ def _worker(rank, world, port, tmp, n, U):
             local = oracle_py.expired_queue(sh["end"], prev, now)
             merged = gather_expired_queues(local, sh["rows"], rank, world)
             assert np.array_equal(merged, oracle_py.expired_queue(cols[1], prev, now).astype(np.int64))
+        # multi-rank archive queue (the reference's group-min chain): groups = users live whole on one rank; the global
+        # queue orders qualifying groups by first appearance in the whole table
+        from sph_pie_amd.shard import gather_archive_queues
+        for now, window in [(T0 - 30 * DAY, 43200000), (T0, 100 * DAY), (T0 - 200 * DAY, 0), (2 ** 62, 1)]:
+            local = oracle_py.archive_queue(sh["start"], sh["end"], sh["user"], sh["n_users"], now, window)
+            merged = gather_archive_queues(local, sh["user"], sh["rows"], rank, world)
+            want = oracle_py.archive_queue(cols[0], cols[1], cols[2], U, now, window).astype(np.int64)
+            assert np.array_equal(merged, want), (now, window, merged[:10], want[:10])
         open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
