@@ -11,12 +11,25 @@ function createFeedService(store, options){
   const opts = options || {};
   const monthsBack = opts.monthsBack === undefined ? 2 : opts.monthsBack;
 
+  // Requests that arrive in the same millisecond, with the same window and discipline filter and no change to the
+  // store in between, see exactly the same table at exactly the same `now`: they share ONE device scan (each still
+  // reads its own slice).  Nothing is ever served from a scan taken at another instant or another state of the store.
+  let last = null;
+  let scansRun = 0;
   function scan(query){
     const q = query || {};
     const now = q.now === undefined ? Date.now() : q.now;
     const cutoff = q.cutoff === undefined ? calendarFeed.getCalendarCutoffTimestamp(monthsBack, now) : q.cutoff;
+    const filter = q.disciplines === undefined ? null : JSON.stringify(q.disciplines);
+    const gen = typeof store.generation === 'function' ? store.generation() : null;
+    if(last !== null && gen !== null && last.gen === gen && last.now === now && last.cutoff === cutoff && last.filter === filter){
+      return last.value;
+    }
     const res = store.scanFeeds({now, cutoff, disciplines: q.disciplines});
-    return {now, cutoff, res};
+    scansRun++;
+    // scanFeeds hands out views of buffers it reuses: the shared result stays valid because any later scan replaces it
+    last = {gen, now, cutoff, filter, value: {now, cutoff, res}};
+    return last.value;
   }
 
   // per-discipline constants of the event object, computed once with the JS mirror of parseCalendarMetadata; a
@@ -121,7 +134,7 @@ function createFeedService(store, options){
     return feeds;
   }
 
-  return {scan, eventsForUser, eventsJsonForUser, icsForUser, allFeeds};
+  return {scan, eventsForUser, eventsJsonForUser, icsForUser, allFeeds, scansRun: () => scansRun};
 }
 
 module.exports = {createFeedService};

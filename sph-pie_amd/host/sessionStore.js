@@ -33,6 +33,7 @@ function createStore(options){
   let pendingEnd = new Map();                      // row -> BigInt new end (touch / delete of resident rows)
   let lastPurge = null;
   let out = null;                                  // scan output arrays, sized lazily
+  let generation = 0;                              // bumped by every change a scan could see (see feedService's scan sharing)
 
   function denseUser(userId){
     let u = userIndex.get(userId);
@@ -78,6 +79,7 @@ function createStore(options){
 
   function forget(row){
     const r = rows[row];
+    generation++;
     if(r.tokenHash !== null){
       rowOfToken.delete(r.tokenHash);
       r.tokenHash = null;
@@ -102,6 +104,7 @@ function createStore(options){
       ? (disciplineConfig.DEFAULT_DISCIPLINE ? disciplineConfig.disciplineIndex(disciplineConfig.DEFAULT_DISCIPLINE.id) : 0)
       : disciplineConfig.disciplineIndex(disciplineId);
     rows.push({tokenHash, userId, user: denseUser(userId), disc, createdAt: now, expiresAt});
+    generation++;
     rowOfToken.set(tokenHash, rows.length - 1);
     return {token, expiresAt};
   }
@@ -131,6 +134,7 @@ function createStore(options){
     const row = rowOfToken.get(existing.tokenHash);
     const newExpires = Date.now() + SESSION_TTL_MS;
     rows[row].expiresAt = newExpires;
+    generation++;
     if(row < uploaded){
       pendingEnd.set(row, BigInt(newExpires));
     }
@@ -233,6 +237,7 @@ function createStore(options){
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,
+    generation: () => generation,
     native, ctx
   };
 }

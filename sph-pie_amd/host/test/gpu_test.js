@@ -211,6 +211,23 @@ function get(port, cookie){
     eq(lead.body.events[0].endTs - lead.body.events[0].startTs, store.SESSION_TTL_MS);
     eq((await get(port, ck(cookies['u-crew']))).body.events.length, 2);
     eq((await get(port, ck(cookies['u-admin']))).body.events.length, 1);
+    // requests at the same instant on an unchanged store share one device scan; a change to the store or the clock does not
+    {
+      const before = feeds.scansRun();
+      await get(port, ck(cookies['u-lead'])); await get(port, ck(cookies['u-crew'])); await get(port, ck(cookies['u-admin']));
+      eq(feeds.scansRun() - before, 0, 'same ms, same store: the scan of the request before them is shared');
+      fakeNow += 1;
+      const again = await get(port, ck(cookies['u-lead']));
+      eq(feeds.scansRun() - before, 1, 'clock moved');
+      eq(again.body, lead.body);
+      const extra = store.createSession('u-lead', 'drones');
+      const more = await get(port, ck(cookies['u-lead']));
+      eq(feeds.scansRun() - before, 2, 'store changed');
+      eq(more.body.events.length, 5);
+      store.deleteSession(extra.token);
+      eq((await get(port, ck(cookies['u-lead']))).body, lead.body);
+      eq(feeds.scansRun() - before, 3);
+    }
     // the same feed as iCalendar text (new route, same auth): one VEVENT per event, same order, UIDs = event ids
     const icsGet = cookie => new Promise((resolve, reject) => {
       http.get({host: '127.0.0.1', port, path: '/api/calendar.ics', headers: cookie ? {cookie} : {}}, res => {
@@ -226,7 +243,7 @@ function get(port, cookie){
     const health = await new Promise((resolve, reject) => {
       http.get({host: '127.0.0.1', port, path: '/api/health'}, res => { let b = ''; res.on('data', c => { b += c; }); res.on('end', () => resolve(JSON.parse(b))); }).on('error', reject);
     });
-    eq([health.status, health.storage, health.scan.rows, health.scan.users], ['ok', 'MI355X HBM columns', 10, 6]);
+    eq([health.status, health.storage, health.scan.rows, health.scan.users], ['ok', 'MI355X HBM columns', 11, 6]);   // 10 sessions + the one created and deleted above (rows are tombstoned, not removed)
     // expiry: 12 h later every session is dead -> 401; the device agrees (no live rows)
     fakeNow = t + store.SESSION_TTL_MS + 10000;
     eq((await get(port, ck(cookies['u-lead']))).status, 401);
