@@ -148,6 +148,10 @@ int pie_scan_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                      size_t *m_out);
+/* One user's feed of the last finished scan: rows idx[offsets[user] .. offsets[user+1]) into idx_out (two small copies
+ * instead of the whole result: the per-request read behind GET /api/calendar, /root/reference/server/index.js:293-302).
+ * *k_out = the feed's length; PIE_E_CAPACITY if it exceeds idx_cap; a user outside [0, U) has an empty feed. */
+int pie_read_user_feed(pie_ctx *ctx, int32_t user, int32_t *idx_out, size_t idx_cap, size_t *k_out);
 /* Device pointers of the last finished scan's results: complete in stream order (pie_ctx_aux_stream) or after
  * pie_synchronize; valid until the next pie_scan_begin. */
 int pie_result_device_ptrs(pie_ctx *ctx, void **counts_dev, void **offsets_dev, void **idx_dev);

@@ -61,6 +61,7 @@ _SIGS = [
     ("pie_scan_begin_packed", C.c_int, [_P, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("pie_scan_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_read_user_feed", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_copy_results_device", C.c_int, [_P, _P, _P, _P, C.c_size_t]),
     ("pie_pack_results_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
@@ -232,6 +233,14 @@ class PieScan:
         m = C.c_size_t(0)
         self._check(self._lib.pie_read_results(self._ctx, _ptr(counts), _ptr(offsets), _ptr(idx), self.n, C.byref(m)))
         return counts, offsets, idx[: m.value].copy()
+
+    def read_user_feed(self, user, cap=None):
+        """Rows of one user's feed from the last finished scan (two small device reads)."""
+        cap = self.n if cap is None else int(cap)
+        out = np.empty(max(cap, 1), np.int32)
+        k = C.c_size_t(0)
+        self._check(self._lib.pie_read_user_feed(self._ctx, int(user), _ptr(out), cap, C.byref(k)))
+        return out[: k.value].copy()
 
     def read_results_into(self, counts_ptr=None, offsets_ptr=None, idx_ptr=None, idx_cap=0):
         """pie_read_results into caller-owned host memory (raw addresses, e.g. of pinned buffers).  -> M."""

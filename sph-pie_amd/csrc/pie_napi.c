@@ -37,6 +37,8 @@
     X(int, pie_set_disciplines, (pie_ctx *, uint64_t, int32_t))                                                     \
     X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
     X(int, pie_fetch_rows, (pie_ctx *, const int32_t *, size_t, int64_t *, int64_t *, int32_t *, int32_t *))        \
+    X(int, pie_scan_device, (pie_ctx *, int64_t, int64_t, size_t *))                                                \
+    X(int, pie_read_user_feed, (pie_ctx *, int32_t, int32_t *, size_t, size_t *))                                   \
     X(int, pie_expired_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_archive_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
@@ -340,6 +342,42 @@ static napi_value fn_scan(napi_env env, napi_callback_info info)
     int rc = p_pie_scan(ctx, now, cutoff, counts, offsets, idx, cap, &m);
     if (rc) return throw_pie(env, ctx, rc);
     return js_int(env, (int64_t)m);
+}
+
+/* scanDevice(ctx, now, cutoff) -> M: the scan with its result left in HBM (read a user's slice with userFeed) */
+static napi_value fn_scan_device(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t now, cutoff;
+    if (!get_i64(env, argv[1], &now) || !get_i64(env, argv[2], &cutoff)) {
+        napi_throw_type_error(env, NULL, "now / cutoff must be finite integers (Number or BigInt)");
+        return NULL;
+    }
+    size_t m = 0;
+    int rc = p_pie_scan_device(ctx, now, cutoff, &m);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)m);
+}
+
+/* userFeed(ctx, user, idx Int32Array) -> k: rows of that user's feed in the last scan, written to idx[0..k) */
+static napi_value fn_user_feed(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t user = 0;
+    size_t cap = 0;
+    int32_t *idx = typed(env, argv[2], napi_int32_array, &cap);
+    if (!get_i64(env, argv[1], &user) || !idx || user < INT32_MIN || user > INT32_MAX) {
+        napi_throw_type_error(env, NULL, "userFeed(ctx, user, Int32Array)");
+        return NULL;
+    }
+    size_t k = 0;
+    int rc = p_pie_read_user_feed(ctx, (int32_t)user, idx, cap, &k);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)k);
 }
 
 /* scanAsync(ctx, now, cutoff, counts, offsets, idx, callback(err, m)) — same scan on the libuv pool */
@@ -746,7 +784,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"open", fn_open}, {"deviceCount", fn_device_count}, {"ctxCreate", fn_ctx_create}, {"ctxDestroy", fn_ctx_destroy},
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
         {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
-        {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
+        {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {

@@ -14,22 +14,38 @@ function createFeedService(store, options){
   // Requests that arrive in the same millisecond, with the same window and discipline filter and no change to the
   // store in between, see exactly the same table at exactly the same `now`: they share ONE device scan (each still
   // reads its own slice).  Nothing is ever served from a scan taken at another instant or another state of the store.
-  let last = null;
+  let last = null;        // the device holds the result of this scan; .full = host copy of every user's feed, if taken
   let scansRun = 0;
-  function scan(query){
+  function key(query){
     const q = query || {};
     const now = q.now === undefined ? Date.now() : q.now;
     const cutoff = q.cutoff === undefined ? calendarFeed.getCalendarCutoffTimestamp(monthsBack, now) : q.cutoff;
     const filter = q.disciplines === undefined ? null : JSON.stringify(q.disciplines);
     const gen = typeof store.generation === 'function' ? store.generation() : null;
-    if(last !== null && gen !== null && last.gen === gen && last.now === now && last.cutoff === cutoff && last.filter === filter){
-      return last.value;
-    }
-    const res = store.scanFeeds({now, cutoff, disciplines: q.disciplines});
+    return {gen, now, cutoff, filter, disciplines: q.disciplines};
+  }
+  const current = k => last !== null && k.gen !== null && last.gen === k.gen && last.now === k.now && last.cutoff === k.cutoff && last.filter === k.filter;
+
+  // whole result on the host (every user's feed): allFeeds and callers that want counts / offsets
+  function scan(query){
+    const k = key(query);
+    if(current(k) && last.full){ return last.full; }
+    const res = store.scanFeeds({now: k.now, cutoff: k.cutoff, disciplines: k.disciplines});
     scansRun++;
     // scanFeeds hands out views of buffers it reuses: the shared result stays valid because any later scan replaces it
-    last = {gen, now, cutoff, filter, value: {now, cutoff, res}};
-    return last.value;
+    last = {gen: k.gen, now: k.now, cutoff: k.cutoff, filter: k.filter, full: {now: k.now, cutoff: k.cutoff, res}};
+    return last.full;
+  }
+
+  // one user's rows: the scan stays in HBM, the request reads its slice (two small copies)
+  function userRows(u, query){
+    const k = key(query);
+    if(!current(k)){
+      store.scanDevice({now: k.now, cutoff: k.cutoff, disciplines: k.disciplines});
+      scansRun++;
+      last = {gen: k.gen, now: k.now, cutoff: k.cutoff, filter: k.filter, full: null};
+    }
+    return store.userFeed(u);
   }
 
   // per-discipline constants of the event object, computed once with the JS mirror of parseCalendarMetadata; a
@@ -50,8 +66,7 @@ function createFeedService(store, options){
   }
 
   // {"events":[...]} as bytes for one slice, by the native serialiser when it covers the rows, else via JSON.stringify
-  function eventsJsonFromSlice(res, lo, hi){
-    const idx = res.idx.subarray(lo, hi);
+  function eventsJsonFromRows(idx){
     const cols = store.fetchRows(idx);
     const table = nativeTable();
     if(table && store.native && typeof store.native.serializeEvents === 'function'){
@@ -68,8 +83,7 @@ function createFeedService(store, options){
 
   // the same slice as iCalendar text (new functionality, see calendarFeed.toICalendar): native writer when it covers
   // the rows, else the JS emitter over the event objects
-  function icsFromSlice(res, lo, hi, dtstamp){
-    const idx = res.idx.subarray(lo, hi);
+  function icsFromRows(idx, dtstamp){
     const cols = store.fetchRows(idx);
     const stamp = dtstamp === undefined ? Date.now() : dtstamp;
     if(store.native && typeof store.native.serializeICal === 'function'){
@@ -88,20 +102,17 @@ function createFeedService(store, options){
   function icsForUser(userId, query, dtstamp){
     const u = store.userIndexOf(userId);
     if(u < 0){ return Buffer.from(calendarFeed.toICalendar([], {dtstamp: dtstamp === undefined ? Date.now() : dtstamp}), 'utf8'); }
-    const {res} = scan(query);
-    return icsFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]), dtstamp);
+    return icsFromRows(userRows(u, query), dtstamp);
   }
 
   // response body bytes for one user's feed
   function eventsJsonForUser(userId, query){
     const u = store.userIndexOf(userId);
     if(u < 0){ return Buffer.from('{"events":[]}'); }
-    const {res} = scan(query);
-    return eventsJsonFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]));
+    return eventsJsonFromRows(userRows(u, query));
   }
 
-  function eventsFromSlice(res, lo, hi){
-    const idx = res.idx.subarray(lo, hi);
+  function eventsFromRows(idx){
     const cols = store.fetchRows(idx);
     const events = [];
     for(let i = 0; i < idx.length; i++){
@@ -111,14 +122,13 @@ function createFeedService(store, options){
     return events;          // already (startTs asc, row asc): the device ordered the bucket
   }
 
-  // events of one user, from a fresh scan
+  // events of one user
   function eventsForUser(userId, query){
     const u = store.userIndexOf(userId);
     if(u < 0){
       return [];
     }
-    const {res} = scan(query);
-    return eventsFromSlice(res, Number(res.offsets[u]), Number(res.offsets[u + 1]));
+    return eventsFromRows(userRows(u, query));
   }
 
   // feeds of every user from ONE scan: Map userId -> events
@@ -128,7 +138,7 @@ function createFeedService(store, options){
     for(let u = 0; u < res.userIds.length; u++){
       const lo = Number(res.offsets[u]), hi = Number(res.offsets[u + 1]);
       if(hi > lo){
-        feeds.set(res.userIds[u], eventsFromSlice(res, lo, hi));
+        feeds.set(res.userIds[u], eventsFromRows(res.idx.subarray(lo, hi)));
       }
     }
     return feeds;

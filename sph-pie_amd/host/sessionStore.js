@@ -199,6 +199,25 @@ function createStore(options){
     return {counts: out.counts, offsets: out.offsets, idx: out.idx.subarray(0, m), m, userIds};
   }
 
+  // the same scan with its result left in HBM; userFeed(u) then reads one user's rows (two small copies).  This is the
+  // per-request path: a request needs one slice, not the counts / offsets / idx of every user.
+  function scanDevice(query){
+    const q = query || {};
+    const now = q.now === undefined ? Date.now() : q.now;
+    const cutoff = q.cutoff === undefined ? END_NONE : q.cutoff;
+    flush();
+    native.setDisciplines(ctx, disciplineConfig.disciplineMask(q.disciplines), disciplineConfig.DISCIPLINES.length);
+    return native.scanDevice(ctx, now, cutoff);
+  }
+  let feedBuf = null;
+  function userFeed(u){
+    if(feedBuf === null || feedBuf.length < rows.length){
+      feedBuf = new Int32Array(Math.max(rows.length, 1));
+    }
+    const k = native.userFeed(ctx, u, feedBuf);
+    return feedBuf.slice(0, k);
+  }
+
   // ordered device queue of rows with prevNow < expiresAt <= now (no change to the host map: purgeExpiredSessions does that)
   function expiredRows(prevNow, now){
     flush();
@@ -233,7 +252,7 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, fetchRows, expiredRows, archivedRows, flush, close,
+    scanFeeds, scanDevice, userFeed, fetchRows, expiredRows, archivedRows, flush, close,
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,

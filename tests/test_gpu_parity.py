@@ -259,6 +259,25 @@ def test_scan_written_message_equals_the_pack_kernel(pie, oracle):
         assert ctx.scan_finish_packed() == (m, True)
 
 
+def test_read_user_feed_is_the_slice(gpu_ctx, oracle, pie):
+    """pie_read_user_feed: one user's rows of the last scan == idx[offsets[u]:offsets[u+1]] of the whole result, for
+    empty, tiny and large feeds; users outside the table have empty feeds; a too-small buffer reports the length."""
+    n, U = 400000, 2000
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 32, 1)
+    u = np.where(np.arange(n) % 7 == 0, 5, u).astype(np.int32)     # one user with a big feed
+    gpu_ctx.load_columns(s, e, u, d, U)
+    gpu_ctx.set_disciplines(ALL, 32)
+    for now in (oracle.T0_MS - 6 * 3600 * 1000, oracle.T0_MS - 40 * DAY):
+        want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+        gpu_ctx.scan_device(now, INT64_MIN)
+        for user in [0, 5, 17, U - 1] + [int(np.argmin(want[0])), int(np.argmax(want[0]))]:
+            assert np.array_equal(gpu_ctx.read_user_feed(user), want[2][want[1][user]:want[1][user + 1]])
+        assert gpu_ctx.read_user_feed(-1).size == 0 and gpu_ctx.read_user_feed(U).size == 0
+        with pytest.raises(pie.PieError) as err:
+            gpu_ctx.read_user_feed(5, cap=3)
+        assert err.value.code == -5   # PIE_E_CAPACITY
+
+
 def test_two_scans_in_flight(pie, oracle):
     """begin(i+1) before finish(i): different queries back to back, results of each finished scan are exact and
     stay readable while the next scan is already queued; a third begin is refused."""
