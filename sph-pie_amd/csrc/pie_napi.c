@@ -37,6 +37,8 @@
     X(int, pie_set_disciplines, (pie_ctx *, uint64_t, int32_t))                                                     \
     X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
     X(int, pie_fetch_rows, (pie_ctx *, const int32_t *, size_t, int64_t *, int64_t *, int32_t *, int32_t *))        \
+    X(int, pie_save_columns, (pie_ctx *, const char *))                                                             \
+    X(int, pie_load_columns_dir, (pie_ctx *, const char *))                                                         \
     X(int, pie_scan_device, (pie_ctx *, int64_t, int64_t, size_t *))                                                \
     X(int, pie_read_user_feed, (pie_ctx *, int32_t, int32_t *, size_t, size_t *))                                   \
     X(int, pie_expired_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
@@ -254,6 +256,34 @@ static napi_value fn_read_columns(napi_env env, napi_callback_info info)
     if (rc) return throw_pie(env, ctx, rc);
     return js_int(env, (int64_t)n);
 }
+
+/* saveColumns(ctx, dir) / loadColumnsDir(ctx, dir) -> {rows, users}: the flat column files of pie_save_columns */
+static napi_value dir_call(napi_env env, napi_callback_info info, int load)
+{
+    ARGS(2)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    char dir[4096];
+    size_t len = 0;
+    if (napi_get_value_string_utf8(env, argv[1], dir, sizeof dir, &len) != napi_ok || len == 0 || len >= sizeof dir - 1) {
+        napi_throw_type_error(env, NULL, "directory path expected");
+        return NULL;
+    }
+    int rc = load ? p_pie_load_columns_dir(ctx, dir) : p_pie_save_columns(ctx, dir);
+    if (rc) return throw_pie(env, ctx, rc);
+    pie_stats st;
+    memset(&st, 0, sizeof st);
+    st.struct_size = sizeof st;
+    rc = p_pie_stats_get(ctx, &st);
+    if (rc) return throw_pie(env, ctx, rc);
+    napi_value out;
+    CHECK(env, napi_create_object(env, &out));
+    napi_set_named_property(env, out, "rows", js_int(env, (int64_t)st.rows));
+    napi_set_named_property(env, out, "users", js_int(env, (int64_t)st.users));
+    return out;
+}
+static napi_value fn_save_columns(napi_env env, napi_callback_info info) { return dir_call(env, info, 0); }
+static napi_value fn_load_columns_dir(napi_env env, napi_callback_info info) { return dir_call(env, info, 1); }
 
 /* setEnd(ctx, rows Int32Array, newEnd BigInt64Array) */
 static napi_value fn_set_end(napi_env env, napi_callback_info info)
@@ -783,7 +813,7 @@ static napi_value init(napi_env env, napi_value exports)
     } table[] = {
         {"open", fn_open}, {"deviceCount", fn_device_count}, {"ctxCreate", fn_ctx_create}, {"ctxDestroy", fn_ctx_destroy},
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
-        {"readColumns", fn_read_columns}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
+        {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
     };

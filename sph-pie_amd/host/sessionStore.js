@@ -11,6 +11,8 @@
 // {userId, createdAt, expiresAt}, kept exact by the row lists the device scans return, so getSession never
 // touches the device.  Mutations are batched and flushed to the device before any scan.
 const crypto = require('crypto');
+const fs = require('fs');
+const path = require('path');
 const disciplineConfig = require('./disciplineConfig');
 const pieNative = require('./pieNative');
 
@@ -245,6 +247,36 @@ function createStore(options){
     return {start: s, end: e, user: u, disc: d};
   }
 
+  // ---- persistence (SURVEY.md 8f-4; the reference keeps sessions in memory only, sessionStore.js:6) -----------------
+  // save(dir): the four column files of pie_save_columns + tokens.json {userIds, tokenHash per row (null = gone),
+  // lastPurge}.  Tokens themselves are never stored, only their sha256 (as in the reference's Map keys, :8-10).
+  function save(dir){
+    flush();
+    native.saveColumns(ctx, dir);
+    const doc = {format: 'pie-tokens', version: 1, rows: rows.length, userIds, tokenHash: rows.map(r => r.tokenHash), lastPurge};
+    fs.writeFileSync(path.join(dir, 'tokens.json'), JSON.stringify(doc));
+  }
+  function restore(dir){
+    if(rows.length !== 0){ throw new Error('restore() needs an empty store'); }
+    const doc = JSON.parse(fs.readFileSync(path.join(dir, 'tokens.json'), 'utf8'));
+    if(doc.format !== 'pie-tokens' || doc.version !== 1){ throw new Error('not a pie-tokens file'); }
+    const loaded = native.loadColumnsDir(ctx, dir);
+    if(loaded.rows !== doc.rows || doc.tokenHash.length !== doc.rows){ throw new Error('tokens.json does not match the column files'); }
+    const n = doc.rows;
+    const s = new BigInt64Array(n), e = new BigInt64Array(n), u = new Int32Array(n), d = new Int32Array(n);
+    if(n > 0){ native.readColumns(ctx, s, e, u, d); }
+    doc.userIds.forEach(id => denseUser(id));
+    for(let i = 0; i < n; i++){
+      const gone = e[i] === END_NONE || doc.tokenHash[i] === null;
+      rows.push({tokenHash: gone ? null : doc.tokenHash[i], userId: userIds[u[i]], user: u[i], disc: d[i],
+        createdAt: Number(s[i]), expiresAt: gone ? 0 : Number(e[i])});
+      if(!gone){ rowOfToken.set(doc.tokenHash[i], i); }
+    }
+    uploaded = n;
+    lastPurge = doc.lastPurge;
+    generation++;
+  }
+
   function close(){
     native.ctxDestroy(ctx);
   }
@@ -252,7 +284,7 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, scanDevice, userFeed, fetchRows, expiredRows, archivedRows, flush, close,
+    scanFeeds, scanDevice, userFeed, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,

@@ -173,6 +173,38 @@ function get(port, cookie){
     store.close();
   }
 
+  // ---- 2b. persistence: save -> close -> restore gives a store that answers like the one that was saved
+  {
+    const os = require('os');
+    const dir = fs.mkdtempSync(path.join(os.tmpdir(), 'pie-store-'));
+    const a = createStore();
+    const toks = [];
+    fakeNow = 1760000000000;
+    for(let i = 0; i < 300; i++){ fakeNow += (i % 5 === 0 ? 0 : 1000 * (1 + i % 7)); toks.push(a.createSession('user-' + (i % 17), ['drones', 'audio', 'video'][i % 3]).token); }
+    fakeNow += 3600 * 1000;
+    a.touchSession(toks[10]); a.touchSession(toks[200]); a.deleteSession(toks[11]); a.deleteSessionsForUser('user-3');
+    fakeNow += 9 * 3600 * 1000;                       // some of the early sessions are now close to expiry, none purged yet
+    a.save(dir);
+    const at = fakeNow + 3 * 3600 * 1000;             // an instant where part of them has expired
+    fakeNow = at;
+    const wantScan = a.scanFeeds({now: at});
+    const wantIdx = Array.from(wantScan.idx), wantCounts = Array.from(wantScan.counts), wantUsers = a.userIds().slice();
+    const wantLive = toks.map(t => { const r = a.getSession(t); return r === null ? null : {userId: r.userId, createdAt: r.createdAt, expiresAt: r.expiresAt}; });
+    a.close();
+    const b = createStore();
+    b.restore(dir);
+    eq(b.userIds(), wantUsers);
+    const gotScan = b.scanFeeds({now: at});
+    eq([Array.from(gotScan.idx), Array.from(gotScan.counts)], [wantIdx, wantCounts], 'restored scan');
+    eq(toks.map(t => { const r = b.getSession(t); return r === null ? null : {userId: r.userId, createdAt: r.createdAt, expiresAt: r.expiresAt}; }), wantLive, 'restored sessions');
+    const fresh = b.createSession('user-1', 'drones');          // the restored table keeps growing
+    eq(b.getSession(fresh.token).userId, 'user-1');
+    eq(b.scanFeeds({now: at}).m, gotScan.m + 1);
+    assert.throws(() => b.restore(dir), /empty store/); checks++;
+    b.close();
+    fs.readdirSync(dir).forEach(f => fs.unlinkSync(path.join(dir, f))); fs.rmdirSync(dir);
+  }
+
   // ---- 3. HTTP seam
   {
     const store = createStore();
