@@ -57,7 +57,8 @@ struct Summary {
     unsigned long long live;    // rows with end > now seen by K1 (drives the choice of K1 variant for the next scan)
     unsigned int n_small;       // entries in the small-segment list (17..256 rows: one wave each)
     unsigned int pad;
-    unsigned long long amb;     // keyed table pass: rows whose liveness key equalled the query's (full `end` compare needed)
+    unsigned long long amb;     // keyed table pass: rows whose liveness key equalled the query's (full `end` compare needed);
+                                // streaming pass: selected rows whose lane neighbour selected a row of the same user
     unsigned int n_hot;         // users whose bucket exceeded the hot threshold (candidates for the next scan's hot set)
     unsigned int pad2;
 };
@@ -305,7 +306,11 @@ __device__ __forceinline__ T stream_load(const T* p)
 //           is output data, not predicate input, so unselected rows never need it
 //   GQ      group-qualified form (archive queue): the row predicate is "row not tombstoned and qual[user] != 0" and the
 //           staged sort key is 0, so the per-bucket order is plain row order
-template <int UNROLL, bool NT, bool LATE_U, bool GQ = false>
+//   AGG     wave-aggregated histogram atomics: in each 64-row slice the lanes of one user form a group and issue ONE
+//           returning atomic.  For tables whose rows are clustered by user (the "best case" order) a dense query
+//           otherwise hammers one counter from all 64 lanes; chosen by the host from the share of selected rows whose
+//           lane neighbour has the same user, which every non-aggregated pass of this kernel counts.
+template <int UNROLL, bool NT, bool LATE_U, bool GQ = false, bool AGG = false>
 __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
@@ -318,12 +323,14 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     __shared__ int stage_rank[kK1Waves][kStage];
     __shared__ int blk_cursor;
     __shared__ int blk_live;
+    __shared__ int blk_dup;
     constexpr int kTile = kUnitRows * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     unsigned int* bad_rows = &summary->bad_rows;
     int nlive = 0; // wave-uniform count of rows with end > now
-    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; }
+    int ndup = 0;  // wave-uniform count of selected rows whose nearest selected lane below holds the same user
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_dup = 0; }
     __syncthreads();
 
     const long long c0 = (long long)blockIdx.x * rows_per_block;
@@ -378,9 +385,33 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
             for (int k = 0; k < 2 * UNROLL; ++k) {
                 const int uu = (k & 1) ? u[k >> 1].y : u[k >> 1].x;
                 rank[k] = 0;
-                if (p[k]) {
-                    if ((unsigned)uu < (unsigned)n_users) rank[k] = atomicAdd(&counts[hist_index(uu, n_users)], 1);
-                    else { atomicAdd(bad_rows, 1u); p[k] = false; }
+                if (p[k] && (unsigned)uu >= (unsigned)n_users) { atomicAdd(bad_rows, 1u); p[k] = false; }
+                if constexpr (AGG) {
+                    int grp_leader = lane, grp_prefix = 0, grp_size = 1;
+                    unsigned long long todo = __ballot(p[k]);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const int u_lead = __shfl(uu, leader, kWave);
+                        const unsigned long long same = __ballot(p[k] && uu == u_lead);
+                        if (p[k] && uu == u_lead) {
+                            grp_leader = leader;
+                            grp_prefix = prefix_in_ballot(same);
+                            grp_size = __popcll(same);
+                        }
+                        todo &= ~same;
+                    }
+                    int base = 0;
+                    if (p[k] && grp_leader == lane) base = atomicAdd(&counts[hist_index(uu, n_users)], grp_size);
+                    rank[k] = __shfl(base, grp_leader, kWave) + grp_prefix;
+                    // reported instead of the neighbour count: selected rows that did NOT need an atomic of their own
+                    ndup += __popcll(__ballot(p[k] && grp_leader != lane));
+                } else {
+                    if (p[k]) rank[k] = atomicAdd(&counts[hist_index(uu, n_users)], 1);
+                    // does the nearest selected lane below this one hold the same user?
+                    const unsigned long long below = __ballot(p[k]) & ((1ull << lane) - 1ull);
+                    const int prev = below ? 63 - __clzll((long long)below) : 0;
+                    const int u_prev = __shfl(uu, prev, kWave);
+                    ndup += __popcll(__ballot(p[k] && below != 0 && uu == u_prev));
                 }
             }
             // phase B: wave-prefix compaction into the LDS ring
@@ -421,10 +452,12 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     }
     if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
     if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    if (lane == 0 && ndup) atomicAdd(&blk_dup, ndup);
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_count[blockIdx.x] = blk_cursor;
-        add_row_stats(summary, blk_live, 0);
+        // the streaming form has no ambiguous keys: the second statistic carries its same-user-neighbour count instead
+        add_row_stats(summary, blk_live, blk_dup);
     }
 }
 

@@ -138,6 +138,7 @@ struct pie_ctx {
     bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
     double live_frac = -1;    // live fraction seen by the last finished scan of this table (-1: none yet)
     bool hot_bucket = false;  // the last finished scan had one bucket with > 1/64 of the selected rows
+    bool clustered = false;   // the last streaming scan found most selected rows next to a row of the same user
     HotSet hot{};             // users whose buckets were "big" in a recent scan: block-level histogram in the aggregated forms
     unsigned hot_seen = 0;    // size of the hot list the set was read from
     unsigned hot_age = 0;     // finished scans since the set was read
@@ -346,6 +347,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
     c->live_frac = -1;
     c->hot_bucket = false;
+    c->clustered = false;
     c->hot.n = 0;
     c->hot_seen = 0;
     c->hot_age = 0;
@@ -542,6 +544,12 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
                            sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct, c->d_qual);
         return;
     }
+    if (sl.variant == 0x43) { // streaming form with wave-aggregated histogram atomics (rows clustered by user)
+        hipLaunchKernelGGL((k_scan_compact<4, true, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
+                           c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
+                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);
+        return;
+    }
     switch (sl.variant & ~0x40) {
     case 0x00: PIE_K1(4, false, false); break;
     case 0x01: PIE_K1(4, true, false); break;
@@ -646,6 +654,8 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
         }
     }
     if ((sl.variant & 0x400) && !c->key_ok) sl.variant = c->k1_live_first; // pinned keyed form without a key column
+    // rows clustered by user + a dense query: the streaming form aggregates its histogram atomics per wave
+    if (!c->k1_pinned && !c->d_qual && sl.variant == 0x03 && c->clustered) sl.variant = 0x43;
     // skewed users (one bucket held > 1/64 of the last scan's selected rows): aggregate the histogram atomics per wave
     if (!c->k1_pinned && !c->d_qual && (sl.variant & 4) && c->hot_bucket) sl.variant |= 0x40;
     sl.hot.n = 0;
@@ -788,6 +798,8 @@ int scan_finish(pie_ctx* c)
         c->last_m = (long long)sl.last.m;
         c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
         c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+        // streaming forms report how many selected rows sat next to (0x03) / shared an atomic with (0x43) a row of the same user
+        if (sl.variant == 0x03 || sl.variant == 0x43) c->clustered = sl.last.m > 4096 && sl.last.amb * 2 > sl.last.m;
         // hot set = the users K2 reported (bucket > 1/256 of the previous M), re-read only when their number changed
         // or every 64 scans (the read waits for the stream, so it must stay rare); a stale set is still exact
         const unsigned n_hot = sl.last.n_hot < (unsigned)kHotMax ? sl.last.n_hot : (unsigned)kHotMax;

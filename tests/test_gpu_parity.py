@@ -112,7 +112,7 @@ def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
     run_both(gpu_ctx, oracle, cols, U, D, oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, 0xAAAAAAAAAAAAAAAA)
 
 
-@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
+@pytest.mark.parametrize("variant", [0x00, 0x01, 0x02, 0x03, 0x43, 0x23, 0x83, 0x04, 0x05, 0x25, 0x85, 0xC5, 0x45,
                                      0x405, 0x425, 0x484, 0x485, 0x4C5, 0xC05, 0xC85, 0xCC5, 0x495, 0xC95, 0xCD5])
 def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
     """Each form of the scan kernel (streaming / late-user / liveness-first, nt on/off, unroll 2/4/8) pinned
@@ -148,6 +148,25 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         assert ctx.stats()["k1_variant"] == 0x485 and ctx.stats()["live"] == n   # 2-byte key: `now` is below the fine key's base
         assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and back to streaming once everything is live
         assert ctx.stats()["k1_variant"] == 0x03
+
+
+def test_streaming_form_aggregates_on_user_clustered_tables(pie, oracle):
+    """Rows clustered by user + a dense query: the streaming form notices that most selected rows sit next to a row of
+    the same user and switches to wave-aggregated histogram atomics (0x43); on a randomly ordered table it does not, and
+    it switches back when the table stops being clustered.  Same bytes throughout."""
+    with pie.PieScan(0) as ctx:
+        n, U, D = 600000, 2000, 32
+        now = oracle.T0_MS - 100 * DAY                       # ~83 % of the rows live: streaming form
+        for flags, want_form in ((2, 0x43), (0, 0x03)):
+            s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, flags)
+            ctx.load_columns(s, e, u, d, U)
+            ctx.set_disciplines(ALL, D)
+            want = oracle.scan(s, e, u, d, U, now, INT64_MIN, 0xFFFFFFFF)
+            forms = []
+            for _ in range(3):
+                assert_same(ctx.scan(now, INT64_MIN), want)
+                forms.append(ctx.stats()["k1_variant"])
+            assert forms == [0x03, want_form, want_form]
 
 
 def test_partition_overflow_reruns_on_the_general_path(pie, oracle, monkeypatch):
