@@ -181,6 +181,8 @@ class ShardedFeeds:
         t.issued = True
         b.busy[p] = True
         if not self.collective:
+            if self.cuda and not t.ready:     # the pack kernel runs on the scan's stream: order the copy behind it
+                torch.cuda.current_stream(self.device).wait_event(b.ev_packed[p])
             b.out[p].copy_(b.msg[p])
             return
         if self.cuda:

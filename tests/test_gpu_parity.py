@@ -217,11 +217,11 @@ def test_partitioned_path_parity(pie, oracle, monkeypatch):
 
 def test_bucket_routes_by_user_table_size(pie, oracle):
     """Three routes to the per-user buckets, chosen by the size of the user table: fused offsets + order kernel over the
-    direct bucket slots (<= 524 288 users), direct slots with separate kernels (up to 8 M users), staged records + scatter
+    direct bucket slots (<= 1 048 576 users), direct slots with separate kernels (up to 8 M users), staged records + scatter
     (beyond).  Sparse and dense queries (buckets of 0..16 rows and of hundreds) give the oracle's bytes on each."""
     n = 1 << 20
     with pie.PieScan(0) as ctx:
-        for U in (1, 300, 100000, 524288, 524289, 9000000):
+        for U in (1, 300, 100000, 1048576, 1048577, 9000000):
             flags = 1 if U > 1000 else 0
             s, e, u, d = oracle.gen(SEED + U, n, 0, n, U, 32, flags)
             ctx.load_columns(s, e, u, d, U)
@@ -295,6 +295,35 @@ def test_read_user_feed_is_the_slice(gpu_ctx, oracle, pie):
         with pytest.raises(pie.PieError) as err:
             gpu_ctx.read_user_feed(5, cap=3)
         assert err.value.code == -5   # PIE_E_CAPACITY
+
+
+def test_sharded_feeds_driver_on_the_device(pie, oracle):
+    """shard.ShardedFeeds over HipShardBackend on one rank (no process group): capacity negotiation, the pipelined
+    run_steps with scan-written messages, a query that outgrows the message (collective re-negotiation path) and the
+    synchronous form — offsets and rows of every feed equal the oracle's."""
+    import torch
+    from sph_pie_amd.shard import HipShardBackend, ShardedFeeds
+    n, U, D = 1 << 20, 5000, 32
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        feeds = ShardedFeeds(HipShardBackend(ctx, torch.device("cuda", 0)), 0, 1, U)
+        sparse = (oracle.T0_MS - 6 * 3600 * 1000, INT64_MIN)
+        dense = (oracle.T0_MS - 60 * DAY, INT64_MIN)
+
+        def check(res, query):
+            want = oracle.scan(s, e, u, d, U, query[0], query[1], 0xFFFFFFFF)
+            m = want[2].size
+            assert int(res["lengths"][0]) == m
+            assert np.array_equal(res["offsets"][0].cpu().numpy(), want[1].astype(np.int32))
+            assert np.array_equal(res["rows"][0].cpu().numpy()[:m], want[2])
+
+        check(feeds.run_steps(7, *sparse), sparse)
+        check(feeds.scan_and_gather(*sparse), sparse)
+        assert feeds.run_steps(4, *dense) is None          # outgrew the negotiated capacity: raised, nothing lost
+        check(feeds.run_steps(4, *dense), dense)
+        check(feeds.run_steps(3, *sparse), sparse)
 
 
 def test_two_scans_in_flight(pie, oracle):

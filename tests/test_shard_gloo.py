@@ -39,6 +39,24 @@ class OracleBackend:
         return m
 
 
+class DirectOracleBackend(OracleBackend):
+    """Stand-in for the GPU backend's second contract: the scan writes its message into the buffer handed to scan_begin
+    and scan_finish_packed returns (M, ready)."""
+    direct_message = True
+
+    def scan_begin(self, now, cutoff, dst=None, u_pad=0, cap=0):
+        self.pending = getattr(self, "pending", [])
+        self.pending.append((now, cutoff, dst, u_pad, cap))
+
+    def scan_finish_packed(self, dst, u_pad, cap):
+        now, cutoff, own_dst, own_pad, own_cap = self.pending.pop(0)
+        self.q = (now, cutoff)
+        if own_dst is None:                       # begun without a buffer (the capacity probe): pack into the one given
+            return OracleBackend.scan_finish_packed(self, dst, u_pad, cap), False
+        assert own_dst is dst and own_pad == u_pad and own_cap == cap
+        return OracleBackend.scan_finish_packed(self, own_dst, own_pad, own_cap), True
+
+
 def _worker(rank, world, port, tmp, n, U):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -53,7 +71,8 @@ def _worker(rank, world, port, tmp, n, U):
         shards = partition_by_user_hash(*cols, U, world)
         sh = shards[rank]
         mask = 0x55555555
-        feeds = ShardedFeeds(OracleBackend(oracle_py, sh, mask), rank, world, sh["n_users"])
+        backend_cls = DirectOracleBackend if os.environ.get("PIE_TEST_DIRECT_BACKEND") == "1" else OracleBackend
+        feeds = ShardedFeeds(backend_cls(oracle_py, sh, mask), rank, world, sh["n_users"])
         queries = [(T0 - 6 * 3600 * 1000, T0 - 61 * DAY), (INT64_MIN, INT64_MIN), (T0 - 100 * DAY, T0 - 61 * DAY)]
         # pipelined use: submit step i+1 before collecting step i (the second query outgrows the negotiated
         # capacity on purpose, so the resubmit path runs too)
@@ -99,9 +118,12 @@ def _worker(rank, world, port, tmp, n, U):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,U", [(20000, 37), (3000, 5)])
-def test_sharded_feeds_world2_gloo(tmp_path, oracle, n, U):
-    port = 29500 + (os.getpid() % 2000) + (n % 7)
+@pytest.mark.parametrize("n,U,direct", [(20000, 37, False), (3000, 5, False), (20000, 37, True)])
+def test_sharded_feeds_world2_gloo(tmp_path, oracle, monkeypatch, n, U, direct):
+    """world 2 over gloo; `direct` = the backend contract of the GPU path (the scan writes the message it is handed at
+    scan_begin, two scans queued ahead of the gathers, three rotating buffer sets)."""
+    monkeypatch.setenv("PIE_TEST_DIRECT_BACKEND", "1" if direct else "0")
+    port = 29500 + (os.getpid() % 2000) + (n % 7) + (11 if direct else 0)
     mp.spawn(_worker, args=(2, port, str(tmp_path), n, U), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
