@@ -60,7 +60,7 @@ struct Summary {
     unsigned long long amb;     // keyed table pass: rows whose liveness key equalled the query's (full `end` compare needed);
                                 // streaming pass: selected rows whose lane neighbour selected a row of the same user
     unsigned int n_hot;         // users whose bucket exceeded the hot threshold (candidates for the next scan's hot set)
-    unsigned int pad2;
+    unsigned int n_over;        // listed buckets with staged records (outgrew the direct slots / hot user / no slots): K3 needed
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -250,10 +250,16 @@ __device__ __forceinline__ void stage_rows(bool sel, long long s, int row, int u
 }
 
 // Direct bucket slots.  A selected row whose rank inside its user's bucket (the value its histogram atomic returned) is
-// below kTinyMax goes straight to direct[user * kTinyMax + rank]: a fixed-capacity bucket per user that needs no offsets,
-// so for the sparse queries this path is built for nothing is staged, K3 has nothing to scatter and the per-bucket
-// order kernel can run right behind K2.  Only ranks >= kTinyMax (buckets that outgrow 16 rows) take the staged route.
-// direct == nullptr (user tables too large to carry 256 B per user) keeps every row on the staged route.
+// below the slot capacity goes straight to direct[(user << shift) + rank]: a fixed-capacity bucket per user that needs no
+// offsets, so nothing is staged for it and K3 has nothing to scatter.  The capacity is 16 (the size the fused K2 orders
+// in registers) until a scan finds buckets that outgrow it; the host then grows it (powers of two up to kSmallMax, the
+// size one wave orders) so that dense queries skip the staging + scatter pass as well.  Only ranks >= capacity take the
+// staged route.  p == nullptr (user tables too large to carry the slots) keeps every row on the staged route.
+struct DirectSlots {
+    BktRec* p;
+    int shift; // capacity per user = 1 << shift
+};
+__device__ __forceinline__ BktRec* slots_of(const DirectSlots& d, int u) { return d.p + ((long long)u << d.shift); }
 // Hot users.  A user who owns a large share of the selected rows (a Zipf head) turns the histogram into same-address
 // atomics, which serialise at ~11 ns each however they are aggregated per wave.  For up to kHotMax such users (the big
 // buckets of the previous scan; the ids travel as kernel arguments, i.e. in SGPRs) the wave-aggregated forms count
@@ -275,16 +281,16 @@ __device__ __forceinline__ int hot_slot_of(const HotSet& hot, int u)
     return slot;
 }
 
-__device__ __forceinline__ void emit_row(bool sel, long long s, int row, int u, int rank, BktRec* __restrict__ direct,
+__device__ __forceinline__ void emit_row(bool sel, long long s, int row, int u, int rank, const DirectSlots& direct,
                                          WaveStage& st, SelRec* __restrict__ out, int* __restrict__ out_rank, int* blk_cursor,
                                          int lane)
 {
-    if (direct && sel && (unsigned)rank < (unsigned)kTinyMax) { // flagged (hot) ranks are negative: never direct
+    if (direct.p && sel && (unsigned)rank < (1u << direct.shift)) { // flagged (hot) ranks are negative: never direct
         BktRec r;
         r.start = s;
         r.idx = row;
         r.pad = 0;
-        direct[(long long)u * kTinyMax + rank] = r;
+        slots_of(direct, u)[rank] = r;
         sel = false;
     }
     stage_rows(sel, s, row, u, rank, st, out, out_rank, blk_cursor, lane);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct,
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, DirectSlots direct,
     const unsigned char* __restrict__ qual = nullptr)
 {
     static_assert(!(GQ && LATE_U), "the group-qualified predicate needs the user column up front");
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_live_first(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
-    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, BktRec* __restrict__ direct,
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, DirectSlots direct,
     HotSet hot, int* __restrict__ blk_hot_base)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
-    BktRec* __restrict__ direct, HotSet hot, int* __restrict__ blk_hot_base)
+    DirectSlots direct, HotSet hot, int* __restrict__ blk_hot_base)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -1386,9 +1392,9 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                                                  int* __restrict__ big_list,
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
-                                                 const BktRec* __restrict__ direct, BktRec* __restrict__ bkt,
+                                                 DirectSlots direct, BktRec* __restrict__ bkt,
                                                  int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, HotSet hot,
-                                                 int hot_thr, int* __restrict__ hot_list)
+                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
@@ -1454,7 +1460,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     int res[8];
     if constexpr (ORDER) {
         const int n = is_hot[0] ? 0 : c[0]; // a hot user's rows were staged, not stored in its direct slots
-        const BktRec* src = direct + (long long)u0 * kTinyMax;
+        const BktRec* src = slots_of(direct, u0);
         if (n == 1) res[0] = src[0].idx;
         else if (n >= 2 && n <= 8) order_bucket_regs<8>(n, src, res);
     }
@@ -1505,20 +1511,26 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                         }
                 }
             }
-            if (n > kTinyMax || (is_hot[k] && n > 0)) {
-                if constexpr (ORDER) {
-                    // the bucket outgrew its direct slots: its first kTinyMax records join the staged ones in bkt
-                    if (!is_hot[k]) {
-#pragma unroll
-                        for (int i = 0; i < kTinyMax; ++i) bkt[run + i] = direct[(long long)u * kTinyMax + i];
-                    }
+            // buckets K2 does not order itself: more than kTinyMax rows (without ORDER: every bucket that is not read from
+            // the direct slots by k_sort_tiny), and every bucket of a hot user
+            const bool listed = n > kTinyMax || (is_hot[k] && n > 0);
+            if (listed) {
+                // whole bucket still in its direct slots?  then the wave that orders it reads it from there (flags bit 1,
+                // the user id above it) and nothing of it was staged; otherwise its direct part joins the staged rest in bkt
+                const int dcap = 1 << direct.shift;
+                const bool in_direct = direct.p && !is_hot[k] && n <= dcap;
+                if (!in_direct) {
+                    // listed for k_copy_direct (a wave per bucket moves the direct part behind offsets[u] in bkt); the
+                    // count also tells the host that staged records exist, i.e. that K3 has work
+                    const unsigned os = wave_list_slot(&summary->n_over);
+                    over_list[os] = (direct.p && !is_hot[k]) ? u : -1;
                 }
                 if (n <= kSmallMax) {
                     const unsigned slot = wave_list_slot(&summary->n_small);
                     Segment sg;
                     sg.pos = run;
                     sg.len = n;
-                    sg.flags = 0;
+                    sg.flags = in_direct ? ((u << 2) | 2) : 0;
                     small_list[slot] = sg;
                 } else if (n <= kSegMax) {
                     const unsigned slot = wave_list_slot(&summary->n_seg);
@@ -1559,7 +1571,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             if (mid) {
                 const long long ob = run - n_mine;
                 int r16[kTinyMax];
-                order_bucket_regs<kTinyMax>(n_mine, direct + (long long)u0 * kTinyMax, r16);
+                order_bucket_regs<kTinyMax>(n_mine, slots_of(direct, u0), r16);
 #pragma unroll
                 for (int i = 0; i < kTinyMax; ++i)
                     if (i < n_mine) {
@@ -1578,7 +1590,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             BktRec r;
             r.start = INT64_MAX;
             r.idx = INT32_MAX;
-            if (lane < nb) r = direct[(long long)ub * kTinyMax + lane];
+            if (lane < nb) r = slots_of(direct, ub)[lane];
             int before = 0;
             for (int j = 0; j < nb; ++j) {
                 const long long sj = __shfl(r.start, j, kWave);
@@ -1630,7 +1642,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             out.pad = 0;
             out.amb = amb;
             out.n_hot = __hip_atomic_load(&summary->n_hot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.pad2 = 0;
+            out.n_over = __hip_atomic_load(&summary->n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             host->s = out;
             __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1669,6 +1681,25 @@ __global__ __launch_bounds__(256) void k_scatter(const SelRec* __restrict__ sel,
             out.pad = 0;
             bkt[pos] = out;
         }
+    }
+}
+
+// Buckets that outgrew their direct slots: the records that did fit (ranks below the capacity) move behind offsets[u] in
+// bkt, where K3 puts the staged rest.  One wave per listed bucket, coalesced 16-byte copies.  (-1 entries: buckets with
+// nothing in the slots — hot users, tables without slots.)
+__global__ __launch_bounds__(256) void k_copy_direct(const int* __restrict__ over_list, const Summary* __restrict__ summary,
+                                                     DirectSlots direct, const long long* __restrict__ offsets,
+                                                     BktRec* __restrict__ bkt)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned n_over = summary->n_over;
+    const int dcap = 1 << direct.shift;
+    for (unsigned w = blockIdx.x * 4 + wave; w < n_over; w += gridDim.x * 4) {
+        const int u = over_list[w];
+        if (u < 0) continue;
+        const BktRec* src = slots_of(direct, u);
+        BktRec* dst = bkt + offsets[u];
+        for (int i = lane; i < dcap; i += kWave) dst[i] = src[i];
     }
 }
 
@@ -1719,21 +1750,14 @@ __device__ __forceinline__ void sort_bucket_regs(int n, const BktRec* __restrict
 // With direct slots the bucket is read from direct[u * kTinyMax ...] (src) and written to out_idx[offsets[u] ...]; a
 // bucket that outgrew the slots has its first kTinyMax records copied behind offsets[u] in bkt, where K3 puts the rest.
 __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                 BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
+                                                 BktRec* __restrict__ bkt, const DirectSlots& direct,
                                                  int* __restrict__ out_idx, const HotSet& hot)
 {
     const int n = counts[u];
-    if (n == 0) return;
-    if (direct && hot.n > 0 && hot_slot_of(hot, u) >= 0) return; // hot user: rows staged, bucket listed for K3 + K4 by K2
+    if (n == 0 || n > kTinyMax) return; // larger buckets were listed by K2 for the wave / block sorts
+    if (hot.n > 0 && hot_slot_of(hot, u) >= 0) return; // hot user: rows staged, bucket listed for K3 + K4 by K2
     const long long o = offsets[u];
-    if (n > kTinyMax) {
-        if (direct) {
-#pragma unroll
-            for (int k = 0; k < kTinyMax; ++k) bkt[o + k] = direct[(long long)u * kTinyMax + k];
-        }
-        return;
-    }
-    const BktRec* src = direct ? direct + (long long)u * kTinyMax : bkt + o;
+    const BktRec* src = direct.p ? slots_of(direct, u) : bkt + o;
     if (n == 1) { out_idx[o] = src[0].idx; return; }
     if (n <= 8) sort_bucket_regs<8>(n, src, out_idx + o);
     else sort_bucket_regs<16>(n, src, out_idx + o);
@@ -1742,7 +1766,7 @@ __device__ __forceinline__ void sort_tiny_bucket(int u, const int* __restrict__ 
 // K4b: one block per segment (<= kSegMax rows): bitonic sort of (start, idx) in LDS.
 // K4 (tiny buckets): one thread per user, buckets of <= 16 rows sorted in registers.
 __global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                   int n_users, BktRec* __restrict__ bkt, const BktRec* __restrict__ direct,
+                                                   int n_users, BktRec* __restrict__ bkt, DirectSlots direct,
                                                    int* __restrict__ out_idx, HotSet hot)
 {
     const int u = blockIdx.x * 256 + threadIdx.x;
@@ -1826,7 +1850,7 @@ __device__ __forceinline__ void sort2_inlane_step(long long (&ks)[EPL], int (&ki
 }
 
 template <int EPL>
-__device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec* __restrict__ bkt, int* __restrict__ out_idx,
+__device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec* __restrict__ src, int* __restrict__ out_idx,
                                                   int lane)
 {
     constexpr int P = EPL * 64;
@@ -1838,7 +1862,7 @@ __device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec
         BktRec r;
         r.start = INT64_MAX;
         r.idx = INT32_MAX;
-        if (i < sg.len) r = bkt[sg.pos + i];
+        if (i < sg.len) r = src[i];
         ks[e] = r.start;
         ki[e] = r.idx;
     }
@@ -1873,15 +1897,17 @@ __device__ __forceinline__ void wave_sort_segment(const Segment sg, const BktRec
 }
 
 __global__ __launch_bounds__(256) void k_sort_small(const Segment* __restrict__ small_list, const Summary* __restrict__ summary,
-                                                    const BktRec* __restrict__ bkt, int* __restrict__ out_idx)
+                                                    const BktRec* __restrict__ bkt, DirectSlots direct, int* __restrict__ out_idx)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned n_small = summary->n_small;
     for (unsigned w = blockIdx.x * 4 + wave; w < n_small; w += gridDim.x * 4) {
         const Segment sg = small_list[w];
-        if (sg.len <= 128) wave_sort_segment<2>(sg, bkt, out_idx, lane);
-        else if (sg.len <= 256) wave_sort_segment<4>(sg, bkt, out_idx, lane);
-        else wave_sort_segment<8>(sg, bkt, out_idx, lane);
+        // flags bit 1: the whole bucket still sits in its user's direct slots (user id in the bits above); else behind pos in bkt
+        const BktRec* src = (sg.flags & 2) ? slots_of(direct, sg.flags >> 2) : bkt + sg.pos;
+        if (sg.len <= 128) wave_sort_segment<2>(sg, src, out_idx, lane);
+        else if (sg.len <= 256) wave_sort_segment<4>(sg, src, out_idx, lane);
+        else wave_sort_segment<8>(sg, src, out_idx, lane);
     }
 }
 

@@ -65,6 +65,7 @@ struct Slot {
     BktRec* direct = nullptr;      // kTinyMax direct bucket slots per user (nullptr: user table too large, staged route only)
     int* blk_hot_base = nullptr;   // per (K1 block, hot user): the base its block-level histogram atomic returned
     int* hot_list = nullptr;       // K2's output: users whose bucket exceeded the hot threshold (<= kHotMax kept)
+    int* over_list = nullptr;      // K2's output: buckets with staged records (user id, or -1 when nothing sits in its direct slots)
     HotSet hot{};                  // hot users of THIS scan (K1 and K3 must agree)
     int* msg = nullptr;            // this scan's result message (caller-owned device memory), or nullptr
     int msg_u_pad = 0;
@@ -137,6 +138,8 @@ struct pie_ctx {
     int k1_live_first = 0x85; // liveness-first form (unroll 8, nontemporal), chosen when few rows are live
     bool k1_pinned = false;   // PIE_K1_VARIANT given: no adaptation
     double live_frac = -1;    // live fraction seen by the last finished scan of this table (-1: none yet)
+    int dshift = 4;           // log2 of the direct-slot capacity per user (16 .. kSmallMax); grown when scans outgrow it
+    int dshift_want = 4;      // capacity the last finished scan asked for (applied at the next pie_scan_begin with nothing in flight)
     bool hot_bucket = false;  // the last finished scan had one bucket with > 1/64 of the selected rows
     bool clustered = false;   // the last streaming scan found most selected rows next to a row of the same user
     HotSet hot{};             // users whose buckets were "big" in a recent scan: block-level histogram in the aggregated forms
@@ -198,6 +201,8 @@ void dfree(T*& p)
     p = nullptr;
 }
 
+DirectSlots direct_of(const pie_ctx* c, const Slot& sl);
+
 // scans in flight are the last n_flight slots handed out; this is the older one
 Slot* oldest_in_flight(pie_ctx* c)
 {
@@ -211,7 +216,7 @@ void free_slots(pie_ctx* c)
         s.counts = nullptr; s.sum = nullptr;
         s.tile_pub = nullptr; s.ctl = nullptr;
         dfree(s.offsets); dfree(s.counts_ord); dfree(s.sel); dfree(s.sel_rank); dfree(s.blk_count);
-        dfree(s.bkt); dfree(s.direct); dfree(s.blk_hot_base); dfree(s.hot_list); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
+        dfree(s.bkt); dfree(s.direct); dfree(s.blk_hot_base); dfree(s.hot_list); dfree(s.over_list); dfree(s.out_idx); dfree(s.seg_list); dfree(s.small_list); dfree(s.big_list); dfree(s.part_rec); s.part_cursor = nullptr;
         s.in_flight = s.have_result = false;
     }
     for (char*& sp : c->span) dfree(sp);
@@ -228,6 +233,14 @@ void free_table(pie_ctx* c)
     dfree(c->d_blk_off);
     free_slots(c);
     c->cap_rows = 0; c->cap_users = 0; c->n = 0; c->n_users = 0;
+}
+
+DirectSlots direct_of(const pie_ctx* c, const Slot& sl)
+{
+    DirectSlots d;
+    d.p = sl.direct;
+    d.shift = c->dshift;
+    return d;
 }
 
 int sync_all(pie_ctx* c)
@@ -331,8 +344,10 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_hot_base, (size_t)(max_blocks + 8) * kHotMax * 4));
             PIE_HIP(c, hipMalloc(&s.hot_list, (size_t)kHotMax * 4));
+            PIE_HIP(c, hipMalloc(&s.over_list, ((size_t)users + 16) * 4));
             PIE_HIP(c, hipMalloc(&s.bkt, rows * sizeof(BktRec)));
             if ((size_t)users * kTinyMax * sizeof(BktRec) <= kDirectMaxBytes) PIE_HIP(c, hipMalloc(&s.direct, (size_t)users * kTinyMax * sizeof(BktRec)));
+            c->dshift = c->dshift_want = 4;
             PIE_HIP(c, hipMalloc(&s.out_idx, rows * 4));
             PIE_HIP(c, hipMalloc(&s.seg_list, ((size_t)users + rows / kSegMax + 16) * sizeof(Segment)));
             PIE_HIP(c, hipMalloc(&s.small_list, ((size_t)users + 16) * sizeof(Segment)));
@@ -494,28 +509,28 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
 #define PIE_K1(UN, NT, LU)                                                                                          \
     hipLaunchKernelGGL((k_scan_compact<UN, NT, LU>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct)
+                       sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl))
 #define PIE_K1L(UN, NT)                                                                                             \
     if (sl.variant & 0x40)                                                                                          \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                            c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                           sl.sel_rank, sl.blk_count, sl.sum, sl.direct, sl.hot, sl.blk_hot_base);                  \
+                           sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), sl.hot, sl.blk_hot_base);          \
     else                                                                                                            \
         hipLaunchKernelGGL((k_scan_live_first<UN, NT, false>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start, c->d_end, \
                        c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts, sl.sel, \
-                       sl.sel_rank, sl.blk_count, sl.sum, sl.direct, sl.hot, sl.blk_hot_base)
+                       sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), sl.hot, sl.blk_hot_base)
     if (sl.variant & 0x400) { // keyed liveness-first form
 #define PIE_K1K3(UN, AG, NT, PP)                                                                                     \
         do {                                                                                                        \
             if (sl.variant & 0x800)                                                                                 \
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_fkey, c->n, sl.rows_per_block, now, host_fine_key_of(c, now), cutoff, mask, \
-                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct,     \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), \
                                    sl.hot, sl.blk_hot_base);                                                        \
             else                                                                                                    \
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask,       \
-                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct,     \
+                                   c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), \
                                    sl.hot, sl.blk_hot_base);                                                        \
         } while (0)
 #define PIE_K1K(UN, AG, NT)                                                                                          \
@@ -541,13 +556,13 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
     if (sl.variant == 0x101) { // group-qualified form, used only by pie_archive_queue
         hipLaunchKernelGGL((k_scan_compact<4, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
                            c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
-                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct, c->d_qual);
+                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), c->d_qual);
         return;
     }
     if (sl.variant == 0x43) { // streaming form with wave-aggregated histogram atomics (rows clustered by user)
         hipLaunchKernelGGL((k_scan_compact<4, true, true, false, true>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_start,
                            c->d_end, c->d_user, c->d_disc, c->n, sl.rows_per_block, now, cutoff, mask, c->n_users, sl.counts,
-                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, sl.direct);
+                           sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl));
         return;
     }
     switch (sl.variant & ~0x40) {
@@ -580,7 +595,7 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
 void launch_sort_tiny(pie_ctx* c, Slot& sl, hipStream_t s)
 {
     const int tiny_blocks = (c->n_users + 255) / 256;
-    hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, s, sl.counts_ord, sl.offsets, c->n_users, sl.bkt, sl.direct, sl.out_idx, sl.hot);
+    hipLaunchKernelGGL(k_sort_tiny, dim3(tiny_blocks), dim3(256), 0, s, sl.counts_ord, sl.offsets, c->n_users, sl.bkt, direct_of(c, sl), sl.out_idx, sl.hot);
 }
 
 // K2 (+ the order of the tiny buckets).  Three shapes: fused (one user per thread; offsets and tiny-bucket order in one
@@ -598,7 +613,7 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
 #define PIE_K2O(B)                                                                                                          \
     hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,   \
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16, \
-                       sl.direct, sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap, sl.hot, hot_thr, sl.hot_list)
+                       direct_of(c, sl), sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap, sl.hot, hot_thr, sl.hot_list, sl.over_list)
         if (ob == 256) PIE_K2O(256);
         else if (ob == 512) PIE_K2O(512);
         else PIE_K2O(1024);
@@ -608,7 +623,7 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
     }
     hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16,
-                       (const BktRec*)nullptr, (BktRec*)nullptr, (int*)nullptr, (int*)nullptr, 0, 0LL, sl.hot, hot_thr, sl.hot_list);
+                       direct_of(c, sl), sl.bkt, (int*)nullptr, (int*)nullptr, 0, 0LL, sl.hot, hot_thr, sl.hot_list, sl.over_list);
     sl.msg_by_k2 = false;
     if (sl.direct) launch_sort_tiny(c, sl, s);
 }
@@ -621,6 +636,24 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     if (c->key_rebuild && c->n_flight == 0) {
         int rc = build_keys(c, 0, true);
         if (rc) return rc;
+    }
+    if (c->dshift_want > c->dshift && c->n_flight == 0 && c->slot[0].direct) {
+        // larger direct slots for every user: both slots' arrays are replaced (their contents are per-scan)
+        int rc = sync_all(c);
+        if (rc) return rc;
+        BktRec* fresh[2] = {nullptr, nullptr};
+        const size_t bytes = ((size_t)c->cap_users << c->dshift_want) * sizeof(BktRec);
+        if (hipMalloc(&fresh[0], bytes) == hipSuccess && hipMalloc(&fresh[1], bytes) == hipSuccess) {
+            for (int k = 0; k < 2; ++k) {
+                (void)hipFree(c->slot[k].direct);   // scratch of finished scans only: their results live in out_idx / offsets / counts
+                c->slot[k].direct = fresh[k];
+            }
+            c->dshift = c->dshift_want;
+        } else {
+            (void)hipGetLastError();
+            if (fresh[0]) (void)hipFree(fresh[0]);
+            c->dshift_want = c->dshift; // no room: stay with what there is
+        }
     }
     Slot& sl = c->slot[c->next_slot];
     hipStream_t s = c->stream;
@@ -798,6 +831,14 @@ int scan_finish(pie_ctx* c)
         c->last_m = (long long)sl.last.m;
         c->live_frac = c->n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
         c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+        // buckets outgrew the direct slots: ask for a capacity that holds the largest one (up to what one wave orders),
+        // within the memory budget; applied at the next begin with nothing in flight
+        if (sl.direct && sl.last.n_over > 0 && sl.last.max_count > (1u << c->dshift)) {
+            int want = c->dshift;
+            while (want < 9 && (1u << want) < sl.last.max_count) ++want;
+            while (want > c->dshift && ((size_t)c->cap_users << want) * sizeof(BktRec) > kDirectMaxBytes) --want;
+            if (want > c->dshift_want) c->dshift_want = want;
+        }
         // streaming forms report how many selected rows sat next to (0x03) / shared an atomic with (0x43) a row of the same user
         if (sl.variant == 0x03 || sl.variant == 0x43) c->clustered = sl.last.m > 4096 && sl.last.amb * 2 > sl.last.m;
         // hot set = the users K2 reported (bucket > 1/256 of the previous M), re-read only when their number changed
@@ -814,15 +855,20 @@ int scan_finish(pie_ctx* c)
         }
     }
 
-    // Without direct slots every record was staged: scatter, then order the tiny buckets.  With them only buckets that
-    // outgrew kTinyMax rows have staged records (and exactly then K2 listed work for the kernels below).
-    const bool staged = sl.direct ? (sl.last.n_small + sl.last.n_seg > 0) : (sl.last.m > 0);
+    // Without direct slots every record was staged: scatter, then order the tiny buckets.  With them only the buckets K2
+    // counted in n_over (outgrew the slot capacity, or belong to a hot user) have staged records.
+    const bool staged = sl.direct ? (sl.last.n_over > 0) : (sl.last.m > 0);
     if (sl.last.m > 0) {
         if (staged) {
             int scat_blocks = sl.k1_blocks;
             if (scat_blocks > c->n_cus * 16) scat_blocks = c->n_cus * 16;
             hipLaunchKernelGGL(k_scatter, dim3(scat_blocks), dim3(256), 0, a, sl.sel, sl.sel_rank, sl.blk_count, sl.k1_blocks,
                                sl.rows_per_block, sl.offsets, sl.bkt, sl.hot, sl.blk_hot_base);
+            if (sl.direct) {
+                unsigned cp_blocks = (sl.last.n_over + 3) / 4;
+                if (cp_blocks > (unsigned)c->n_cus * 8) cp_blocks = (unsigned)c->n_cus * 8;
+                hipLaunchKernelGGL(k_copy_direct, dim3(cp_blocks), dim3(256), 0, a, sl.over_list, sl.sum, direct_of(c, sl), sl.offsets, sl.bkt);
+            }
         }
         if (!sl.direct) launch_sort_tiny(c, sl, a);
         if (sl.last.n_seg > 0) {
@@ -832,7 +878,7 @@ int scan_finish(pie_ctx* c)
         if (sl.last.n_small > 0) {
             unsigned small_blocks = (sl.last.n_small + 3) / 4;
             if (small_blocks > (unsigned)c->n_cus * 8) small_blocks = (unsigned)c->n_cus * 8;
-            hipLaunchKernelGGL(k_sort_small, dim3(small_blocks), dim3(256), 0, a, sl.small_list, sl.sum, sl.bkt, sl.out_idx);
+            hipLaunchKernelGGL(k_sort_small, dim3(small_blocks), dim3(256), 0, a, sl.small_list, sl.sum, sl.bkt, direct_of(c, sl), sl.out_idx);
         }
     }
     if (sl.last.n_big > 0) {
