@@ -1,5 +1,7 @@
 """Build recipes for the native pieces (gfx950 only).  Everything is built in-tree so the .so files travel
 to the GPU box with the repo snapshot."""
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -12,11 +14,46 @@ NAPI_ADDON = os.path.join(PKG_DIR, "host", "pie_napi.node")
 ORACLE_LIB = os.path.join(REPO, "oracle", "libpie_oracle.so")
 
 
+def _digest(sources):
+    h = hashlib.sha256()
+    for path in sources:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _newer(target, sources):
+    """Is `target` built from exactly these sources?  Judged by a digest of the sources stored beside the target (copies
+    of the tree — the GPU box gets one — do not keep modification times in order); by modification time without one."""
     if not os.path.exists(target):
         return False
+    side = target + ".srchash"
+    if os.path.exists(side):
+        with open(side) as f:
+            return f.read().strip() == _digest(sources)
     t = os.path.getmtime(target)
     return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _build(target, sources, make_cmd, force):
+    """Build `target` unless it is fresh.  Safe when several processes ask at once (one rank per GPU does): an exclusive
+    lock serialises them, whoever comes second finds the target fresh, and the output appears by an atomic rename."""
+    if not force and _newer(target, sources):
+        return target
+    with open(target + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and _newer(target, sources):
+            return target
+        tmp = "%s.tmp.%d" % (target, os.getpid())
+        try:
+            _run(make_cmd(tmp))
+            os.replace(tmp, target)
+            with open(target + ".srchash", "w") as f:
+                f.write(_digest(sources))
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return target
 
 
 def _run(cmd, cwd=None):
@@ -30,22 +67,16 @@ def build_hip(force=False):
     """hipcc --offload-arch=gfx950 -> sph-pie_amd/libpie_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "pie_scan.hip"), os.path.join(CSRC, "pie_kernels.h"),
             os.path.join(REPO, "include", "pie_scan.h")]
-    if not force and _newer(HIP_LIB, srcs):
-        return HIP_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-          "-o", HIP_LIB, os.path.join(CSRC, "pie_scan.hip")])
-    return HIP_LIB
+    return _build(HIP_LIB, srcs, lambda out: [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+                                              "-o", out, os.path.join(CSRC, "pie_scan.hip")], force)
 
 
 def build_oracle(force=False):
     """gcc -> oracle/libpie_oracle.so (test infrastructure only)."""
     odir = os.path.join(REPO, "oracle")
     srcs = [os.path.join(odir, "pie_oracle.c"), os.path.join(odir, "pie_oracle.h")]
-    if not force and _newer(ORACLE_LIB, srcs):
-        return ORACLE_LIB
-    _run(["make", "-C", odir, "-B", "libpie_oracle.so"])
-    return ORACLE_LIB
+    return _build(ORACLE_LIB, srcs, lambda out: ["make", "-C", odir, "-B", "libpie_oracle.so", "OUT=" + out], force)
 
 
 def build_napi(force=False):
@@ -60,11 +91,9 @@ def build_napi(force=False):
             break
     if inc is None:
         return None
-    if not force and _newer(NAPI_ADDON, [src, os.path.join(REPO, "include", "pie_scan.h")]):
-        return NAPI_ADDON
-    _run(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-Wall", "-I", inc, "-I", os.path.join(REPO, "include"),
-          "-o", NAPI_ADDON, src, "-ldl"])
-    return NAPI_ADDON
+    return _build(NAPI_ADDON, [src, os.path.join(REPO, "include", "pie_scan.h")],
+                  lambda out: ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-Wall", "-I", inc, "-I", os.path.join(REPO, "include"),
+                               "-o", out, src, "-ldl"], force)
 
 
 def build_all(force=False):
