@@ -235,6 +235,7 @@ def main():
                 "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/k1_traffic.json (rocprofv3 PMC, separate passes, gfx950 FETCH_SIZE x2 correction)" if traffic else None,
+                "hbm_gbs_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9) if traffic else None,
                 "hbm_frac_of_peak_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "note": "achieved = algorithmic 24 B/row over kernel time, as the metric defines it; the keyed table pass streams a "
                         "1- or 2-byte liveness key per row and gathers one 16-byte payload record per candidate row, so the HBM "
