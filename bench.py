@@ -91,7 +91,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--js-rows", type=int, default=10 ** 6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=4)
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
+                         "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
     ap.add_argument("--mode", choices=["scan", "expired"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic)")
@@ -180,9 +182,10 @@ def main():
     run_steps(max(args.warmup, 1))
     fence()
     ctx.stats_reset()
-    # HIP events around the scan kernels, on the stream they are launched on; every 4th step carries them (an event
+    # HIP events around the scan kernels, on the stream they are launched on; every 16th step (at least three per run) carries them (an event
     # between two kernels drains the pipeline for a few microseconds, which would inflate ms_per_step)
-    ctx.set_profiling(1 if args.mode == "expired" else args.profile_every)
+    profile_every = args.profile_every if args.profile_every > 0 else max(1, min(16, args.steps // 3))
+    ctx.set_profiling(1 if args.mode == "expired" else profile_every)
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     fence()
@@ -235,8 +238,8 @@ def main():
                 "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/k1_traffic.json (rocprofv3 PMC, separate passes, gfx950 FETCH_SIZE x2 correction)" if traffic else None,
-                "hbm_gbs_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9) if traffic else None,
-                "hbm_frac_of_peak_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "hbm_gbs_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9) if traffic and k1_ms > 0 else None,
+                "hbm_frac_of_peak_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k1_ms > 0 else None,
                 "note": "achieved = algorithmic 24 B/row over kernel time, as the metric defines it; the keyed table pass streams a "
                         "1- or 2-byte liveness key per row and gathers one 16-byte payload record per candidate row, so the HBM "
                         "bytes it moves (traffic, PMC-measured) are far below the algorithmic bytes: judge the kernel by "
