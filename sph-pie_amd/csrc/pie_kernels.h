@@ -88,9 +88,9 @@ constexpr int kStatSlots = 64;
 constexpr int kSummaryBytes = 128; // Summary, padded: the slots start here
 static_assert(sizeof(Summary) <= kSummaryBytes, "Summary outgrew its padded slot");
 __device__ __forceinline__ StatSlot* stat_slots(Summary* s) { return reinterpret_cast<StatSlot*>(reinterpret_cast<char*>(s) + kSummaryBytes); }
-__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb)
+__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb, int bid = (int)blockIdx.x)
 {
-    StatSlot* slot = stat_slots(s) + (blockIdx.x & (kStatSlots - 1));
+    StatSlot* slot = stat_slots(s) + (bid & (kStatSlots - 1));
     if (live) atomicAdd(&slot->live, (unsigned long long)live);
     if (amb) atomicAdd(&slot->amb, (unsigned long long)amb);
 }
@@ -718,11 +718,11 @@ constexpr int kFineKeyRowsPerLoad = 16 * kWave; // 1024 rows (1-byte keys)
 // (C) one batch later again, take the returned ranks and emit — so neither the gather's nor the atomic's round trip
 // stalls the wave: the key stream keeps flowing in between.
 template <int UNROLL, bool AGG, bool NT, class KT, bool PIPE>
-__global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
+__device__ __forceinline__ void scan_keyed_body(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
-    DirectSlots direct, HotSet hot, int* __restrict__ blk_hot_base)
+    DirectSlots direct, const HotSet& hot, int* __restrict__ blk_hot_base, int bid)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     if (AGG && threadIdx.x < kHotMax) blk_hot_cnt[threadIdx.x] = 0;
     __syncthreads();
 
-    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    const long long c0 = (long long)bid * rows_per_block;
     long long c1 = c0 + rows_per_block;
     if (c1 > n) c1 = n;
     SelRec* out = sel + c0;
@@ -924,15 +924,26 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
     __syncthreads();
     if (threadIdx.x == 0) {
-        blk_count[blockIdx.x] = blk_cursor;
-        add_row_stats(summary, blk_live, blk_amb);
+        blk_count[bid] = blk_cursor;
+        add_row_stats(summary, blk_live, blk_amb, bid);
     }
     if constexpr (AGG) { // one histogram atomic per (block, hot user); K3 needs the base it returned
         if ((int)threadIdx.x < hot.n) {
             const int cnt = blk_hot_cnt[threadIdx.x];
-            blk_hot_base[(long long)blockIdx.x * kHotMax + threadIdx.x] = cnt ? atomicAdd(&counts[hist_index(hot.user[threadIdx.x], n_users)], cnt) : 0;
+            blk_hot_base[(long long)bid * kHotMax + threadIdx.x] = cnt ? atomicAdd(&counts[hist_index(hot.user[threadIdx.x], n_users)], cnt) : 0;
         }
     }
+}
+
+template <int UNROLL, bool AGG, bool NT, class KT, bool PIPE>
+__global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
+    const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
+    long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
+    SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
+    DirectSlots direct, HotSet hot, int* __restrict__ blk_hot_base)
+{
+    scan_keyed_body<UNROLL, AGG, NT, KT, PIPE>(pay, end, key, n, rows_per_block, now, now_key, cutoff, mask, n_users, counts, sel, sel_rank,
+                                               blk_count, summary, direct, hot, blk_hot_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ partitioned fast path
@@ -1385,7 +1396,7 @@ __device__ __forceinline__ unsigned wave_list_slot(unsigned int* counter, unsign
 }
 
 template <int UPT, bool ORDER, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
+__device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
                                                  Segment* __restrict__ seg_list, Segment* __restrict__ small_list,
@@ -1393,8 +1404,8 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
                                                  DirectSlots direct, BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, HotSet hot,
-                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list)
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, const HotSet& hot,
+                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
@@ -1409,7 +1420,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (zero_span) {
         const int4 z = make_int4(0, 0, 0, 0);
-        for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < zero_vec16; i += (long long)gridDim.x * BLOCK) zero_span[i] = z;
+        for (long long i = (long long)bid * BLOCK + threadIdx.x; i < zero_vec16; i += (long long)nblk * BLOCK) zero_span[i] = z;
     }
     if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
@@ -1611,7 +1622,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     }
     if constexpr (ORDER) {
         // message tail, by the last tile: off[u] = M for the padding users n_users .. u_pad, then the M word
-        if (msg && tile == (int)gridDim.x - 1) {
+        if (msg && tile == nblk - 1) {
             __syncthreads();
             const long long m_all = total_s;
             for (int u = n_users + threadIdx.x; u <= u_pad + 1; u += BLOCK) msg_store(msg + u, (int)m_all);
@@ -1624,7 +1635,7 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int is_last;
-    if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == gridDim.x - 1 && host) ? 1 : 0;
+    if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == (unsigned)nblk - 1u && host) ? 1 : 0;
     __syncthreads();
     if (is_last && threadIdx.x < 64) {
         unsigned long long live = 0, amb = 0;
@@ -1646,6 +1657,88 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
             host->s = out;
             __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+template <int UPT, bool ORDER, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
+                                                 unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
+                                                 long long* __restrict__ offsets,
+                                                 Segment* __restrict__ seg_list, Segment* __restrict__ small_list,
+                                                 int* __restrict__ big_list,
+                                                 Summary* __restrict__ summary, HostSummary* __restrict__ host,
+                                                 unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
+                                                 DirectSlots direct, BktRec* __restrict__ bkt,
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, HotSet hot,
+                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list)
+{
+    offsets_body<UPT, ORDER, BLOCK>(counts, counts_ord, n_users, tile_pub, ctl, offsets, seg_list, small_list, big_list, summary, host, seq, zero_span, zero_vec16, direct, bkt, out_idx, msg, u_pad, msg_cap, hot, hot_thr, hot_list, over_list, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------ K1(i+1) + K2(i) in one launch
+//
+// With two scans in flight, K2 of scan i does not have to sit between two table passes: its inputs are complete when
+// K1(i) is, and nothing K1(i+1) touches depends on it (each K2 zeroes the histogram span of the scan AFTER the next).
+// So the launch that runs the table pass of scan i+1 carries K2(i) in its first n_tail blocks: the latency-bound chain
+// (ticket, look-back, summary hand-off) runs beside the stream of the next pass instead of in front of it.
+template <class KT>
+struct KeyedArgs {
+    const PayRec* pay;
+    const long long* end;
+    const KT* key;
+    long long n, rows_per_block, now;
+    unsigned now_key;
+    long long cutoff;
+    unsigned long long mask;
+    int n_users;
+    int* counts;
+    SelRec* sel;
+    int* sel_rank;
+    int* blk_count;
+    Summary* summary;
+    DirectSlots direct;
+    HotSet hot;
+    int* blk_hot_base;
+};
+struct OffsetsArgs {
+    const int* counts;
+    int* counts_ord;
+    int n_users;
+    unsigned long long* tile_pub;
+    ScanCtl* ctl;
+    long long* offsets;
+    Segment* seg_list;
+    Segment* small_list;
+    int* big_list;
+    Summary* summary;
+    HostSummary* host;
+    unsigned long long seq;
+    int4* zero_span;
+    long long zero_vec16;
+    DirectSlots direct;
+    BktRec* bkt;
+    int* out_idx;
+    int* msg;
+    int u_pad;
+    long long msg_cap;
+    HotSet hot;
+    int hot_thr;
+    int* hot_list;
+    int* over_list;
+    int n_tail; // blocks [0, n_tail) of the launch do K2 (256 users each), the rest the table pass
+};
+
+template <int UNROLL, bool NT, class KT>
+__global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<KT> a, OffsetsArgs t)
+{
+    if ((int)blockIdx.x < t.n_tail) {
+        offsets_body<1, true, kK1Threads>(t.counts, t.counts_ord, t.n_users, t.tile_pub, t.ctl, t.offsets, t.seg_list, t.small_list,
+                                          t.big_list, t.summary, t.host, t.seq, t.zero_span, t.zero_vec16, t.direct, t.bkt, t.out_idx,
+                                          t.msg, t.u_pad, t.msg_cap, t.hot, t.hot_thr, t.hot_list, t.over_list, (int)blockIdx.x, t.n_tail);
+    } else {
+        scan_keyed_body<UNROLL, false, NT, KT, false>(a.pay, a.end, a.key, a.n, a.rows_per_block, a.now, a.now_key, a.cutoff, a.mask,
+                                                      a.n_users, a.counts, a.sel, a.sel_rank, a.blk_count, a.summary, a.direct, a.hot,
+                                                      a.blk_hot_base, (int)blockIdx.x - t.n_tail);
     }
 }
 

@@ -67,6 +67,8 @@ struct Slot {
     int* hot_list = nullptr;       // K2's output: users whose bucket exceeded the hot threshold (<= kHotMax kept)
     int* over_list = nullptr;      // K2's output: buckets with staged records (user id, or -1 when nothing sits in its direct slots)
     HotSet hot{};                  // hot users of THIS scan (K1 and K3 must agree)
+    bool k2_pending = false;       // K1 is queued, K2 is not yet: it rides in the next scan's launch or is launched by finish
+    int4* zero_span = nullptr;     // the histogram span this scan's K2 zeroes (the one the scan after the next will use)
     int* msg = nullptr;            // this scan's result message (caller-owned device memory), or nullptr
     int msg_u_pad = 0;
     long long msg_cap = 0;
@@ -122,6 +124,7 @@ struct pie_ctx {
     bool key_rebuild = false;   // ... and a rebuild may help: done at the next pie_scan_begin with nothing in flight
     bool keyed_enabled = true;  // PIE_K1_KEYED=0 turns the keyed form off
     int order_block = 512;       // threads (= users) per block of the fused K2 + order kernel (PIE_ORDER_BLOCK: 256 / 512 / 1024)
+    bool no_ride = false;        // PIE_K2_RIDE=0: K2 never rides in the next scan's launch (A/B runs)
     bool no_fused_order = false; // PIE_FUSED_ORDER=0: K2 and the tiny-bucket order as two kernels (A/B runs)
     int k1_keyed = 0xC85;       // keyed liveness-first form (bit 0x400; 0x800: the 1-byte fine key where the query allows), unroll 8
     long long* d_range = nullptr;
@@ -602,11 +605,17 @@ void launch_sort_tiny(pie_ctx* c, Slot& sl, hipStream_t s)
 // kernel) when buckets have direct slots and the tile count suits the all-predecessors look-back; otherwise the
 // 2048-user tiles, followed by the tiny-bucket kernel right away (direct slots) or after K3 (staged route).
 constexpr int kOrderMaxTiles = 2048; // fused form: few enough tiles for the all-predecessors look-back
+
+// a bucket is "hot" when it holds more than 1/256 of the rows the previous scan selected (and enough of them that
+// same-address histogram atomics hurt): such users are reported for the next scan's hot set
+int hot_threshold(const pie_ctx* c)
+{
+    return (c->last_m >= 65536 && !c->d_qual) ? (int)std::min<long long>(c->last_m / 256, 0x7FFFFFFF) : 0;
+}
+
 void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long zero_vec16)
 {
-    // a bucket is "hot" when it holds more than 1/256 of the rows the previous scan selected (and enough of them that
-    // same-address histogram atomics hurt): such users are reported for the next scan's hot set
-    const int hot_thr = (c->last_m >= 65536 && !c->d_qual) ? (int)std::min<long long>(c->last_m / 256, 0x7FFFFFFF) : 0;
+    const int hot_thr = hot_threshold(c);
     const int ob = c->order_block;
     const int order_tiles = (c->n_users + ob - 1) / ob;
     if (sl.direct && order_tiles <= kOrderMaxTiles && !c->no_fused_order) {
@@ -626,6 +635,51 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
                        direct_of(c, sl), sl.bkt, (int*)nullptr, (int*)nullptr, 0, 0LL, sl.hot, hot_thr, sl.hot_list, sl.over_list);
     sl.msg_by_k2 = false;
     if (sl.direct) launch_sort_tiny(c, sl, s);
+}
+
+// K2 of `tail` can ride in another scan's launch: fused form (direct slots), few enough 256-user tiles
+bool tail_can_ride(const pie_ctx* c, const Slot& tail)
+{
+    const int tiles = (c->n_users + kK1Threads - 1) / kK1Threads;
+    return tail.direct != nullptr && tiles <= kOrderMaxTiles && !c->no_fused_order && !c->no_ride && !tail.fast && !c->d_qual;
+}
+
+// the default keyed forms (no wave aggregation, no pipelining) exist with a tail
+bool keyed_can_carry(const pie_ctx* c, const Slot& sl)
+{
+    (void)c;
+    return (sl.variant & ~0x880) == 0x405 && ((sl.variant & 0xA0) == 0x80 || (sl.variant & 0xA0) == 0x00);
+}
+
+void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, long long now, long long cutoff, unsigned long long mask)
+{
+    OffsetsArgs t;
+    t.counts = tail.counts; t.counts_ord = tail.counts_ord; t.n_users = c->n_users; t.tile_pub = tail.tile_pub; t.ctl = tail.ctl;
+    t.offsets = tail.offsets; t.seg_list = tail.seg_list; t.small_list = tail.small_list; t.big_list = tail.big_list;
+    t.summary = tail.sum; t.host = tail.h_sum_dev; t.seq = tail.seq; t.zero_span = tail.zero_span;
+    t.zero_vec16 = (long long)(counts_span(c) / 16); t.direct = direct_of(c, tail); t.bkt = tail.bkt; t.out_idx = tail.out_idx;
+    t.msg = tail.msg; t.u_pad = tail.msg_u_pad; t.msg_cap = tail.msg_cap; t.hot = tail.hot; t.hot_thr = hot_threshold(c);
+    t.hot_list = tail.hot_list; t.over_list = tail.over_list;
+    t.n_tail = (c->n_users + kK1Threads - 1) / kK1Threads;
+    tail.msg_by_k2 = tail.msg != nullptr;
+    const unsigned grid = (unsigned)(sl.k1_blocks + t.n_tail);
+#define PIE_RIDE(UN, KT, KEYPTR, NOWKEY)                                                                                 \
+    do {                                                                                                                \
+        KeyedArgs<KT> a;                                                                                                \
+        a.pay = c->d_pay; a.end = c->d_end; a.key = KEYPTR; a.n = c->n; a.rows_per_block = sl.rows_per_block; a.now = now; \
+        a.now_key = NOWKEY; a.cutoff = cutoff; a.mask = mask; a.n_users = c->n_users; a.counts = sl.counts; a.sel = sl.sel;  \
+        a.sel_rank = sl.sel_rank; a.blk_count = sl.blk_count; a.summary = sl.sum; a.direct = direct_of(c, sl); a.hot = sl.hot; \
+        a.blk_hot_base = sl.blk_hot_base;                                                                               \
+        if (sl.variant & 1) hipLaunchKernelGGL((k_scan_keyed_with_tail<UN, true, KT>), dim3(grid), dim3(kK1Threads), 0, s, a, t);  \
+        else hipLaunchKernelGGL((k_scan_keyed_with_tail<UN, false, KT>), dim3(grid), dim3(kK1Threads), 0, s, a, t);        \
+    } while (0)
+    const bool un8 = (sl.variant & 0xA0) == 0x80;
+    if (sl.variant & 0x800) {
+        if (un8) PIE_RIDE(8, fkey_t, c->d_fkey, host_fine_key_of(c, now)); else PIE_RIDE(4, fkey_t, c->d_fkey, host_fine_key_of(c, now));
+    } else {
+        if (un8) PIE_RIDE(8, lkey_t, c->d_key, host_key_of(c, now)); else PIE_RIDE(4, lkey_t, c->d_key, host_key_of(c, now));
+    }
+#undef PIE_RIDE
 }
 
 // Head of a scan: K1 and K2 on the stream (plus the tiny-bucket order kernel when buckets have direct slots).  No host wait.
@@ -713,7 +767,10 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
         sl.sum = reinterpret_cast<Summary*>(base + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128);
         c->span_next = (c->span_next + 1) % 3;
     }
-    int4* zero_span = reinterpret_cast<int4*>(c->span[c->span_next]);
+    // K2 (or the fast path's tail) zeroes the span of the scan AFTER the next one: every span is clean again before its
+    // next user starts, and K2 of this scan may run beside the next scan's table pass, which uses span_next
+    int4* zero_span = reinterpret_cast<int4*>(c->span[(c->span_next + 1) % 3]);
+    sl.zero_span = zero_span;
     c->scans_begun++;
     sl.q_now = now;
     sl.q_cutoff = cutoff;
@@ -727,6 +784,12 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
         sl.fast = mean + 6.0 * __builtin_sqrt(mean) + 16.0 <= (double)kPartCap;
     }
     if (sl.fast) {
+        // the fast path's tail zeroes the span the scan in flight still needs for its K2: that K2 goes first
+        Slot& prev = c->slot[c->next_slot ^ 1];
+        if (c->n_flight == 1 && prev.in_flight && prev.k2_pending) {
+            launch_k2(c, prev, s, prev.zero_span, (long long)(counts_span(c) / 16));
+            prev.k2_pending = false;
+        }
         sl.variant = 0x285;
         sl.k1_blocks = c->plan_blocks[1];
         sl.rows_per_block = c->plan_rows[1];
@@ -750,10 +813,23 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
         c->next_slot ^= 1;
         return PIE_OK;
     }
+    // K2 of the scan already in flight (if it is still pending) rides in this scan's launch when both fit the fused
+    // kernel; otherwise it goes first, on its own
+    Slot& other = c->slot[c->next_slot ^ 1];
+    const bool ride = c->n_flight == 1 && other.in_flight && other.k2_pending && tail_can_ride(c, other) && keyed_can_carry(c, sl);
+    if (c->n_flight == 1 && other.in_flight && other.k2_pending && !ride) {
+        launch_k2(c, other, s, other.zero_span, (long long)(counts_span(c) / 16));
+        other.k2_pending = false;
+    }
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e0, s));
-    launch_k1(c, sl, s, now, cutoff, mask);
+    if (ride) {
+        launch_keyed_with_tail(c, sl, other, s, now, cutoff, mask);
+        other.k2_pending = false;
+    } else {
+        launch_k1(c, sl, s, now, cutoff, mask);
+    }
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e1, s));
-    launch_k2(c, sl, s, zero_span, (long long)(counts_span(c) / 16));
+    sl.k2_pending = true; // launched by the next pie_scan_begin (riding) or by pie_scan_finish, whichever comes first
     PIE_HIP(c, hipGetLastError());
     sl.in_flight = true;
     c->n_flight++;
@@ -769,6 +845,11 @@ int scan_finish(pie_ctx* c)
     if (!slp) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
     Slot& sl = *slp;
     hipStream_t a = c->stream;
+    if (sl.k2_pending) { // no later scan took it along
+        launch_k2(c, sl, a, sl.zero_span, (long long)(counts_span(c) / 16));
+        PIE_HIP(c, hipGetLastError());
+        sl.k2_pending = false;
+    }
     sl.in_flight = false;
     c->n_flight--;
     // wait for K2's last block to publish the summary in mapped host memory (no copy node, no event wait);
@@ -1010,6 +1091,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_K1_LIVE_FIRST")) c->k1_live_first = (int)strtol(v, nullptr, 0);
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
+    if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);

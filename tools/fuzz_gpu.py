@@ -88,6 +88,19 @@ while time.time() < t_end:
                 for _ in range(reps):
                     same(ctx.scan(now, cutoff), want, what + " scan now %d cutoff %d" % (now, cutoff))
                     scans += 1
+                if rng.random() < 0.5:   # a chain of scans with two in flight (K2 of one rides in the launch of the next)
+                    chain = []
+                    for _ in range(int(rng.integers(2, 6))):
+                        n2 = now if rng.random() < 0.6 else int(T0 - rng.integers(0, 30 * 3600 * 1000))
+                        chain.append((n2, oracle.scan(s, e, u, d, U, n2, cutoff, m_eff)))
+                    ctx.scan_begin(chain[0][0], cutoff)
+                    for k in range(len(chain)):
+                        if k + 1 < len(chain):
+                            ctx.scan_begin(chain[k + 1][0], cutoff)
+                        if ctx.scan_finish() != chain[k][1][2].size:
+                            raise AssertionError(what + " chained scan %d: M differs" % k)
+                        same(ctx.read_results(), chain[k][1], what + " chained scan %d now %d" % (k, chain[k][0]))
+                        scans += 1
                 if rng.random() < 0.4:   # the scan-written exchange message
                     m = want[2].size
                     u_pad, cap = U + int(rng.integers(0, 5)), int(rng.choice([m, m + 3, max(m // 2, 1)]))
