@@ -637,7 +637,9 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
     if (sl.direct) launch_sort_tiny(c, sl, s);
 }
 
-// K2 of `tail` can ride in another scan's launch: fused form (direct slots), few enough 256-user tiles
+// K2 of `tail` can ride in another scan's launch: fused form (direct slots), few enough 256-user tiles.  (Beside a
+// table pass K2 takes about twice as long, so a caller that wants a scan's summary early should not begin the next scan
+// first; the exchange driver in shard.py does its host work in that window instead.)
 bool tail_can_ride(const pie_ctx* c, const Slot& tail)
 {
     const int tiles = (c->n_users + kK1Threads - 1) / kK1Threads;

@@ -66,21 +66,25 @@ class HipShardBackend:
         return m, False
 
 
+N_SETS = 4
+
+
 class _Buffers:
-    """Three message / gather buffers of one capacity; scan i of a pipelined run uses set i % 3."""
+    """Four message / gather buffer sets of one capacity; scan i of a pipelined run uses set i % 4 (one being written by
+    the scan just begun, one by the scan in flight, one being gathered, one being collected)."""
 
     def __init__(self, world, u_pad, cap, device, cuda):
         self.cap, self.u_pad = cap, u_pad
         L = self.L = u_pad + 2 + cap
-        self.msg = [torch.zeros(L, dtype=torch.int32, device=device) for _ in range(3)]
-        self.out = [torch.zeros(world * L, dtype=torch.int32, device=device) for _ in range(3)]
-        self.len_host = [torch.zeros(world, dtype=torch.int32, pin_memory=cuda) for _ in range(3)]
+        self.msg = [torch.zeros(L, dtype=torch.int32, device=device) for _ in range(N_SETS)]
+        self.out = [torch.zeros(world * L, dtype=torch.int32, device=device) for _ in range(N_SETS)]
+        self.len_host = [torch.zeros(world, dtype=torch.int32, pin_memory=cuda) for _ in range(N_SETS)]
         # strided view of the M word of every rank's message, made once
         self.len_dev = [o.view(world, L)[:, u_pad + 1] for o in self.out]
-        self.busy = [False, False, False]   # a gather that reads msg[p] / writes out[p] has been issued and not collected
+        self.busy = [False] * N_SETS   # a gather that reads msg[p] / writes out[p] has been issued and not collected
         if cuda:
-            self.ev_packed = [torch.cuda.Event() for _ in range(3)]
-            self.ev_done = [torch.cuda.Event() for _ in range(3)]
+            self.ev_packed = [torch.cuda.Event() for _ in range(N_SETS)]
+            self.ev_done = [torch.cuda.Event() for _ in range(N_SETS)]
             # the zero fills above ran on torch's stream; the scans write these buffers from the library's own stream
             torch.cuda.current_stream(device).synchronize()
 
@@ -99,7 +103,7 @@ class ShardedFeeds:
         exchange         issue the all-gather of that message on the side stream (GPU-async)
         collect          wait for the side stream only; hand out the gathered views
     run_steps() keeps two scans queued on the GPU while the host issues and collects gathers, so neither the host work
-    nor the gather sits between two table passes.  Three message / result buffer sets rotate."""
+    nor the gather sits between two table passes.  Four message / result buffer sets rotate."""
 
     def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
@@ -145,10 +149,10 @@ class ShardedFeeds:
             t.bufs, t.parity = None, 0          # first use: a probe scan learns M
             self.backend.scan_begin(now, cutoff)
         else:
-            t.bufs, t.parity = self._buffers(), self.step % 3
+            t.bufs, t.parity = self._buffers(), self.step % N_SETS
             self.step += 1
             if t.bufs.busy[t.parity]:
-                raise RuntimeError("collect() the ticket issued three steps ago before its buffers are used again")
+                raise RuntimeError("collect() the ticket issued four steps ago before its buffers are used again")
             if self.direct:
                 self.backend.scan_begin(now, cutoff, t.bufs.msg[t.parity], self.u_pad, t.bufs.cap)
             else:
@@ -233,33 +237,40 @@ class ShardedFeeds:
                 return res
 
     def run_steps(self, k, now, cutoff):
-        """k steps of the same query, software-pipelined: scan i+1 is queued on the GPU before the host waits for scan i,
-        the gather of step i is issued while scan i+1 runs, and collected one step later.  Every scan begun is finished
-        and every gather collected before returning.
+        """k steps of the same query, software-pipelined.  Per iteration: scan i+1 is queued (its launch carries the offsets
+        kernel of scan i, which also writes scan i's message), then — while that runs — the host issues the gather of
+        step i-1 and collects the gather of step i-2, and only then waits for scan i's summary.  Every scan begun is
+        finished and every gather collected before returning.
         -> last collected result (None if a message overflowed: the capacity has been raised, call again)."""
-        last, flying = None, None
         if k <= 0:
             return None
+        last = None
         if self.cap is None:          # capacity negotiation needs a whole scan of its own
             last = self.scan_and_gather(now, cutoff)
             k -= 1
             if k == 0:
                 return last
-        self.begin(now, cutoff)
         overflow = False
+        finished = None               # ticket of the scan finished in the previous iteration: its gather is issued next
+        flying = None                 # ticket whose gather has been issued and not collected
+        self.begin(now, cutoff)
         for i in range(k):
             if i + 1 < k and not overflow:
-                self.begin(now, cutoff)      # the next table pass is queued right behind this one
-            t = self.finish_and_pack()       # waits for scan i's summary; its message is (being) written
-            self.exchange(t)                 # gather of step i, on the side stream, while scan i+1 runs
-            if flying is not None:           # gather of step i-1: issued a whole scan ago
-                last = self.collect(flying)
-                overflow = overflow or last is None
-            flying = t
+                self.begin(now, cutoff)          # queued right behind scan i
+            if finished is not None:
+                self.exchange(finished)          # gather of step i-1, on the side stream
+            if flying is not None:
+                overflow = (self.collect(flying) is None) or overflow   # gather of step i-2: issued a whole scan ago
+            flying, finished = finished, None
+            finished = self.finish_and_pack()    # scan i's summary (its offsets kernel ran beside scan i+1's table pass)
             if overflow and not self.begun:
                 break
-        last_flying = self.collect(flying)
-        return None if overflow or last_flying is None else last_flying
+        if finished is not None:
+            self.exchange(finished)
+        if flying is not None:
+            overflow = (self.collect(flying) is None) or overflow
+        last = self.collect(finished) if finished is not None else last
+        return None if overflow or last is None else last
 
 
 def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device="cpu", group=None):
