@@ -7,12 +7,14 @@
 // rejected (its dependent loads crawl under a saturated HBM and every cross-queue dependency costs ~15 us:
 // profiles/r01_d_two_stream_timeline.txt).
 // The big per-scan buffers exist twice (two SLOTS) and the small histogram "spans" three times, rotating: K2 of
-// every scan zeroes the span the NEXT scan will use (whose consumers are two scans old), so no memset and no
+// every scan zeroes the span the scan AFTER THE NEXT will use (its last user is two launches old), so no memset and no
 // event sits between kernels — a marker packet between two kernels costs ~6 us here, a plain kernel boundary ~0.
 // pie_scan_begin enqueues K1+K2 and returns; pie_scan_finish spins on the summary that K2's last block writes to
 // mapped host memory, then enqueues K3/K4 sized from it if any bucket needs them.  With begin(i+1) called before
 // finish(i) the stream always holds the next table pass, so the host's round trip is off the critical path:
-//   stream:  K1(i) K2(i) | K1(i+1) K2(i+1) | [K3(i) K4(i)] consumers(i) | K1(i+2) K2(i+2) | ...
+//   stream:  K1(i) | K1(i+1)+K2(i) in one launch | [K3(i) K4(i)] consumers(i) | K1(i+2)+K2(i+1) | ...
+// (K2 of a scan rides in the first blocks of the next scan's table-pass launch; a scan nobody follows gets its K2 from
+// pie_scan_finish).
 // The table carries three derived columns (2-byte and 1-byte liveness keys, 16-byte payload records; pie_kernels.h)
 // that every writer of `end` keeps in step; the scan form is chosen per scan from what the previous scan observed
 // (live fraction, ambiguous keys, hot buckets) — see scan_begin.
