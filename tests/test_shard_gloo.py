@@ -53,7 +53,7 @@ class DirectOracleBackend(OracleBackend):
         self.q = (now, cutoff)
         if own_dst is None:                       # begun without a buffer (the capacity probe): pack into the one given
             return OracleBackend.scan_finish_packed(self, dst, u_pad, cap), False
-        assert own_dst is dst and own_pad == u_pad and own_cap == cap
+        assert own_dst.data_ptr() == dst.data_ptr() and own_pad == u_pad and own_cap == cap
         return OracleBackend.scan_finish_packed(self, own_dst, own_pad, own_cap), True
 
 
@@ -81,6 +81,13 @@ def _worker(rank, world, port, tmp, n, U):
         assert first[0] is not None and torch.equal(first[0]["rows"], first[1]["rows"])
         piped = feeds.run_steps(5, *queries[0])
         assert torch.equal(piped["rows"], first[0]["rows"]) and torch.equal(piped["offsets"], first[0]["offsets"])
+        # several scans per all-gather (direct-message backends): same lists, for batch sizes that do and do not divide k
+        for batch, k in ((3, 7), (4, 4), (2, 1)):
+            feeds.batch = batch
+            got = feeds.run_steps(k, *queries[0])
+            assert torch.equal(got["rows"][:, : first[0]["rows"].shape[1]], first[0]["rows"]) and torch.equal(got["offsets"], first[0]["offsets"])
+            assert torch.equal(got["lengths"], first[0]["lengths"])
+        feeds.batch = 1
         for now, cutoff in queries:
             out = feeds.scan_and_gather(now, cutoff)
             # rebuild global feeds from the gathered buffers and compare with the oracle on the WHOLE table
