@@ -132,9 +132,12 @@ int pie_scan(pie_ctx *ctx, int64_t now, int64_t cutoff, int32_t *counts_out, int
              int32_t *idx_out, size_t idx_cap, size_t *m_out);
 /* Same scan, results left in device memory (for the multi-GPU gather and for benchmarking). */
 int pie_scan_device(pie_ctx *ctx, int64_t now, int64_t cutoff, size_t *m_out);
-/* The same scan in two halves for callers that overlap host work with it: begin enqueues the table pass and the
- * offsets kernel and returns at once; finish waits for the scan's summary (M), enqueues scatter + per-bucket order
- * (and the rare big-bucket merge passes) and returns M.  Results of a finished scan end at the next begin. */
+/* The same scan in two halves for callers that overlap host work with it: begin enqueues the table pass and returns at
+ * once; finish waits for the scan's summary (M), enqueues what is left (scatter + order of buckets that outgrew their
+ * direct slots, the rare big-bucket merge passes) and returns M.  Up to two scans may be in flight: with begin(i+1)
+ * called before finish(i), the offsets + order kernel of scan i runs inside the launch of scan i+1's table pass, so
+ * a steady stream of scans costs one kernel launch each — and the summary of scan i arrives while scan i+1 runs (a
+ * caller that wants it sooner calls finish(i) first).  Results of a finished scan end at the next begin. */
 int pie_scan_begin(pie_ctx *ctx, int64_t now, int64_t cutoff);
 int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
 /* The same pair for the exchange step of a sharded table: the scan also produces its result message
