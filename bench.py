@@ -213,7 +213,7 @@ def main():
             kname = "k_scan_live_first_part"
         if variant & 0x400:
             # with two scans in flight the launch also carries the offsets + order kernel of the scan before
-            rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x880) == 0x405
+            rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
             kname = "k_scan_keyed_with_tail" if rides else "k_scan_keyed"
         if args.mode == "expired":
             kname = "k_expired_stage" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed"

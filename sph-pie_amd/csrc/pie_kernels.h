@@ -1728,7 +1728,7 @@ struct OffsetsArgs {
     int n_tail; // blocks [0, n_tail) of the launch do K2 (256 users each), the rest the table pass
 };
 
-template <int UNROLL, bool NT, class KT>
+template <int UNROLL, bool NT, class KT, bool AGG>
 __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<KT> a, OffsetsArgs t)
 {
     if ((int)blockIdx.x < t.n_tail) {
@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
                                           t.big_list, t.summary, t.host, t.seq, t.zero_span, t.zero_vec16, t.direct, t.bkt, t.out_idx,
                                           t.msg, t.u_pad, t.msg_cap, t.hot, t.hot_thr, t.hot_list, t.over_list, (int)blockIdx.x, t.n_tail);
     } else {
-        scan_keyed_body<UNROLL, false, NT, KT, false>(a.pay, a.end, a.key, a.n, a.rows_per_block, a.now, a.now_key, a.cutoff, a.mask,
+        scan_keyed_body<UNROLL, AGG, NT, KT, false>(a.pay, a.end, a.key, a.n, a.rows_per_block, a.now, a.now_key, a.cutoff, a.mask,
                                                       a.n_users, a.counts, a.sel, a.sel_rank, a.blk_count, a.summary, a.direct, a.hot,
                                                       a.blk_hot_base, (int)blockIdx.x - t.n_tail);
     }

@@ -648,11 +648,11 @@ bool tail_can_ride(const pie_ctx* c, const Slot& tail)
     return tail.direct != nullptr && tiles <= kOrderMaxTiles && !c->no_fused_order && !c->no_ride && !tail.fast && !c->d_qual;
 }
 
-// the default keyed forms (no wave aggregation, no pipelining) exist with a tail
+// the default keyed forms (unroll 8, nontemporal loads, with or without wave aggregation; no pipelining) exist with a tail
 bool keyed_can_carry(const pie_ctx* c, const Slot& sl)
 {
     (void)c;
-    return (sl.variant & ~0x880) == 0x405 && ((sl.variant & 0xA0) == 0x80 || (sl.variant & 0xA0) == 0x00);
+    return (sl.variant & ~0x840) == 0x485;
 }
 
 void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, long long now, long long cutoff, unsigned long long mask)
@@ -667,22 +667,18 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
     t.n_tail = (c->n_users + kK1Threads - 1) / kK1Threads;
     tail.msg_by_k2 = tail.msg != nullptr;
     const unsigned grid = (unsigned)(sl.k1_blocks + t.n_tail);
-#define PIE_RIDE(UN, KT, KEYPTR, NOWKEY)                                                                                 \
+#define PIE_RIDE(KT, KEYPTR, NOWKEY)                                                                                     \
     do {                                                                                                                \
         KeyedArgs<KT> a;                                                                                                \
         a.pay = c->d_pay; a.end = c->d_end; a.key = KEYPTR; a.n = c->n; a.rows_per_block = sl.rows_per_block; a.now = now; \
         a.now_key = NOWKEY; a.cutoff = cutoff; a.mask = mask; a.n_users = c->n_users; a.counts = sl.counts; a.sel = sl.sel;  \
         a.sel_rank = sl.sel_rank; a.blk_count = sl.blk_count; a.summary = sl.sum; a.direct = direct_of(c, sl); a.hot = sl.hot; \
         a.blk_hot_base = sl.blk_hot_base;                                                                               \
-        if (sl.variant & 1) hipLaunchKernelGGL((k_scan_keyed_with_tail<UN, true, KT>), dim3(grid), dim3(kK1Threads), 0, s, a, t);  \
-        else hipLaunchKernelGGL((k_scan_keyed_with_tail<UN, false, KT>), dim3(grid), dim3(kK1Threads), 0, s, a, t);        \
+        if (sl.variant & 0x40) hipLaunchKernelGGL((k_scan_keyed_with_tail<8, true, KT, true>), dim3(grid), dim3(kK1Threads), 0, s, a, t);  \
+        else hipLaunchKernelGGL((k_scan_keyed_with_tail<8, true, KT, false>), dim3(grid), dim3(kK1Threads), 0, s, a, t);   \
     } while (0)
-    const bool un8 = (sl.variant & 0xA0) == 0x80;
-    if (sl.variant & 0x800) {
-        if (un8) PIE_RIDE(8, fkey_t, c->d_fkey, host_fine_key_of(c, now)); else PIE_RIDE(4, fkey_t, c->d_fkey, host_fine_key_of(c, now));
-    } else {
-        if (un8) PIE_RIDE(8, lkey_t, c->d_key, host_key_of(c, now)); else PIE_RIDE(4, lkey_t, c->d_key, host_key_of(c, now));
-    }
+    if (sl.variant & 0x800) PIE_RIDE(fkey_t, c->d_fkey, host_fine_key_of(c, now));
+    else PIE_RIDE(lkey_t, c->d_key, host_key_of(c, now));
 #undef PIE_RIDE
 }
 
