@@ -125,14 +125,14 @@ def _worker(rank, world, port, tmp, n, U):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,U,direct", [(20000, 37, False), (3000, 5, False), (20000, 37, True)])
-def test_sharded_feeds_world2_gloo(tmp_path, oracle, monkeypatch, n, U, direct):
-    """world 2 over gloo; `direct` = the backend contract of the GPU path (the scan writes the message it is handed at
-    scan_begin, two scans queued ahead of the gathers, three rotating buffer sets)."""
+@pytest.mark.parametrize("n,U,direct,world", [(20000, 37, False, 2), (3000, 5, False, 2), (20000, 37, True, 2), (12000, 101, True, 5)])
+def test_sharded_feeds_world2_gloo(tmp_path, oracle, monkeypatch, n, U, direct, world):
+    """world 2 (and 5) over gloo; `direct` = the backend contract of the GPU path (the scan writes the message it is handed
+    at scan_begin, two scans queued ahead of the gathers, rotating buffer sets, several scans per all-gather)."""
     monkeypatch.setenv("PIE_TEST_DIRECT_BACKEND", "1" if direct else "0")
-    port = 29500 + (os.getpid() % 2000) + (n % 7) + (11 if direct else 0)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), n, U), nprocs=2, join=True)
-    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+    port = 29500 + (os.getpid() % 2000) + (n % 7) + (11 if direct else 0) + 3 * world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n, U), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
 
 
 def test_partition_is_a_partition(pie, oracle):
