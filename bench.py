@@ -200,6 +200,17 @@ def main():
         dt = float(t.item())
     st = ctx.stats()
     m = last if not gather else int(last["lengths"][rank])
+    scan_only_ms = None
+    if gather and args.mode == "scan":
+        # scan-only throughput beside scan + gather — the same K steps without the exchange, after the
+        # timed region (not part of value); max over ranks like the headline
+        fence()
+        t1 = time.perf_counter()
+        ctx.scan_pipelined(args.steps, now, cutoff)
+        fence()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        scan_only_ms = float(t.item()) * 1e3 / args.steps
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -232,6 +243,7 @@ def main():
             "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
             "sessions_per_sec": N * world / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "scan_only_ms_per_step": scan_only_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
