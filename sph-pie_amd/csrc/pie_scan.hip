@@ -837,8 +837,9 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     return PIE_OK;
 }
 
-// Tail of the oldest scan in flight: wait for its summary, then scatter + per-bucket order
-// (plus the merge passes of big buckets, sized from the summary).
+// Tail of the oldest scan in flight: launch its K2 if no later scan took it along, wait for its summary, then — only for
+// buckets that outgrew their direct slots — scatter + per-bucket order (plus the merge passes of big buckets, sized from
+// the summary).  Also where the adaptive choices for the next scans are made (scan form, key fit, hot set, slot capacity).
 int scan_finish(pie_ctx* c)
 {
     Slot* slp = oldest_in_flight(c);
