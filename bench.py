@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--js-rows", type=int, default=10 ** 6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-batch", type=int, default=4, help="multi-GPU: scans per all-gather (1 = one gather per scan)")
+    ap.add_argument("--gather-batch", type=int, default=8, help="multi-GPU: scans per all-gather (1 = one gather per scan)")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
                          "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
