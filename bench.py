@@ -77,8 +77,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10 ** 8, help="sessions per GPU (weak scaling)")
     ap.add_argument("--users", type=int, default=10 ** 5, help="users per GPU shard")
     ap.add_argument("--disc", type=int, default=32)
