@@ -1866,55 +1866,118 @@ __global__ __launch_bounds__(256) void k_sort_tiny(const int* __restrict__ count
     if (u < n_users) sort_tiny_bucket(u, counts, offsets, bkt, direct, out_idx, hot);
 }
 
-// K4 (segments): buckets of 513..4096 rows, and the 4096-row tiles of bigger buckets: one 1024-thread block each,
-// bitonic sort of (start, idx) in LDS.  1024 threads because the sort is a chain of up to 78 barrier-separated
-// steps: its latency, not its throughput, is what a skewed table pays (one hot bucket = one block).
+// K4 (segments): buckets of 513..4096 rows, and the 4096-row tiles of bigger buckets: one 1024-thread block each.
+// A bitonic sort whose 78 compare-exchange steps were all LDS + barrier in the first version; its latency (≈59 µs per
+// 4096-row tile) is what a skewed table pays, since one hot bucket = one block.  Now every wave keeps its 256 elements
+// in registers (four per lane): all steps whose partner lies inside the wave's chunk (j < 256: every step of the first
+// eight stages, and the last eight steps of each later stage) run as lane shuffles / in-lane exchanges without a
+// barrier, and only the j >= 256 steps of the last four stages go through LDS: 10 barrier steps + 8 hand-overs.
+template <int EPL, int J>
+__device__ __forceinline__ void sort2_inlane_step(long long (&ks)[EPL], int (&ki)[EPL], int lane, int k); // defined with the wave sort below
+
+template <int EPL>
+__device__ __forceinline__ void wave_stage(long long (&ks)[EPL], int (&ki)[EPL], int lane, int base, int k, int j_from)
+{
+    // steps j = j_from, j_from / 2, ..., 1 of bitonic stage k; element e of this lane has global index base + lane*EPL + e
+    for (int j = j_from; j >= EPL; j >>= 1) { // partner in lane ^ (j / EPL), same slot
+        const int lm = j / EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int g = base + lane * EPL + e;
+            const long long os = __shfl_xor(ks[e], lm, kWave);
+            const int oi = __shfl_xor(ki[e], lm, kWave);
+            const bool keep_min = ((g & j) == 0) == ((g & k) == 0);
+            const bool other_less = key_less(os, oi, ks[e], ki[e]);
+            const bool take = keep_min ? other_less : !other_less;
+            ks[e] = take ? os : ks[e];
+            ki[e] = take ? oi : ki[e];
+        }
+    }
+    // partners inside the lane: the helper derives the direction from (lane_arg * EPL + e) & k, so it is handed the
+    // lane's position in the whole segment (base is a multiple of EPL)
+    const int seg_lane = base / EPL + lane;
+    if constexpr (EPL >= 4) { if (j_from >= 2) sort2_inlane_step<EPL, 2>(ks, ki, seg_lane, k); }
+    if constexpr (EPL >= 2) { if (j_from >= 1) sort2_inlane_step<EPL, 1>(ks, ki, seg_lane, k); }
+}
+
 __global__ __launch_bounds__(1024) void k_sort_segments(const Segment* __restrict__ seg_list, const Summary* __restrict__ summary,
                                                         BktRec* __restrict__ bkt, int* __restrict__ out_idx)
 {
-    __shared__ long long ks[kSegMax];
-    __shared__ int ki[kSegMax];
+    constexpr int EPL = 4, kChunk = EPL * kWave; // 256 elements per wave
+    __shared__ long long ks_s[kSegMax];
+    __shared__ int ki_s[kSegMax];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = wave * kChunk;
     const unsigned n_seg = summary->n_seg;
     for (unsigned w = blockIdx.x; w < n_seg; w += gridDim.x) {
         const Segment sg = seg_list[w];
-        int p = 64;
+        int p = kChunk;
         while (p < sg.len) p <<= 1;
-        for (int i = threadIdx.x; i < p; i += blockDim.x) {
+        const bool active = base < p; // waves beyond the padded length only keep the barriers company
+        long long ks[EPL];
+        int ki[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int g = base + lane * EPL + e;
             BktRec r;
             r.start = INT64_MAX;
             r.idx = INT32_MAX;
-            if (i < sg.len) r = bkt[sg.pos + i];
-            ks[i] = r.start;
-            ki[i] = r.idx;
+            if (active && g < sg.len) r = bkt[sg.pos + g];
+            ks[e] = r.start;
+            ki[e] = r.idx;
         }
-        __syncthreads();
-        for (int k = 2; k <= p; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
+        if (active)
+            for (int k = 2; k <= kChunk; k <<= 1) wave_stage<EPL>(ks, ki, lane, base, k, k >> 1);
+        for (int k = kChunk * 2; k <= p; k <<= 1) {
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    ks_s[base + lane * EPL + e] = ks[e];
+                    ki_s[base + lane * EPL + e] = ki[e];
+                }
+            }
+            __syncthreads();
+            for (int j = k >> 1; j >= kChunk; j >>= 1) {
                 for (int t = threadIdx.x; t < (p >> 1); t += blockDim.x) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)); // index with bit j clear
                     const int l = i | j;
                     const bool up = (i & k) == 0;
-                    const long long sa = ks[i], sb = ks[l];
-                    const int ia = ki[i], ib = ki[l];
+                    const long long sa = ks_s[i], sb = ks_s[l];
+                    const int ia = ki_s[i], ib = ki_s[l];
                     const bool swap = up ? key_less(sb, ib, sa, ia) : key_less(sa, ia, sb, ib);
                     if (swap) {
-                        ks[i] = sb; ks[l] = sa;
-                        ki[i] = ib; ki[l] = ia;
+                        ks_s[i] = sb; ks_s[l] = sa;
+                        ki_s[i] = ib; ki_s[l] = ia;
                     }
                 }
                 __syncthreads();
             }
-        }
-        if (sg.flags & 1) {
-            for (int i = threadIdx.x; i < sg.len; i += blockDim.x) {
-                BktRec r;
-                r.start = ks[i];
-                r.idx = ki[i];
-                r.pad = 0;
-                bkt[sg.pos + i] = r;
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    ks[e] = ks_s[base + lane * EPL + e];
+                    ki[e] = ki_s[base + lane * EPL + e];
+                }
+                wave_stage<EPL>(ks, ki, lane, base, k, kChunk >> 1);
             }
-        } else {
-            for (int i = threadIdx.x; i < sg.len; i += blockDim.x) out_idx[sg.pos + i] = ki[i];
+            __syncthreads(); // the next stage's stores must not overtake another wave's loads of this stage
+        }
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int g = base + lane * EPL + e;
+                if (g < sg.len) {
+                    if (sg.flags & 1) {
+                        BktRec r;
+                        r.start = ks[e];
+                        r.idx = ki[e];
+                        r.pad = 0;
+                        bkt[sg.pos + g] = r;
+                    } else {
+                        out_idx[sg.pos + g] = ki[e];
+                    }
+                }
+            }
         }
         __syncthreads();
     }
