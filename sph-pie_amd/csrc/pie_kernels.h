@@ -2067,11 +2067,12 @@ __global__ __launch_bounds__(256) void k_sort_small(const Segment* __restrict__ 
     }
 }
 
-// K4c: one merge pass over every big bucket: sorted runs of `width` -> sorted runs of 2*width.  Each thread
-// owns one input element, binary-searches its rank in the sibling run, and stores it at its final slot
+// K4c: one merge pass over every big bucket: sorted runs of `width` -> sorted runs of ways*width (4-way passes halve
+// the number of launches, and a pass is all launch + search latency).  Each thread owns one input element,
+// binary-searches its rank in the sibling runs, and stores it at its final slot
 // (keys are unique, so ranks are a permutation).  grid.y indexes big_list.
 __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_list, int n_big, const int* __restrict__ counts,
-                                                    const long long* __restrict__ offsets, long long width,
+                                                    const long long* __restrict__ offsets, long long width, int ways,
                                                     const BktRec* __restrict__ src, BktRec* __restrict__ dst,
                                                     int* __restrict__ dst_idx_only)
 {
@@ -2080,21 +2081,25 @@ __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_
         const long long n = counts[u], o = offsets[u];
         for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
             const long long run = p / width;
-            const long long pair0 = (run >> 1) * 2 * width; // first slot of this pair of runs
-            const bool right = run & 1;
-            const long long sib0 = right ? pair0 : pair0 + width;
-            long long sib_n = n - sib0;
-            if (sib_n > width) sib_n = width;
-            if (sib_n < 0) sib_n = 0;
+            const long long group0 = (run / ways) * ways * width; // first slot of this group of `ways` runs
             const BktRec me = src[o + p];
-            long long lo = 0, hi = sib_n; // number of sibling keys smaller than mine
-            while (lo < hi) {
-                const long long mid = (lo + hi) >> 1;
-                const BktRec x = src[o + sib0 + mid];
-                if (key_less(x.start, x.idx, me.start, me.idx)) lo = mid + 1; else hi = mid;
+            // keys are unique, so my place in the merged group = my place in my run + the number of smaller keys in every
+            // other run of the group (independent binary searches)
+            long long smaller = 0;
+            for (int r = 0; r < ways; ++r) {
+                const long long r0 = group0 + (long long)r * width;
+                if (r0 == run * width || r0 >= n) continue;
+                long long rn = n - r0;
+                if (rn > width) rn = width;
+                long long lo = 0, hi = rn;
+                while (lo < hi) {
+                    const long long mid = (lo + hi) >> 1;
+                    const BktRec x = src[o + r0 + mid];
+                    if (key_less(x.start, x.idx, me.start, me.idx)) lo = mid + 1; else hi = mid;
+                }
+                smaller += lo;
             }
-            const long long in_run = p - run * width;
-            const long long q = o + pair0 + in_run + lo;
+            const long long q = o + group0 + (p - run * width) + smaller;
             if (dst_idx_only) dst_idx_only[q] = me.idx; // last pass: only the row order is wanted
             else dst[q] = me;
         }

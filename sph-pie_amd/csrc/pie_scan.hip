@@ -967,19 +967,22 @@ int scan_finish(pie_ctx* c)
         // big buckets: tiles of kSegMax were sorted in place by K4; merge passes ping-pong between the bucket
         // arrays and scratch carved out of this slot's (now consumed) record staging; the last pass lands in out_idx.
         BktRec* tmp = reinterpret_cast<BktRec*>(sl.sel); // same 16-B records, n of them
+        // 4-way passes, a final 2-way pass when that is all it takes
         int passes = 0;
-        for (long long w = kSegMax; w < (long long)sl.last.max_count; w <<= 1) ++passes;
+        for (long long w = kSegMax; w < (long long)sl.last.max_count; w *= 4) ++passes;
         bool in_bkt = true; // which buffer holds the current runs
         long long w = kSegMax;
-        for (int p = 0; p < passes; ++p, w <<= 1) {
+        for (int p = 0; p < passes; ++p) {
+            const int ways = (w * 2 >= (long long)sl.last.max_count) ? 2 : 4;
             const BktRec* src = in_bkt ? sl.bkt : tmp;
             BktRec* dst = in_bkt ? tmp : sl.bkt;
             int* idx_only = (p == passes - 1) ? sl.out_idx : nullptr;
             const unsigned gx = (unsigned)((sl.last.max_count + 255u) / 256u);
             const unsigned gy = sl.last.n_big < 65535u ? sl.last.n_big : 65535u;
             hipLaunchKernelGGL(k_merge_pass, dim3(gx < 4096u ? gx : 4096u, gy), dim3(256), 0, a, sl.big_list,
-                               (int)sl.last.n_big, sl.counts_ord, sl.offsets, w, src, dst, idx_only);
+                               (int)sl.last.n_big, sl.counts_ord, sl.offsets, w, ways, src, dst, idx_only);
             in_bkt = !in_bkt;
+            w *= ways;
         }
     }
     PIE_HIP(c, hipGetLastError());
