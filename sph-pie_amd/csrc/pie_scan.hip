@@ -118,6 +118,8 @@ struct pie_ctx {
     int fkey_shift = 0;
     bool fkey_poor = false;     // a fine-keyed scan found too many ambiguous rows: use the 15-bit key
     unsigned int* d_hist = nullptr;
+    std::vector<unsigned int> key_hist;  // host copy of the key histogram of the last full key build (8 keys per bin)
+    long long key_hist_rows = 0;         // rows it covers
     long long key_base = 0;
     int key_shift = 0;
     bool key_ok = false;        // d_key covers rows [0, n) under (key_base, key_shift)
@@ -365,13 +367,17 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     c->n = n;
     c->n_users = n_users;
     c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
-    c->live_frac = -1;
-    c->hot_bucket = false;
-    c->clustered = false;
-    c->hot.n = 0;
-    c->hot_seen = 0;
-    c->hot_age = 0;
-    c->last_m = -1;
+    if (keep_rows == 0) {
+        // a new table: nothing is known about it.  An append keeps what the last scans observed (live fraction, skew,
+        // clustering): a few new rows do not change the picture, and one scan corrects it if they do
+        c->live_frac = -1;
+        c->hot_bucket = false;
+        c->clustered = false;
+        c->hot.n = 0;
+        c->hot_seen = 0;
+        c->hot_age = 0;
+        c->last_m = -1;
+    }
     c->fast_enabled = c->fast_env;
     c->part_shift = -1;
     for (int sh = 0; (1 << sh) <= kPartRange; ++sh) {
@@ -446,6 +452,8 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
         PIE_HIP(c, hipGetLastError());
         PIE_HIP(c, hipMemcpyAsync(hist.data(), c->d_hist, kKeyHistBins * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
+        c->key_hist = hist;
+        c->key_hist_rows = c->n;
         unsigned long long cum = 0;
         int bin = 0, top_bin = 0;
         for (int b = 0; b < kKeyHistBins; ++b)
@@ -738,6 +746,18 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
             sl.variant = c->k1_keyed & ~0x800;
             // queries above the fine key's base (every query that few rows survive) stream 1 B/row instead of 2
             if ((c->k1_keyed & 0x800) && !c->fkey_poor && now >= c->fkey_base) sl.variant |= 0x800;
+        }
+    }
+    else if (!c->k1_pinned && !c->d_qual && c->live_frac < 0 && c->keyed_enabled && c->key_ok && !c->key_dirty &&
+             c->key_hist_rows == c->n && c->n > 0) {
+        // first scan of a table: no scan has counted live rows yet, but the key histogram taken when the key columns were
+        // built bounds them: rows whose key bin lies at or above the bin of key(now) (an upper bound on the live rows)
+        const int bin = (int)(host_key_of(c, now) >> 3);
+        unsigned long long at_or_above = 0;
+        for (int b = bin; b < kKeyHistBins; ++b) at_or_above += c->key_hist[(size_t)b];
+        if ((double)at_or_above < kLiveFirstBelow * (double)c->n) {
+            sl.variant = c->k1_keyed & ~0x800;
+            if ((c->k1_keyed & 0x800) && now >= c->fkey_base) sl.variant |= 0x800;
         }
     }
     if ((sl.variant & 0x400) && !c->key_ok) sl.variant = c->k1_live_first; // pinned keyed form without a key column

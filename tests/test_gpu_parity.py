@@ -129,8 +129,10 @@ def test_every_k1_form_is_bit_exact(pie, oracle, variant, monkeypatch):
 
 
 def test_k1_form_follows_live_fraction(pie, oracle):
-    """Unpinned: the first scan of a table streams every predicate column; once a scan has seen that few rows are
-    live the liveness-first form takes over, and it falls back when most rows are live.  Same bytes either way."""
+    """Unpinned: the form of the table pass follows what is known about the table.  A freshly loaded table has its key
+    histogram (taken when the key columns were built), which bounds the live rows of a query: few -> the keyed
+    liveness-first form from the first scan on; afterwards the live fraction the previous scan counted decides, and
+    the streaming form takes over once most rows are live.  Same bytes either way."""
     with pie.PieScan(0) as ctx:
         n, U, D = 400000, 1000, 32
         s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
@@ -141,13 +143,23 @@ def test_k1_form_follows_live_fraction(pie, oracle):
         want_all = oracle.scan(s, e, u, d, U, INT64_MIN, INT64_MIN, mask & 0xFFFFFFFF)
         assert_same(ctx.scan(now, cutoff), want_spec)
         st = ctx.stats()
-        assert st["k1_variant"] == 0x03 and abs(st["live"] / n - 18 / (120 * 24)) < 2e-3
+        assert st["k1_variant"] == 0xC85 and abs(st["live"] / n - 18 / (120 * 24)) < 2e-3   # keyed at once, from the histogram
         assert_same(ctx.scan(now, cutoff), want_spec)
-        assert ctx.stats()["k1_variant"] == 0xC85              # keyed liveness-first: streams the 1-byte top-of-range key
+        assert ctx.stats()["k1_variant"] == 0xC85
         assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # still liveness-first (decided from the last scan), on the
         assert ctx.stats()["k1_variant"] == 0x485 and ctx.stats()["live"] == n   # 2-byte key: `now` is below the fine key's base
-        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and back to streaming once everything is live
+        assert_same(ctx.scan(INT64_MIN, INT64_MIN), want_all)   # ... and streaming once everything is live
         assert ctx.stats()["k1_variant"] == 0x03
+        # a freshly loaded table and a query that most rows survive: streaming from the first scan
+        ctx.load_columns(s, e, u, d, U)
+        assert_same(ctx.scan(oracle.T0_MS - 100 * DAY, INT64_MIN), oracle.scan(s, e, u, d, U, oracle.T0_MS - 100 * DAY, INT64_MIN, mask & 0xFFFFFFFF))
+        assert ctx.stats()["k1_variant"] == 0x03
+        # an append keeps what the scans learned (no fall-back to streaming for one new row)
+        assert_same(ctx.scan(now, cutoff), want_spec)
+        assert_same(ctx.scan(now, cutoff), want_spec)
+        ctx.append_rows(s[:1], e[:1], u[:1], d[:1], U)
+        ctx.scan(now, cutoff)
+        assert ctx.stats()["k1_variant"] == 0xC85
 
 
 def test_streaming_form_aggregates_on_user_clustered_tables(pie, oracle):
@@ -586,8 +598,8 @@ def test_liveness_key_refit_and_fallback(pie, oracle):
             assert_same(ctx.scan(now, INT64_MIN), want)
             st = ctx.stats()
             seen.append((st["k1_variant"], st["key_ambiguous"]))
-        assert seen[1][0] == 0xC85 and seen[1][1] > 250000      # every appended row sat on the clamp key
-        assert seen[3][0] == 0xC85 and seen[3][1] < 2000        # rebuilt: selective again
+        assert seen[0][0] == 0xC85 and seen[0][1] > 250000      # every appended row sat on the clamp key
+        assert seen[2][0] == 0xC85 and seen[2][1] < 2000        # rebuilt: selective again
         # all ends equal: no key can separate a query at that instant
         e3 = np.full(n, oracle.T0_MS, np.int64)
         ctx.load_columns(s[:n], e3, u[:n], d[:n], U)
