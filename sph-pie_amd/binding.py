@@ -218,8 +218,12 @@ class PieScan:
     def scan(self, now, cutoff, idx_cap=None):
         """-> (counts[U] int32, offsets[U+1] int64, idx[M] int32), host arrays."""
         U = self.n_users
+        if idx_cap is None:
+            # size the row list by what the scan selected (a table-sized buffer per call would cost more than the scan)
+            self.scan_device(now, cutoff)
+            return self.read_results()
         counts, offsets = np.empty(U, np.int32), np.empty(U + 1, np.int64)
-        cap = self.n if idx_cap is None else int(idx_cap)
+        cap = int(idx_cap)
         idx = np.empty(max(cap, 1), np.int32)
         m = C.c_size_t(0)
         self._check(self._lib.pie_scan(self._ctx, int(now), int(cutoff), _ptr(counts), _ptr(offsets), _ptr(idx), cap, C.byref(m)))
@@ -229,10 +233,12 @@ class PieScan:
         """Host copies (counts, offsets, idx) of the last FINISHED scan (scan_finish / scan_device / scan_pipelined)."""
         U = self.n_users
         counts, offsets = np.empty(U, np.int32), np.empty(U + 1, np.int64)
-        idx = np.empty(max(self.n, 1), np.int32)
         m = C.c_size_t(0)
-        self._check(self._lib.pie_read_results(self._ctx, _ptr(counts), _ptr(offsets), _ptr(idx), self.n, C.byref(m)))
-        return counts, offsets, idx[: m.value].copy()
+        self._check(self._lib.pie_read_results(self._ctx, _ptr(counts), _ptr(offsets), None, 0, C.byref(m)))
+        idx = np.empty(max(m.value, 1), np.int32)
+        if m.value:
+            self._check(self._lib.pie_read_results(self._ctx, None, None, _ptr(idx), m.value, C.byref(m)))
+        return counts, offsets, idx[: m.value]
 
     def read_user_feed(self, user, cap=None):
         """Rows of one user's feed from the last finished scan (two small device reads)."""
