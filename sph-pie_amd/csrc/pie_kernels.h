@@ -1408,6 +1408,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
                                                  int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
+    (void)bkt; // the direct part of outgrown buckets is moved by k_copy_direct, not here
     static_assert(!ORDER || UPT == 1, "the fused order step owns one user per thread");
     constexpr int kTileUsers = BLOCK * UPT;
     constexpr int kWaves = BLOCK / kWave;
