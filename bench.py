@@ -201,6 +201,20 @@ def main():
     st = ctx.stats()
     m = last if not gather else int(last["lengths"][rank])
     scan_only_ms = None
+    gather_ok = None
+    if gather and args.mode == "scan":
+        # the gathered lists of this rank (as every rank received them) against this rank's own result of the same query
+        import numpy as np
+        ctx.scan_device(now, cutoff)
+        _, own_off, own_idx = ctx.read_results()
+        ok = int(last["lengths"][rank]) == own_idx.size and \
+            np.array_equal(last["offsets"][rank].cpu().numpy()[: U + 1], own_off.astype(np.int32)) and \
+            np.array_equal(last["rows"][rank].cpu().numpy()[: own_idx.size], own_idx)
+        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        gather_ok = bool(int(t_ok.item()))
+        if not gather_ok:
+            log("WARNING: rank %d: gathered lists differ from the local result" % rank)
     if gather and args.mode == "scan":
         # scan-only throughput beside scan + gather — the same K steps without the exchange, after the
         # timed region (not part of value); max over ranks like the headline
@@ -243,7 +257,7 @@ def main():
             "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
             "sessions_per_sec": N * world / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "scan_only_ms_per_step": scan_only_ms,
+            "scan_only_ms_per_step": scan_only_ms, "gather_verified": gather_ok,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
