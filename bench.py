@@ -5,17 +5,28 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
-A step = one scan (one `now`/`cutoff`/discipline-mask query) over the rank's resident session table,
-producing counts/offsets/idx for every user of the shard; for N > 1 followed by the all-gather of per-user
-counts and row lists (RCCL).  Workload at N = 1: BASELINE.json config 3 — 10^8 sessions / 10^5 users /
-32 disciplines, SoA int64 start/end + int32 user/disc, resident in HBM before the timed region.
-Scaling is weak: every rank holds a 10^8-row shard of its own users (user-hash sharded table of N x 10^8).
+A step = one scan (one `now`/`cutoff`/discipline-mask query) over the resident session table, producing
+counts/offsets/idx for every user; for N > 1 the ONE 10^8-row corpus is sharded by user hash over the ranks
+(BASELINE.json configs[3], strong scaling) and a step also all-gathers the per-user offsets and row lists (RCCL).
+Workload at N = 1: BASELINE.json config 3 — 10^8 sessions / 10^5 users / 32 disciplines, SoA int64 start/end +
+int32 user/disc, resident in HBM before the timed region.
 
-One JSON line on stdout (rank 0).  Everything else goes to stderr.
+What one run measures (rank 0 prints ONE JSON line on stdout, everything else goes to stderr):
+  value / ms_per_step   the headline loop: K steps, R times (median; min / max beside it), two scans in flight
+  roofline              the dominant kernel of that loop, HIP-event timed in the run; frac = HBM traffic / time / peak
+                        (traffic: rocprofv3 PMC of this very command, committed under profiles/; a byte model from the
+                        run's own row counters beside it) — never above 1; the 24 B/row figure is `alg_equiv_gbs`
+  roofline_full_read    the same query with the table pass pinned to the form that reads every byte of the four columns
+                        (24 B/row = SURVEY.md 8d's algorithmic bytes): t_scan = first kernel start -> last kernel end
+  value_with_d2h        the headline loop with counts + offsets delivered to pinned host memory by every scan
+  cpu_baseline          oracle C port on this box's host cores: full N on 1 thread and on all threads, checked against
+                        the GPU result; reference-faithful JS (Map of session objects) beside it
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,40 +43,113 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(args, U, D, now, cutoff, mask, flags):
-    """Oracle (CPU port, 1 thread) timed on a bounded sample of the same workload, on this box's host cores."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import oracle_py
-    sample = args.cpu_sample_rows
-    s, e, u, d = oracle_py.gen(SEED, args.rows, 0, sample, U, D, flags)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        oracle_py.scan(s, e, u, d, U, now, cutoff, mask)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds or reps >= 1000:
-            break
-    rows_per_s = sample * reps / dt
-    out = {
-        "value": rows_per_s * U / args.rows, "unit": "feeds/s", "cores": 1, "kind": "port",
-        "sessions_per_sec": rows_per_s,
-        "sample": "%d reps x first %d rows of the same corpus (U=%d, D=%d), oracle/pie_oracle.c scan, %.1f s; "
-                  "feeds/s scaled by U/N of the full workload; host has %d cores" % (reps, sample, U, D, dt, os.cpu_count()),
-    }
-    # reference-faithful JS (Map of {userId, createdAt, expiresAt} objects, single thread) when node exists
+def spread(xs):
+    return {"median": statistics.median(xs), "min": min(xs), "max": max(xs), "n": len(xs)}
+
+
+def kernel_name(variant, rides, mode):
+    """Name of the table-pass kernel a scan form runs (as rocprofv3 prints it, without 'void pie::')."""
+    if mode == "expired":
+        return "k_expired_stage<8>" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed<2>"
+    if variant & 0x400:
+        kt = "unsigned char" if variant & 0x800 else "unsigned short"
+        agg = "true" if variant & 0x40 else "false"
+        if rides:
+            return "k_scan_keyed_with_tail<8, true, %s, %s>" % (kt, agg)
+        un = 2 if (variant & 0xA0) == 0x20 else 8 if (variant & 0xA0) == 0x80 else 4
+        return "k_scan_keyed<%d, %s, %s, %s, %s>" % (un, agg, "true" if variant & 1 else "false", kt, "true" if variant & 0x10 else "false")
+    if variant & 0x200:
+        return "k_scan_live_first_part<8, true>"
+    un = 2 if (variant & 0xA0) == 0x20 else 8 if (variant & 0xA0) == 0x80 else 4
+    if variant & 4:
+        return "k_scan_live_first<%d, %s, %s>" % (un, "true" if variant & 1 else "false", "true" if variant & 0x40 else "false")
+    if variant == 0x43:
+        return "k_scan_compact<4, true, true, false, true>"
+    return "k_scan_compact<%d, %s, %s, false, false>" % (un, "true" if variant & 1 else "false", "true" if variant & 2 else "false")
+
+
+def pmc_traffic(kname, default_workload):
+    """HBM bytes per launch of `kname` from the committed rocprofv3 PMC summary of this command (profiles/traffic.json,
+    written by tools/pmc_traffic.py), or None.  Only quoted for the workload it was measured on."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    if not default_workload or not os.path.exists(path):
+        return None, None
+    doc = json.load(open(path))
+    for k, v in doc.get("kernels", {}).items():
+        if kname in k:
+            return v, doc.get("source")
+    return None, None
+
+
+def start_js_baseline(args, U, D):
+    """Reference-faithful JS (Map of {userId, createdAt, expiresAt} objects, one thread): started first, collected last —
+    it runs on one host core while the GPU phases run, and is finished before the multi-thread CPU leg starts."""
     try:
         import shutil
-        import subprocess
         node = shutil.which("node")
         js = os.path.join(REPO, "oracle", "ref_faithful.js")
-        if node and os.path.exists(js):
-            res = subprocess.run([node, "--max-old-space-size=8192", js, "--bench", str(args.js_rows), str(max(U // 100, 10)), str(D)],
-                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
-            if res.returncode == 0:
-                out["js_reference_faithful"] = json.loads(res.stdout.strip().splitlines()[-1])
+        if node and os.path.exists(js) and args.js_rows > 0:
+            return subprocess.Popen([node, "--max-old-space-size=12288", js, "--bench", str(args.js_rows), str(max(U // 100, 10)), str(D)],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     except Exception as ex:  # the JS leg is optional context, never fatal
         log("js baseline skipped:", ex)
+    return None
+
+
+def cpu_baseline(args, U, D, now, cutoff, mask, flags, gpu_result, js_proc):
+    """Baseline B2 of BASELINE.md section 3: the oracle (C port of the path) over the same SoA columns at FULL N, on one
+    thread and on all host threads, outputs compared with the GPU result; B1 (JS) collected from its subprocess."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import oracle_py
+    cores = os.cpu_count() or 1
+    N = args.rows
+    n_cpu = min(N, args.cpu_rows)
+    out = {"unit": "feeds/s", "kind": "port", "host_cores": cores}
+    js = None
+    if js_proc is not None:
+        try:
+            so, se = js_proc.communicate(timeout=args.js_timeout)
+            if js_proc.returncode == 0:
+                js = json.loads(so.strip().splitlines()[-1])
+            else:
+                log("js baseline failed:", se[-300:])
+        except Exception as ex:
+            js_proc.kill()
+            log("js baseline skipped:", ex)
+    t0 = time.perf_counter()
+    s, e, u, d = oracle_py.gen_mt(SEED, N, 0, n_cpu, U, D, flags, threads=cores)
+    t_gen = time.perf_counter() - t0
+    bufs = (np.empty(U, np.int32), np.empty(U + 1, np.int64), np.empty(n_cpu, np.int32))
+
+    def timed(threads, budget):
+        reps, t1 = 0, time.perf_counter()
+        while True:
+            res = oracle_py.scan_mt(s, e, u, d, U, now, cutoff, mask, threads, out=bufs)
+            reps += 1
+            dt = time.perf_counter() - t1
+            if dt >= budget or reps >= 200:
+                return res, reps, dt
+
+    res1, reps1, dt1 = timed(1, args.cpu_seconds)
+    resA, repsA, dtA = timed(cores, args.cpu_seconds / 2)
+    rows1, rowsA = n_cpu * reps1 / dt1, n_cpu * repsA / dtA
+    verified = None
+    if gpu_result is not None and n_cpu == N:
+        verified = all(np.array_equal(a, b) for a, b in zip(resA, gpu_result))
+        if not verified:
+            log("WARNING: the GPU result differs from the CPU oracle on the full table")
+    out.update({
+        "value": rows1 * U / N, "cores": 1, "sessions_per_sec": rows1,
+        "all_threads": {"value": rowsA * U / N, "cores": cores, "sessions_per_sec": rowsA, "reps": repsA, "seconds": dtA},
+        "gpu_result_equals_cpu_result": verified,
+        "sample": "%d reps x %d rows (%s) of the same corpus (U=%d, D=%d), oracle/pie_oracle.c scan on 1 thread, %.1f s; all-thread "
+                  "leg: %d threads, %d reps, %.1f s; corpus generated on the host in %.1f s; feeds/s = rows/s x U/N" %
+                  (reps1, n_cpu, "the FULL table" if n_cpu == N else "first rows", U, D, dt1, cores, repsA, dtA, t_gen),
+    })
+    if js is not None:
+        out["js_reference_faithful"] = js
+        out["js_reference_faithful"]["extrapolated_seconds_per_1e8_row_scan"] = 1e8 / js["sessions_per_sec"]
     return out
 
 
@@ -79,18 +163,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rows", type=int, default=10 ** 8, help="sessions per GPU (weak scaling)")
-    ap.add_argument("--users", type=int, default=10 ** 5, help="users per GPU shard")
+    ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each (median / min / max reported)")
+    ap.add_argument("--rows", type=int, default=10 ** 8, help="sessions of the whole corpus (sharded over the ranks)")
+    ap.add_argument("--users", type=int, default=10 ** 5, help="users of the whole corpus")
     ap.add_argument("--disc", type=int, default=32)
     ap.add_argument("--order", choices=["random", "clustered"], default="random")
-    ap.add_argument("--users-dist", choices=["uniform", "zipf"], default="uniform", help="zipf: Zipf(1.1) over the shard's users")
+    ap.add_argument("--users-dist", choices=["uniform", "zipf"], default="uniform", help="zipf: Zipf(1.1) over the users")
     ap.add_argument("--variant", choices=["auth", "interval"], default="auth")
     ap.add_argument("--query", choices=["spec", "wide", "future"], default="spec",
                     help="spec: now=T0-6h, cutoff=T0-61d, 16/32 disciplines (SURVEY.md §8d); wide: ~25%% selected")
-    ap.add_argument("--cpu-sample-rows", type=int, default=2 * 10 ** 7)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--js-rows", type=int, default=10 ** 6)
+    ap.add_argument("--cpu-rows", type=int, default=10 ** 8, help="rows of the CPU baseline (default: the full table)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--js-rows", type=int, default=10 ** 7)
+    ap.add_argument("--js-timeout", type=float, default=240.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the full-read / D2H legs (secondary workloads, sweeps)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = ONE corpus of --rows sharded by user hash (BASELINE configs[3]); weak = --rows per rank")
     ap.add_argument("--gather-batch", type=int, default=8, help="multi-GPU: scans per all-gather (1 = one gather per scan)")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
@@ -110,6 +199,14 @@ def main():
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
 
+    N, U, D = args.rows, args.users, args.disc
+    js_proc = None
+    if args.users_dist == "zipf":
+        args.no_cpu_baseline = True   # the CPU leg generates the uniform-user corpus
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "scan":
+        js_proc = start_js_baseline(args, U, D)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import sph_pie_amd as pie
@@ -126,7 +223,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    N, U, D = args.rows, args.users, args.disc
     flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0)
     if args.query == "spec":
         now, cutoff, mask = T0_MS - 6 * 3600 * 1000, T0_MS - 61 * DAY, 0x5555555555555555
@@ -141,24 +237,36 @@ def main():
     pie.build_hip()
     ctx = pie.PieScan(local_rank)
     t_gen = time.perf_counter()
-    # every rank owns the users that hash to it; its shard is rows [rank*N, (rank+1)*N) of the world*N-row corpus
+    strong = world > 1 and args.scaling == "strong"
     if args.users_dist == "zipf":
-        ctx.gen_synthetic_cdf(SEED, N * world, N * rank, N, U, D, flags, pie.zipf_cdf(U))
+        cdf = pie.zipf_cdf(U)
+        if world > 1 and not strong:
+            ctx.gen_synthetic_cdf(SEED, N * world, N * rank, N, U, D, flags, cdf)
+        else:
+            ctx.gen_synthetic_cdf(SEED, N, 0, N, U, D, flags, cdf)
+    elif world > 1 and not strong:
+        ctx.gen_synthetic(SEED, N * world, N * rank, N, U, D, flags)   # weak: rows [rank*N, (rank+1)*N) of a world*N-row corpus
     else:
-        ctx.gen_synthetic(SEED, N * world, N * rank, N, U, D, flags)
+        ctx.gen_synthetic(SEED, N, 0, N, U, D, flags)
+    shard_info = None
+    if strong:
+        # ONE corpus, sharded on the device: this rank keeps the rows of the users that hash to it (pie_shard_of), users
+        # re-numbered densely; nothing leaves the GPU
+        shard_info = ctx.shard_table(rank, world)
     ctx.set_disciplines(mask, D)
-    log("rank %d: generated %d rows in %.2f s" % (rank, N, time.perf_counter() - t_gen))
+    n_local, u_local = ctx.n, ctx.n_users
+    log("rank %d: %d rows / %d users resident after %.2f s" % (rank, n_local, u_local, time.perf_counter() - t_gen))
+    info = ctx.table_info()
 
     backend = HipShardBackend(ctx, dev) if gather else None
-    # --gather-batch scans per all-gather: the collective is latency-bound at this size (1.7 MB per rank), so the same
-    # lists travel in fewer, larger messages
-    feeds = ShardedFeeds(backend, rank, world, U, always_collective=gather, batch=args.gather_batch) if gather else None
+    # --gather-batch scans per all-gather: the collective is latency-bound at this size, so the same lists travel in
+    # fewer, larger messages
+    feeds = ShardedFeeds(backend, rank, world, u_local, always_collective=gather, batch=args.gather_batch) if gather else None
 
     expired_window = (T0_MS - 30 * DAY, T0_MS - 29 * DAY)   # one day of expiries: ~0.83 % of the rows queue up
 
     def run_steps(k):
-        """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1 (depth-1 pipeline,
-        every gather is collected inside the same call)."""
+        """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1."""
         last = None
         if args.mode == "expired":
             for _ in range(k):
@@ -182,140 +290,235 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_region(fn, k):
+        """EXACTLY k steps between two fences; max over ranks.  -> seconds"""
+        fence()
+        t0 = time.perf_counter()
+        out = fn(k)
+        fence()
+        dt = time.perf_counter() - t0
+        if gather:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     run_steps(max(args.warmup, 1))
     fence()
     ctx.stats_reset()
-    # HIP events around the scan kernels, on the stream they are launched on; every 16th step (at least three per run) carries them (an event
-    # between two kernels drains the pipeline for a few microseconds, which would inflate ms_per_step)
+    # HIP events around the scan kernels, on the stream they are launched on; every 16th step (at least three per region)
+    # carries them (an event between two kernels drains the pipeline for a few microseconds)
     profile_every = args.profile_every if args.profile_every > 0 else max(1, min(16, args.steps // 3))
     ctx.set_profiling(1 if args.mode == "expired" else profile_every)
-    t0 = time.perf_counter()
-    last = run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
+    region_ms, kernel_ms_regions, scan_ms_regions, n_prof = [], [], [], 0
+    last = None
+    for _ in range(max(args.repeat, 1)):
+        dt, last = timed_region(run_steps, args.steps)
+        region_ms.append(dt * 1e3 / args.steps)
+        st = ctx.stats()
+        if st["n_profiled"]:
+            kernel_ms_regions.append(st["k1_ms_sum"] / st["n_profiled"])
+            scan_ms_regions.append(st["scan_ms_sum"] / st["n_profiled"])
+            n_prof += st["n_profiled"]
+        ctx.stats_reset()
     ctx.set_profiling(0)
-    if gather:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     st = ctx.stats()
     m = last if not gather else int(last["lengths"][rank])
+    ms_per_step = statistics.median(region_ms)
+    k1_ms = statistics.median(kernel_ms_regions) if kernel_ms_regions else 0.0
+
     scan_only_ms = None
     gather_ok = None
     if gather and args.mode == "scan":
         # the gathered lists of this rank (as every rank received them) against this rank's own result of the same query
-        import numpy as np
         ctx.scan_device(now, cutoff)
         _, own_off, own_idx = ctx.read_results()
         ok = int(last["lengths"][rank]) == own_idx.size and \
-            np.array_equal(last["offsets"][rank].cpu().numpy()[: U + 1], own_off.astype(np.int32)) and \
+            np.array_equal(last["offsets"][rank].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
             np.array_equal(last["rows"][rank].cpu().numpy()[: own_idx.size], own_idx)
         t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         gather_ok = bool(int(t_ok.item()))
         if not gather_ok:
             log("WARNING: rank %d: gathered lists differ from the local result" % rank)
-    if gather and args.mode == "scan":
         # SURVEY.md 8(e): scan-only throughput beside scan + gather — the same K steps without the exchange, after the
-        # timed region (not part of value); max over ranks like the headline
-        fence()
-        t1 = time.perf_counter()
-        ctx.scan_pipelined(args.steps, now, cutoff)
-        fence()
-        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        scan_only_ms = float(t.item()) * 1e3 / args.steps
+        # timed regions (not part of value); max over ranks like the headline
+        so = [timed_region(lambda k: ctx.scan_pipelined(k, now, cutoff), args.steps)[0] * 1e3 / args.steps for _ in range(3)]
+        scan_only_ms = spread(so)
 
+    # totals over the ranks (strong scaling: every rank holds a different number of rows / users)
+    tot_rows, tot_users = n_local, u_local
+    if gather:
+        t = torch.tensor([n_local, u_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot_rows, tot_users = int(t[0]), int(t[1])
+
+    line = None
     if rank == 0:
-        ms_per_step = dt * 1e3 / args.steps
-        k1_ms = st["k1_ms_sum"] / max(st["n_profiled"], 1)
-        scan_ms = st["scan_ms_sum"] / max(st["n_profiled"], 1)
-        alg = (8.0 if args.mode == "expired" else 24.0) * N
-        achieved = alg / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         variant = st["k1_variant"]
-        kname = "k_scan_live_first" if variant & 4 else "k_scan_compact"
-        if variant & 0x200:
-            kname = "k_scan_live_first_part"
-        if variant & 0x400:
-            # with two scans in flight the launch also carries the offsets + order kernel of the scan before
-            rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
-            kname = "k_scan_keyed_with_tail" if rides else "k_scan_keyed"
-        if args.mode == "expired":
-            kname = "k_expired_stage" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed"
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "k1_traffic.json")
-        default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist) == \
-            (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform")
-        if default_workload and os.path.exists(tpath):
-            tdoc = json.load(open(tpath))
-            if tdoc.get("kernel", "").endswith(kname) or kname in tdoc.get("kernel", ""):
-                traffic = tdoc["hbm_bytes_per_launch"]   # PMC-measured for this kernel form and this workload
+        rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
+        kname = kernel_name(variant, rides, args.mode)
+        default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
+            (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
+        alg = (8.0 if args.mode == "expired" else 24.0) * n_local
+        traffic_doc, traffic_src = pmc_traffic(kname, default_workload)
+        traffic = traffic_doc["hbm_bytes_per_launch"] if traffic_doc else None
+        # byte model from the run's own counters (keyed form): key stream + one 128-B sector per candidate payload record
+        # and per ambiguous `end` + one 64-B write per selected row (bucket slot) + K2's outputs
+        model = None
+        if args.mode == "scan" and variant & 0x400:
+            kb = 1 if variant & 0x800 else 2
+            model = n_local * kb + st["candidates"] * 128 + st["key_ambiguous"] * 128 + int(m) * 64 + u_local * 12 + int(m) * 4
+        elif args.mode == "scan" and not variant & 4:
+            model = n_local * (24 if not variant & 2 else 20) + int(m) * (64 + 4 + (4 if variant & 2 else 0)) + u_local * 12
+        basis = traffic if traffic else model
+        achieved = (basis / (k1_ms * 1e-3) / 1e9) if basis and k1_ms > 0 else None
+        per_step_units = (tot_users if args.mode == "scan" else tot_rows)
         line = {
             "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X" if args.mode == "scan" else
                       "expired-queue pass (SURVEY 8f-1): sessions scanned/sec; value counts table rows, not feeds",
-            "value": (U if args.mode == "scan" else N) * world / (ms_per_step * 1e-3),
+            "value": per_step_units / (ms_per_step * 1e-3),
             "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
-            "sessions_per_sec": N * world / (ms_per_step * 1e-3),
+            "sessions_per_sec": tot_rows / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "timing": {"timed_regions": len(region_ms), "steps_per_region": args.steps, "ms_per_step": spread(region_ms),
+                       "ms_per_step_all": region_ms,
+                       "note": "every region is exactly --steps steps between barrier + synchronize fences (max over ranks); "
+                               "value and ms_per_step are the median region"},
             "scan_only_ms_per_step": scan_only_ms, "gather_verified": gather_ok,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3: %d sessions / %d users / %d disciplines per GPU, SoA int64 start/end + int32 "
-                            "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s users, %s variant, %s query" % (N, U, D, args.order, args.users_dist, args.variant, args.query),
-                "sessions_per_gpu": N, "users_per_gpu": U, "disciplines": D, "selected_rows_rank0": int(m),
-                "parallelism": "user-hash shards x%d, RCCL all-gather of per-user offsets + row lists (%d scans per collective), overlapped with the next scans" % (world, args.gather_batch) if world > 1 else "single GPU",
+                "workload": "BASELINE config %s: %d sessions / %d users / %d disciplines%s, SoA int64 start/end + int32 "
+                            "user/disc, splitmix64 seed 0x5EED5EED, %s order, %s users, %s variant, %s query" %
+                            ("3" if world == 1 else "4", N if (strong or world == 1) else N * world, U, D,
+                             "" if world == 1 else (" sharded by user hash over %d GPUs" % world if strong else " per GPU (weak)"),
+                             args.order, args.users_dist, args.variant, args.query),
+                "sessions_total": tot_rows, "users_total": tot_users, "sessions_rank0": n_local, "users_rank0": u_local,
+                "disciplines": D, "selected_rows_rank0": int(m),
+                "parallelism": "user-hash shards x%d (device-side partition of one corpus), RCCL all-gather of per-user offsets + row "
+                               "lists (%d scans per collective), overlapped with the next scans" % (world, args.gather_batch) if world > 1 else "single GPU",
             },
             "roofline": {
-                "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/k1_traffic.json (rocprofv3 PMC, separate passes, gfx950 FETCH_SIZE x2 correction)" if traffic else None,
-                "hbm_gbs_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9) if traffic and k1_ms > 0 else None,
-                "hbm_frac_of_peak_from_traffic": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k1_ms > 0 else None,
-                "note": "the timed launch is the table pass of one scan plus, in its first blocks, the offsets + order kernel of the "
-                        "scan before it; achieved = algorithmic 24 B/row over kernel time, as the metric defines it; the keyed table pass streams a "
-                        "1- or 2-byte liveness key per row and gathers one 16-byte payload record per candidate row, so the HBM "
-                        "bytes it moves (traffic, PMC-measured) are far below the algorithmic bytes: judge the kernel by "
-                        "hbm_frac_of_peak_from_traffic (DESIGN.md sections 3, 4, 6)",
-                "alg_bytes_per_launch": alg, "kernel_ms": k1_ms, "launches_timed": st["n_profiled"],
-                # whole step (table pass + offsets + scatter + per-bucket order [+ exchange]) against the same peak
-                "whole_step_frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_model": model,
+                "traffic_model_note": "bytes from this run's own counters: key stream N x key bytes + 128 B per candidate payload record + 128 B "
+                                      "per ambiguous `end` + 64 B per selected row stored + K2 outputs; `achieved` uses the PMC traffic when the "
+                                      "committed profile covers this kernel and workload, else this model",
+                "alg_bytes_per_launch": alg,
+                "alg_equiv_gbs": (alg / (k1_ms * 1e-3) / 1e9) if k1_ms > 0 else None,
+                "alg_equiv_note": "24 B/row x rows over kernel time: what a scan that read every byte would need to sustain to match this "
+                                  "kernel; NOT a bandwidth — the keyed pass streams a 1- or 2-byte liveness key per row and gathers one 16-byte "
+                                  "payload record per candidate (DESIGN.md sections 3, 4, 6); see roofline_full_read for the every-byte form",
+                "kernel_ms": k1_ms, "kernel_ms_regions": spread(kernel_ms_regions) if kernel_ms_regions else None,
+                "launches_timed": n_prof,
+                "note": "the timed launch is the table pass of one scan plus, in its first blocks, the offsets + order kernel of the scan "
+                        "before it" if rides else "the timed launch is the table pass",
                 # latency of one scan, first kernel start -> last kernel end; with two scans in flight the tail of
                 # scan i is queued behind the table pass of scan i+1, so this exceeds ms_per_step by design
-                "scan_latency_ms": scan_ms, "scans_in_flight": args.depth if not gather else 1,
+                "scan_latency_ms": statistics.median(scan_ms_regions) if scan_ms_regions else None,
+                "scans_in_flight": args.depth if not gather else 1,
                 "k1_blocks": st["k1_blocks"],
             },
+            "index": {"index_build_ms": info["index_build_ms"], "derived_bytes": info["derived_bytes"],
+                      "table_bytes": info["table_bytes"], "workspace_bytes": info["workspace_bytes"],
+                      "note": "the keyed pass reads derived columns built at load (outside the timed region) and kept in step by every "
+                              "writer of `end`; index_build_ms = one full build on this table"},
         }
-        if world == 1 and args.mode == "scan" and not gather:
-            # D2H of counts/offsets and of idx, reported beside the headline (results normally stay in HBM
-            # for the exchange step / the host serialiser's fetch); pinned host buffers, synchronous calls, 20 reps
-            h_counts = torch.empty(U, dtype=torch.int32).pin_memory()
-            h_offsets = torch.empty(U + 1, dtype=torch.int64).pin_memory()
-            h_idx = torch.empty(max(int(m), 1), dtype=torch.int32).pin_memory()
-            reps = 20
+
+    gpu_result = None
+    if world == 1 and args.mode == "scan" and not gather and not args.no_extra:
+        # ---- the every-byte form of the same query, same table, same run (SURVEY.md 8d's 24 B/row really read)
+        ctx.set_scan_form(0x01)
+        for _ in range(3):
             ctx.scan_device(now, cutoff)
-            ctx.read_results_into(h_counts.data_ptr(), h_offsets.data_ptr(), h_idx.data_ptr(), h_idx.numel())  # first use of the buffers
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ctx.scan_device(now, cutoff)
-            t2 = time.perf_counter()
-            for _ in range(reps):
-                ctx.scan_device(now, cutoff)
-                ctx.read_results_into(h_counts.data_ptr(), h_offsets.data_ptr())
-            t3 = time.perf_counter()
-            for _ in range(reps):
-                ctx.read_results_into(None, None, h_idx.data_ptr(), h_idx.numel())
-            t4 = time.perf_counter()
-            line["d2h"] = {
-                "one_scan_synchronous_ms": (t2 - t1) * 1e3 / reps,
-                "one_scan_plus_counts_offsets_to_host_ms": (t3 - t2) * 1e3 / reps,
-                "idx_to_host_ms": (t4 - t3) * 1e3 / reps, "idx_bytes": int(m) * 4, "counts_offsets_bytes": U * 4 + (U + 1) * 8,
-                "note": "one scan at a time (no run-ahead), host-synchronous, pinned buffers; not part of value",
-            }
-            nonempty = int((h_counts > 0).sum())
-            line["config"]["nonempty_feeds_rank0"] = nonempty
-            line["nonempty_feeds_per_sec"] = nonempty / (ms_per_step * 1e-3)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, U, D, now, cutoff, mask, flags)
+        ctx.stats_reset()
+        ctx.set_profiling(1)
+        n_sync = max(5, min(args.steps, 20))
+        for _ in range(n_sync):   # one scan at a time: e0 | K1 | K2 [| K3 K4] | e2
+            ctx.scan_device(now, cutoff)
+        sf = ctx.stats()
+        ctx.set_profiling(0)
+        ctx.stats_reset()
+        fr_regions = [timed_region(lambda k: ctx.scan_pipelined(k, now, cutoff), args.steps)[0] * 1e3 / args.steps
+                      for _ in range(max(args.repeat, 1))]
+        ctx.set_scan_form(-1)
+        fr_k1 = sf["k1_ms_sum"] / max(sf["n_profiled"], 1)
+        fr_scan = sf["scan_ms_sum"] / max(sf["n_profiled"], 1)
+        fr_name = kernel_name(0x01, False, "scan")
+        fr_doc, fr_src = pmc_traffic(fr_name, default_workload)
+        fr_ms = statistics.median(fr_regions)
+        line["roofline_full_read"] = {
+            "bound": "hbm", "kernel": fr_name, "kernel_variant": hex(sf["k1_variant"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "alg_bytes_per_scan": 24.0 * N,
+            "t_scan_ms": fr_scan, "achieved": 24.0 * N / (fr_scan * 1e-3) / 1e9, "frac": 24.0 * N / (fr_scan * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "t_scan_note": "first kernel start -> last kernel end of ONE scan (HIP events, scan stream, %d scans one at a time): table pass "
+                           "+ offsets/order kernel; frac = 24 B x N / t_scan / peak" % sf["n_profiled"],
+            "kernel_ms": fr_k1, "kernel_achieved": 24.0 * N / (fr_k1 * 1e-3) / 1e9, "kernel_frac": 24.0 * N / (fr_k1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ms_per_step": fr_ms, "ms_per_step_spread": spread(fr_regions),
+            "step_frac": 24.0 * N / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "step_note": "steady state with two scans in flight, same fences and --steps as the headline",
+            "feeds_per_sec": U / (fr_ms * 1e-3),
+            "traffic": fr_doc["hbm_bytes_per_launch"] if fr_doc else None, "traffic_source": fr_src,
+        }
+        # ---- the headline loop with counts + offsets delivered to pinned host memory by every scan (SURVEY.md 8d)
+        sets = []
+        for _ in range(3):
+            off_h, off_d, off_addr = ctx.host_alloc(U + 2)
+            cnt_h, cnt_d, cnt_addr = ctx.host_alloc(U)
+            sets.append((off_h, off_d, off_addr, cnt_h, cnt_d, cnt_addr))
+
+        def run_d2h(k):
+            mm = 0
+            ctx.scan_begin_packed2(now, cutoff, sets[0][1], U, 0, sets[0][4])
+            for i in range(k):
+                if i + 1 < k:
+                    sx = sets[(i + 1) % 3]
+                    ctx.scan_begin_packed2(now, cutoff, sx[1], U, 0, sx[4])
+                mm, ready = ctx.scan_finish_packed()
+                if not ready:
+                    ctx.synchronize()
+            return mm
+
+        run_d2h(5)
+        d2h_regions = [timed_region(run_d2h, args.steps)[0] * 1e3 / args.steps for _ in range(max(args.repeat, 1))]
+        # the host copies of the last scan against a plain read-back of the same result
+        k_last = (args.steps - 1) % 3
+        counts_dev, offsets_dev, idx_dev = ctx.read_results()
+        gpu_result = (counts_dev, offsets_dev, idx_dev)
+        host_ok = bool(np.array_equal(sets[k_last][3][:U], counts_dev) and
+                       np.array_equal(sets[k_last][0][: U + 1].astype(np.int64), offsets_dev) and int(sets[k_last][0][U + 1]) == idx_dev.size)
+        d2h_ms = statistics.median(d2h_regions)
+        line["value_with_d2h"] = {
+            "value": U / (d2h_ms * 1e-3), "unit": "feeds/s", "ms_per_step": d2h_ms, "ms_per_step_spread": spread(d2h_regions),
+            "host_copy_verified": host_ok, "bytes_per_scan_to_host": (2 * U + 2) * 4,
+            "note": "every scan's offsets[U+1] + M (int32) and counts[U] land in mapped pinned host memory, written by the scan's own "
+                    "offsets kernel (no copy node, no event): complete when the scan's summary is; idx stays in HBM (SURVEY.md 8d "
+                    "reports its D2H separately)",
+        }
+        h_idx = torch.empty(max(int(m), 1), dtype=torch.int32).pin_memory()
+        ctx.read_results_into(None, None, h_idx.data_ptr(), h_idx.numel())
+        t1 = time.perf_counter()
+        for _ in range(20):
+            ctx.read_results_into(None, None, h_idx.data_ptr(), h_idx.numel())
+        line["value_with_d2h"]["idx_to_host_ms"] = (time.perf_counter() - t1) * 1e3 / 20
+        line["value_with_d2h"]["idx_bytes"] = int(m) * 4
+        for sx in sets:
+            ctx.host_free(sx[2])
+            ctx.host_free(sx[5])
+        nonempty = int((counts_dev > 0).sum())
+        line["config"]["nonempty_feeds_rank0"] = nonempty
+        line["nonempty_feeds_per_sec"] = nonempty / (ms_per_step * 1e-3)
+    elif world == 1 and args.mode == "scan" and not gather and not args.no_cpu_baseline:
+        ctx.scan_device(now, cutoff)
+        gpu_result = ctx.read_results()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "scan":
+            line["cpu_baseline"] = cpu_baseline(args, U, D, now, cutoff, mask, flags, gpu_result, js_proc)
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if gather:
         dist.barrier()

@@ -61,6 +61,7 @@ typedef struct pie_stats {
                               0x400 keyed: streams the 2-byte liveness key instead of the `end` column) */
     uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
     uint64_t live;         /* rows with end > now seen by the last scan */
+    uint64_t candidates;   /* keyed form: rows whose key was >= the query's, i.e. payload records the table pass gathered */
 } pie_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------- */
@@ -148,6 +149,17 @@ int pie_scan_finish(pie_ctx *ctx, size_t *m_out);
  * enqueued on the context's stream to write it (order the consumer after that stream, e.g. with an event). */
 int pie_scan_begin_packed(pie_ctx *ctx, int64_t now, int64_t cutoff, void *dst_i32, size_t u_pad, size_t idx_cap);
 int pie_scan_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
+/* pie_scan_begin_packed with a second destination: counts_dst_i32 (n_users words, may be NULL) receives counts[U].  Both
+ * destinations are device-visible memory; they may be MAPPED PINNED HOST memory (pie_host_alloc): the scan's own kernels
+ * then deliver offsets / counts / rows to the host with no copy node behind the scan ("D2H of
+ * counts/offsets included"), complete when pie_scan_finish_packed returns with *ready_out = 1 or, with 0, after
+ * pie_synchronize. */
+int pie_scan_begin_packed2(pie_ctx *ctx, int64_t now, int64_t cutoff, void *dst_i32, size_t u_pad, size_t idx_cap,
+                           void *counts_dst_i32);
+/* Pinned host memory mapped into the device's address space: *host_out is the CPU address, *dev_out the address a
+ * kernel (or pie_scan_begin_packed*) uses for the same bytes. */
+int pie_host_alloc(pie_ctx *ctx, size_t bytes, void **host_out, void **dev_out);
+int pie_host_free(pie_ctx *ctx, void *host_ptr);
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                      size_t *m_out);
@@ -183,6 +195,20 @@ int pie_expired_queue(pie_ctx *ctx, int64_t prev_now, int64_t now, int32_t *queu
 int pie_archive_queue(pie_ctx *ctx, int64_t now, int64_t window_ms, int32_t *queue_out, size_t cap, size_t *q_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
+/* Pin the form of the table pass (the codes of pie_stats.k1_variant, DESIGN.md section 8: 0x01 reads every byte of the
+ * four columns, 0x03 the streaming form, 0xC85 the keyed form ...); form < 0 returns to the adaptive choice.  A tuning /
+ * measurement switch: every form produces identical results.  Not while a scan is in flight. */
+int pie_set_scan_form(pie_ctx *ctx, int form);
+typedef struct pie_table_info {
+    uint32_t struct_size;     /* set by caller to sizeof(pie_table_info) */
+    uint32_t has_keys;        /* 1: the derived liveness-key / payload columns exist and are in step */
+    uint64_t rows, users;
+    uint64_t table_bytes;     /* 24 * capacity rows: the four caller-visible columns */
+    uint64_t derived_bytes;   /* derived columns (2-byte key, 1-byte key, 16-byte payload record) */
+    uint64_t workspace_bytes; /* per-scan workspace of the two slots + histogram spans */
+    double index_build_ms;    /* host wall time of the last full build of the derived columns (kernels + syncs) */
+} pie_table_info;
+int pie_table_info_get(pie_ctx *ctx, pie_table_info *out);
 /* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
  * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */
 int pie_set_profiling(pie_ctx *ctx, int enabled);

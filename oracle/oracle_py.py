@@ -38,6 +38,11 @@ def lib():
         l.pie_oracle_scan.restype = C.c_int
         l.pie_oracle_scan.argtypes = [P, P, P, P, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, P, P, P,
                                       C.c_size_t, C.POINTER(C.c_size_t)]
+        l.pie_oracle_scan_mt.restype = C.c_int
+        l.pie_oracle_scan_mt.argtypes = [P, P, P, P, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, P, P, P,
+                                         C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
+        l.pie_oracle_gen_mt.restype = None
+        l.pie_oracle_gen_mt.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, P, P, P, P, C.c_int]
         l.pie_oracle_expired_queue.restype = C.c_int
         l.pie_oracle_expired_queue.argtypes = [P, C.c_size_t, C.c_int64, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_archive_queue.restype = C.c_int
@@ -95,6 +100,29 @@ def scan(start, end, user, disc, n_users, now, cutoff, mask):
     if rc != 0:
         raise RuntimeError("pie_oracle_scan rc=%d" % rc)
     return counts, offsets, idx[: m.value].copy()
+
+
+def gen_mt(seed, n_total, row0, n, n_users, n_disc, flags=0, threads=1):
+    """gen() on `threads` host threads (row slices); same corpus."""
+    s, e = np.empty(n, np.int64), np.empty(n, np.int64)
+    u, d = np.empty(n, np.int32), np.empty(n, np.int32)
+    lib().pie_oracle_gen_mt(seed, n_total, row0, n, n_users, n_disc, flags, _p(s), _p(e), _p(u), _p(d), int(threads))
+    return s, e, u, d
+
+
+def scan_mt(start, end, user, disc, n_users, now, cutoff, mask, threads, out=None):
+    """scan() on `threads` host threads (bench.py's cpu_baseline B2); identical output.  `out` = (counts, offsets, idx)
+    buffers to reuse between repetitions (idx sized n)."""
+    n = start.shape[0]
+    if out is None:
+        out = (np.empty(n_users, np.int32), np.empty(n_users + 1, np.int64), np.empty(max(n, 1), np.int32))
+    counts, offsets, idx = out
+    m = C.c_size_t(0)
+    rc = lib().pie_oracle_scan_mt(_p(start), _p(end), _p(user), _p(disc), n, n_users, int(now), int(cutoff),
+                                  int(mask) & (2 ** 64 - 1), _p(counts), _p(offsets), _p(idx), n, C.byref(m), int(threads))
+    if rc != 0:
+        raise RuntimeError("pie_oracle_scan_mt rc=%d" % rc)
+    return counts, offsets, idx[: m.value]
 
 
 def expired_queue(end, prev_now, now):

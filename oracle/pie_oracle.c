@@ -5,6 +5,7 @@
 #define _GNU_SOURCE
 #include "pie_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -164,6 +165,165 @@ int pie_oracle_scan(const int64_t *start, const int64_t *end, const int32_t *use
     for (size_t k = 0; k < m; ++k) idx[k] = pairs[k].idx;
     free(sel); free(pairs); free(cursor);
     return 0;
+}
+
+/* ---------------------------------------------------------------- the same scan on several host threads (B2) */
+
+typedef struct mt_job {
+    /* inputs */
+    const int64_t *start, *end;
+    const int32_t *user, *disc;
+    size_t n;
+    int32_t n_users;
+    int64_t now, cutoff;
+    uint64_t mask;
+    int n_threads, tid;
+    /* shared state */
+    struct mt_job *all;
+    int32_t *counts;      /* global */
+    int64_t *offsets;     /* global */
+    pair_t *pairs, *tmp;  /* global, m entries each */
+    int32_t *idx;
+    pthread_barrier_t *bar;
+    volatile int *err;
+    size_t *m_shared;
+    size_t idx_cap;
+    /* per thread */
+    int32_t *sel;         /* selected rows of this thread's chunk, in row order */
+    size_t n_sel;
+    int32_t *cnt;         /* per-user counts of this chunk, then this chunk's first slot per user */
+} mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    const int T = j->n_threads, t = j->tid;
+    const size_t lo = j->n * (size_t)t / (size_t)T, hi = j->n * (size_t)(t + 1) / (size_t)T;
+    /* phase 1: select this chunk (row order == Map insertion order, server/sessionStore.js:59,68) */
+    size_t cap = (hi - lo) / 64 + 1024, m = 0;
+    int32_t *sel = (int32_t *)malloc(cap * sizeof(int32_t));
+    int32_t *cnt = (int32_t *)calloc((size_t)j->n_users, sizeof(int32_t));
+    if (!sel || !cnt) *j->err = -3;
+    for (size_t i = lo; i < hi && !*j->err; ++i) {
+        if (!pie_oracle_selected(j->start[i], j->end[i], j->disc[i], j->now, j->cutoff, j->mask)) continue;
+        const int32_t u = j->user[i];
+        if (u < 0 || u >= j->n_users) { *j->err = -2; break; }
+        if (m == cap) {
+            cap *= 2;
+            int32_t *p = (int32_t *)realloc(sel, cap * sizeof(int32_t));
+            if (!p) { *j->err = -3; break; }
+            sel = p;
+        }
+        sel[m++] = (int32_t)i;
+        cnt[u]++;
+    }
+    j->sel = sel; j->n_sel = m; j->cnt = cnt;
+    pthread_barrier_wait(j->bar);
+    if (*j->err) return NULL;
+    /* phase 2: counts[u] = sum over chunks (users split over the threads) */
+    const int32_t ulo = (int32_t)((int64_t)j->n_users * t / T), uhi = (int32_t)((int64_t)j->n_users * (t + 1) / T);
+    for (int32_t u = ulo; u < uhi; ++u) {
+        int32_t c = 0;
+        for (int k = 0; k < T; ++k) c += j->all[k].cnt[u];
+        j->counts[u] = c;
+    }
+    pthread_barrier_wait(j->bar);
+    if (t == 0) { /* the prefix over U users is serial: 10^5 additions */
+        j->offsets[0] = 0;
+        for (int32_t u = 0; u < j->n_users; ++u) j->offsets[u + 1] = j->offsets[u] + j->counts[u];
+        const size_t m_all = (size_t)j->offsets[j->n_users];
+        *j->m_shared = m_all;
+        if (m_all > 0 && m_all <= j->idx_cap) { /* bucket arrays sized by M, now that it is known */
+            j->all[0].pairs = (pair_t *)malloc(m_all * sizeof(pair_t));
+            j->all[0].tmp = (pair_t *)malloc(m_all * sizeof(pair_t));
+            if (!j->all[0].pairs || !j->all[0].tmp) { free(j->all[0].pairs); free(j->all[0].tmp); j->all[0].pairs = j->all[0].tmp = NULL; *j->err = -3; }
+        }
+    }
+    pthread_barrier_wait(j->bar);
+    if (!j->all[0].pairs) return NULL; /* caller's idx too small, nothing selected, or out of memory: counts/offsets are done */
+    /* phase 3: chunk k's first slot in bucket u = offsets[u] + rows of u in chunks before k (cnt becomes that slot,
+     * relative to offsets[u]; it fits int32 because a bucket holds < 2^31 rows) */
+    for (int32_t u = ulo; u < uhi; ++u) {
+        int32_t run = 0;
+        for (int k = 0; k < T; ++k) { const int32_t c = j->all[k].cnt[u]; j->all[k].cnt[u] = run; run += c; }
+    }
+    pthread_barrier_wait(j->bar);
+    pair_t *pairs = j->all[0].pairs, *tmp = j->all[0].tmp;
+    for (size_t k = 0; k < m; ++k) { /* fill buckets in row order */
+        const int32_t i = sel[k];
+        const int32_t u = j->user[i];
+        pair_t *p = &pairs[j->offsets[u] + cnt[u]++];
+        p->start = j->start[i];
+        p->idx = i;
+    }
+    pthread_barrier_wait(j->bar);
+    /* phase 4: per-bucket stable order, users split over the threads; scratch = the same slots of tmp */
+    for (int32_t u = ulo; u < uhi; ++u)
+        if (j->counts[u] > 1) stable_sort_pairs(pairs + j->offsets[u], tmp + j->offsets[u], (size_t)j->counts[u]);
+    for (int64_t k = j->offsets[ulo]; k < j->offsets[uhi]; ++k) j->idx[k] = pairs[k].idx;
+    return NULL;
+}
+
+int pie_oracle_scan_mt(const int64_t *start, const int64_t *end, const int32_t *user, const int32_t *disc, size_t n,
+                       int32_t n_users, int64_t now, int64_t cutoff, uint64_t disc_mask, int32_t *counts,
+                       int64_t *offsets, int32_t *idx, size_t idx_cap, size_t *m_out, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof(mt_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    volatile int err = 0;
+    size_t m = 0;
+    if (!jobs || !th) { free(jobs); free(th); return -3; }
+    pthread_barrier_init(&bar, NULL, (unsigned)n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        mt_job *j = &jobs[t];
+        j->start = start; j->end = end; j->user = user; j->disc = disc; j->n = n; j->n_users = n_users;
+        j->now = now; j->cutoff = cutoff; j->mask = disc_mask; j->n_threads = n_threads; j->tid = t; j->all = jobs;
+        j->counts = counts; j->offsets = offsets; j->idx = idx; j->bar = &bar;
+        j->err = &err; j->m_shared = &m; j->idx_cap = idx_cap;
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    for (int t = 0; t < n_threads; ++t) { free(jobs[t].sel); free(jobs[t].cnt); }
+    free(jobs[0].pairs); free(jobs[0].tmp);
+    free(jobs); free(th);
+    if (m_out) *m_out = m;
+    if (err) return err;
+    return m > idx_cap ? -1 : 0;
+}
+
+typedef struct {
+    uint64_t seed; int64_t n_total, row0, n; int32_t n_users, n_disc; uint32_t flags;
+    int64_t *start, *end; int32_t *user, *disc;
+} gen_job;
+
+static void *gen_worker(void *arg)
+{
+    gen_job *g = (gen_job *)arg;
+    pie_oracle_gen(g->seed, g->n_total, g->row0, g->n, g->n_users, g->n_disc, g->flags, g->start, g->end, g->user, g->disc);
+    return NULL;
+}
+
+void pie_oracle_gen_mt(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
+                       uint32_t flags, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    gen_job *jobs = (gen_job *)calloc((size_t)n_threads, sizeof(gen_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); pie_oracle_gen(seed, n_total, row0, n, n_users, n_disc, flags, start, end, user, disc); return; }
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+        gen_job *g = &jobs[t];
+        g->seed = seed; g->n_total = n_total; g->row0 = row0 + lo; g->n = hi - lo; g->n_users = n_users; g->n_disc = n_disc;
+        g->flags = flags; g->start = start + lo; g->end = end + lo; g->user = user + lo; g->disc = disc + lo;
+        pthread_create(&th[t], NULL, gen_worker, g);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(jobs); free(th);
 }
 
 /* ---------------------------------------------------------------- "next" row: dispatch-queue compaction */

@@ -53,6 +53,17 @@ int pie_oracle_scan(const int64_t *start, const int64_t *end, const int32_t *use
                     int32_t n_users, int64_t now, int64_t cutoff, uint64_t disc_mask, int32_t *counts,
                     int64_t *offsets, int32_t *idx, size_t idx_cap, size_t *m_out);
 
+/* The same scan on `n_threads` host threads (baseline B2 "all host threads" of BASELINE.md section 3; bench.py's
+ * cpu_baseline leg only).  Rows are split into contiguous chunks, one per thread: select + per-thread histogram, then a
+ * per-user prefix over the threads (so every bucket is still filled in row order), then the buckets are ordered in
+ * parallel over users.  Output identical to pie_oracle_scan.  Same return codes. */
+int pie_oracle_scan_mt(const int64_t *start, const int64_t *end, const int32_t *user, const int32_t *disc, size_t n,
+                       int32_t n_users, int64_t now, int64_t cutoff, uint64_t disc_mask, int32_t *counts,
+                       int64_t *offsets, int32_t *idx, size_t idx_cap, size_t *m_out, int n_threads);
+/* pie_oracle_gen on n_threads threads (row slices). */
+void pie_oracle_gen_mt(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
+                       uint32_t flags, int64_t *start, int64_t *end, int32_t *user, int32_t *disc, int n_threads);
+
 /* "next" row: newly-expired change predicate  prev_now < end <= now  -> ordered queue. */
 int pie_oracle_expired_queue(const int64_t *end, size_t n, int64_t prev_now, int64_t now, int32_t *queue,
                              size_t cap, size_t *q_out);

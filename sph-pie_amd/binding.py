@@ -23,12 +23,20 @@ class PieError(RuntimeError):
         self.code = code
 
 
+class PieTableInfo(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("has_keys", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
+        ("table_bytes", C.c_uint64), ("derived_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64),
+        ("index_build_ms", C.c_double),
+    ]
+
+
 class PieStats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("n_profiled", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
         ("selected", C.c_uint64), ("alg_bytes", C.c_uint64), ("k1_ms_sum", C.c_double), ("scan_ms_sum", C.c_double),
         ("max_bucket", C.c_uint32), ("n_segments", C.c_uint32), ("n_big", C.c_uint32), ("k1_blocks", C.c_uint32),
-        ("k1_variant", C.c_uint32), ("key_ambiguous", C.c_uint32), ("live", C.c_uint64),
+        ("k1_variant", C.c_uint32), ("key_ambiguous", C.c_uint32), ("live", C.c_uint64), ("candidates", C.c_uint64),
     ]
 
 
@@ -60,6 +68,11 @@ _SIGS = [
     ("pie_scan_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
     ("pie_scan_begin_packed", C.c_int, [_P, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t]),
     ("pie_scan_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    ("pie_scan_begin_packed2", C.c_int, [_P, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    ("pie_host_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(_P)]),
+    ("pie_host_free", C.c_int, [_P, _P]),
+    ("pie_set_scan_form", C.c_int, [_P, C.c_int]),
+    ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_read_user_feed", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
@@ -265,15 +278,41 @@ class PieScan:
 
     def scan_finish(self):
         m = C.c_size_t(0)
-        if self._begun:
+        rc = self._lib.pie_scan_finish(self._ctx, C.byref(m))
+        if self._begun and rc != -6:   # the library dropped the oldest scan (finished or failed); PIE_E_STATE: nothing was in flight
             self._begun.pop(0)
-        self._check(self._lib.pie_scan_finish(self._ctx, C.byref(m)))
+        self._check(rc)
         return m.value
 
     def scan_begin_packed(self, now, cutoff, dst_ptr, u_pad, idx_cap):
         """scan_begin whose scan also writes its result message (layout of pack_results_device) into dst_ptr."""
         self._check(self._lib.pie_scan_begin_packed(self._ctx, int(now), int(cutoff), dst_ptr, int(u_pad), int(idx_cap)))
         self._begun.append(True)
+
+    def scan_begin_packed2(self, now, cutoff, dst_ptr, u_pad, idx_cap, counts_ptr=None):
+        """scan_begin_packed with a second destination for counts[U]; both may be mapped pinned host memory (host_alloc)."""
+        self._check(self._lib.pie_scan_begin_packed2(self._ctx, int(now), int(cutoff), dst_ptr, int(u_pad), int(idx_cap), counts_ptr))
+        self._begun.append(True)
+
+    def host_alloc(self, n_words):
+        """Mapped pinned host memory of n_words int32.  -> (numpy view of the host side, device address, host address)."""
+        h, d = _P(), _P()
+        self._check(self._lib.pie_host_alloc(self._ctx, int(n_words) * 4, C.byref(h), C.byref(d)))
+        arr = np.ctypeslib.as_array(C.cast(h.value, C.POINTER(C.c_int32)), shape=(int(n_words),))
+        return arr, d.value, h.value
+
+    def host_free(self, host_addr):
+        self._check(self._lib.pie_host_free(self._ctx, host_addr))
+
+    def set_scan_form(self, form):
+        """Pin the table-pass form (pie_stats.k1_variant codes); form < 0: adaptive."""
+        self._check(self._lib.pie_set_scan_form(self._ctx, int(form)))
+
+    def table_info(self):
+        ti = PieTableInfo()
+        ti.struct_size = C.sizeof(PieTableInfo)
+        self._check(self._lib.pie_table_info_get(self._ctx, C.byref(ti)))
+        return {k: getattr(ti, k) for k, _ in PieTableInfo._fields_}
 
     def in_flight_packed(self):
         """True when the oldest scan in flight was begun with scan_begin_packed."""
@@ -283,9 +322,10 @@ class PieScan:
         """-> (M, ready): ready = the message was complete in device memory on return (no stream ordering needed);
         otherwise a pack kernel was enqueued on the context's stream."""
         m, ready = C.c_size_t(0), C.c_int(0)
-        if self._begun:
+        rc = self._lib.pie_scan_finish_packed(self._ctx, C.byref(m), C.byref(ready))
+        if self._begun and rc != -6:
             self._begun.pop(0)
-        self._check(self._lib.pie_scan_finish_packed(self._ctx, C.byref(m), C.byref(ready)))
+        self._check(rc)
         return int(m.value), bool(ready.value)
 
     def scan_pipelined(self, k, now, cutoff):

@@ -61,6 +61,7 @@ struct Summary {
                                 // streaming pass: selected rows whose lane neighbour selected a row of the same user
     unsigned int n_hot;         // users whose bucket exceeded the hot threshold (candidates for the next scan's hot set)
     unsigned int n_over;        // listed buckets with staged records (outgrew the direct slots / hot user / no slots): K3 needed
+    unsigned long long cand;    // keyed table pass: candidate rows (key >= key(now)), i.e. payload records gathered
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -81,29 +82,34 @@ struct HostSummary {
 // streams), so the blocks spread over 64 counters on separate 128-byte lines, right behind the scan's Summary; the
 // kernel that publishes the summary adds them up.
 struct alignas(128) StatSlot {
-    unsigned long long live, amb;
-    unsigned long long pad[14];
+    unsigned long long live, amb, cand;
+    unsigned long long pad[13];
 };
 constexpr int kStatSlots = 64;
 constexpr int kSummaryBytes = 128; // Summary, padded: the slots start here
 static_assert(sizeof(Summary) <= kSummaryBytes, "Summary outgrew its padded slot");
 __device__ __forceinline__ StatSlot* stat_slots(Summary* s) { return reinterpret_cast<StatSlot*>(reinterpret_cast<char*>(s) + kSummaryBytes); }
-__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb, int bid = (int)blockIdx.x)
+__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb, int bid = (int)blockIdx.x, int cand = 0)
 {
     StatSlot* slot = stat_slots(s) + (bid & (kStatSlots - 1));
     if (live) atomicAdd(&slot->live, (unsigned long long)live);
     if (amb) atomicAdd(&slot->amb, (unsigned long long)amb);
+    if (cand) atomicAdd(&slot->cand, (unsigned long long)cand);
 }
 // one wave: lane l reads slot l; every lane returns the totals
-__device__ __forceinline__ void sum_row_stats(Summary* s, int lane, unsigned long long& live, unsigned long long& amb)
+__device__ __forceinline__ void sum_row_stats(Summary* s, int lane, unsigned long long& live, unsigned long long& amb,
+                                              unsigned long long* cand = nullptr)
 {
     StatSlot* slot = stat_slots(s) + (lane & (kStatSlots - 1));
     live = __hip_atomic_load(&slot->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     amb = __hip_atomic_load(&slot->amb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cd = __hip_atomic_load(&slot->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int o = 32; o > 0; o >>= 1) {
         live += __shfl_xor(live, o, 64);
         amb += __shfl_xor(amb, o, 64);
+        cd += __shfl_xor(cd, o, 64);
     }
+    if (cand) *cand = cd;
 }
 
 constexpr int kWave = 64;
@@ -730,13 +736,14 @@ __device__ __forceinline__ void scan_keyed_body(
     __shared__ int blk_cursor;
     __shared__ int blk_live;
     __shared__ int blk_amb;
+    __shared__ int blk_cand;
     __shared__ int blk_hot_cnt[kHotMax];
     constexpr int kPerLane = 16 / (int)sizeof(KT); // rows per lane per 16-byte load
     constexpr int kRowsPerLoad = kPerLane * kWave;
     constexpr int kTile = kRowsPerLoad * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; }
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; blk_cand = 0; }
     if (AGG && threadIdx.x < kHotMax) blk_hot_cnt[threadIdx.x] = 0;
     __syncthreads();
 
@@ -751,7 +758,7 @@ __device__ __forceinline__ void scan_keyed_body(
     st.head = 0;
     st.fill = 0;
     int* lring = live_ring[wave];
-    int lhead = 0, lfill = 0, nlive = 0, namb = 0; // wave-uniform
+    int lhead = 0, lfill = 0, nlive = 0, namb = 0, ncand = 0; // wave-uniform
 
     // evaluate `cnt` queued candidates (cnt <= 64), one per lane; bit 31 of a ring entry marks an ambiguous key
     // step A state (gathers in flight), step B state (atomics in flight); all "have" flags are wave-uniform
@@ -787,6 +794,7 @@ __device__ __forceinline__ void scan_keyed_body(
         }
         nlive += __popcll(__ballot(live));
         namb += __popcll(__ballot(a_valid && a_amb));
+        ncand += __popcll(__ballot(a_valid));
         // hot users: rank inside the block from an LDS counter, flagged (see HotSet); the rest: wave-aggregated
         // histogram atomics for skewed users (see k_scan_live_first)
         bool hotrow = false;
@@ -922,10 +930,11 @@ __device__ __forceinline__ void scan_keyed_body(
     if (st.fill > 0) stage_flush(st, st.fill, out, out_rank, &blk_cursor, lane);
     if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
     if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
+    if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_count[bid] = blk_cursor;
-        add_row_stats(summary, blk_live, blk_amb, bid);
+        add_row_stats(summary, blk_live, blk_amb, bid, blk_cand);
     }
     if constexpr (AGG) { // one histogram atomic per (block, hot user); K3 needs the base it returned
         if ((int)threadIdx.x < hot.n) {
@@ -1247,6 +1256,7 @@ __global__ __launch_bounds__(256) void k_publish_summary(Summary* __restrict__ s
         Summary out = *summary;
         out.live = live;
         out.amb = amb;
+        out.cand = 0;
         out.max_count = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         out.n_seg = out.n_big = out.n_small = 0;
         out.q = 0;
@@ -1404,7 +1414,8 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
                                                  DirectSlots direct, BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, const HotSet& hot,
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap,
+                                                 int* __restrict__ msg_counts, const HotSet& hot,
                                                  int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
@@ -1434,7 +1445,10 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
         c[k] = (u0 + k < n_users) ? counts[hist_index(u0 + k, n_users)] : 0;
-        if (u0 + k < n_users) counts_ord[u0 + k] = c[k];
+        if (u0 + k < n_users) {
+            counts_ord[u0 + k] = c[k];
+            if (msg_counts) msg_store(msg_counts + u0 + k, c[k]); // the caller's copy (e.g. mapped host memory), see pie_scan_begin_packed2
+        }
     }
     unsigned int local_max = 0;
 #pragma unroll
@@ -1639,10 +1653,11 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
     if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == (unsigned)nblk - 1u && host) ? 1 : 0;
     __syncthreads();
     if (is_last && threadIdx.x < 64) {
-        unsigned long long live = 0, amb = 0;
-        sum_row_stats(summary, (int)threadIdx.x, live, amb); // K1 finished before this kernel started
+        unsigned long long live = 0, amb = 0, cand = 0;
+        sum_row_stats(summary, (int)threadIdx.x, live, amb, &cand); // K1 finished before this kernel started
         if (threadIdx.x == 0) {
             Summary out;
+            out.cand = cand;
             out.m = __hip_atomic_load(&summary->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.n_seg = __hip_atomic_load(&summary->n_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.n_big = __hip_atomic_load(&summary->n_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1670,10 +1685,11 @@ __global__ __launch_bounds__(BLOCK) void k_offsets(const int* __restrict__ count
                                                  Summary* __restrict__ summary, HostSummary* __restrict__ host,
                                                  unsigned long long seq, int4* __restrict__ zero_span, long long zero_vec16,
                                                  DirectSlots direct, BktRec* __restrict__ bkt,
-                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap, HotSet hot,
+                                                 int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap,
+                                                 int* __restrict__ msg_counts, HotSet hot,
                                                  int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list)
 {
-    offsets_body<UPT, ORDER, BLOCK>(counts, counts_ord, n_users, tile_pub, ctl, offsets, seg_list, small_list, big_list, summary, host, seq, zero_span, zero_vec16, direct, bkt, out_idx, msg, u_pad, msg_cap, hot, hot_thr, hot_list, over_list, (int)blockIdx.x, (int)gridDim.x);
+    offsets_body<UPT, ORDER, BLOCK>(counts, counts_ord, n_users, tile_pub, ctl, offsets, seg_list, small_list, big_list, summary, host, seq, zero_span, zero_vec16, direct, bkt, out_idx, msg, u_pad, msg_cap, msg_counts, hot, hot_thr, hot_list, over_list, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ K1(i+1) + K2(i) in one launch
@@ -1722,6 +1738,7 @@ struct OffsetsArgs {
     int* msg;
     int u_pad;
     long long msg_cap;
+    int* msg_counts;
     HotSet hot;
     int hot_thr;
     int* hot_list;
@@ -1735,7 +1752,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
     if ((int)blockIdx.x < t.n_tail) {
         offsets_body<1, true, kK1Threads>(t.counts, t.counts_ord, t.n_users, t.tile_pub, t.ctl, t.offsets, t.seg_list, t.small_list,
                                           t.big_list, t.summary, t.host, t.seq, t.zero_span, t.zero_vec16, t.direct, t.bkt, t.out_idx,
-                                          t.msg, t.u_pad, t.msg_cap, t.hot, t.hot_thr, t.hot_list, t.over_list, (int)blockIdx.x, t.n_tail);
+                                          t.msg, t.u_pad, t.msg_cap, t.msg_counts, t.hot, t.hot_thr, t.hot_list, t.over_list, (int)blockIdx.x, t.n_tail);
     } else {
         scan_keyed_body<UNROLL, AGG, NT, KT, false>(a.pay, a.end, a.key, a.n, a.rows_per_block, a.now, a.now_key, a.cutoff, a.mask,
                                                       a.n_users, a.counts, a.sel, a.sel_rank, a.blk_count, a.summary, a.direct, a.hot,

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -74,6 +75,7 @@ struct Slot {
     int* msg = nullptr;            // this scan's result message (caller-owned device memory), or nullptr
     int msg_u_pad = 0;
     long long msg_cap = 0;
+    int* msg_counts = nullptr;     // optional second destination: the per-user counts (pie_scan_begin_packed2)
     bool msg_by_k2 = false;        // K2 wrote the message (fused route)
     int* out_idx = nullptr;
     Segment* seg_list = nullptr;
@@ -162,6 +164,8 @@ struct pie_ctx {
     char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
     int span_next = 0;
     int profile_every = 1;   // with profiling on, every n-th scan carries timing events
+    double index_build_ms = 0;         // pie_table_info: last full build of the derived columns
+    double wait_deadline_ms = 20000.0; // bound of every wait on a scan summary (PIE_WAIT_DEADLINE_MS)
     unsigned long long scans_begun = 0;
     int next_slot = 0;   // slot the next pie_scan_begin uses
     int n_flight = 0;    // scans begun and not finished (0..2)
@@ -418,6 +422,12 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     if (c->n == 0) { c->key_ok = true; c->key_base = 0; c->key_shift = 0; c->key_dirty = false; return PIE_OK; }
     hipStream_t s = c->stream;
     const int grid = c->n_cus * 8;
+    const bool full_build = row0 == 0 || !c->key_ok || rebuild;
+    timespec tb0{};
+    if (full_build) { // index_build_ms of pie_table_info: everything from here to the last key kernel's completion
+        PIE_HIP(c, hipStreamSynchronize(s));
+        clock_gettime(CLOCK_MONOTONIC, &tb0);
+    }
     if (row0 == 0 || !c->key_ok || rebuild) {
         const long long init[2] = {INT64_MAX, INT64_MIN};
         long long got[2];
@@ -475,6 +485,12 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     hipLaunchKernelGGL(k_build_fine_key, dim3(grid), dim3(256), 0, s, c->d_end, row0, c->n, c->fkey_base, c->fkey_shift, c->d_fkey);
     PIE_HIP(c, hipGetLastError());
     c->key_ok = true;
+    if (full_build) {
+        PIE_HIP(c, hipStreamSynchronize(s));
+        timespec tb1{};
+        clock_gettime(CLOCK_MONOTONIC, &tb1);
+        c->index_build_ms = (double)(tb1.tv_sec - tb0.tv_sec) * 1e3 + (double)(tb1.tv_nsec - tb0.tv_nsec) * 1e-6;
+    }
     return PIE_OK;
 }
 
@@ -632,7 +648,7 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
 #define PIE_K2O(B)                                                                                                          \
     hipLaunchKernelGGL((k_offsets<1, true, B>), dim3(order_tiles), dim3(B), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,   \
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16, \
-                       direct_of(c, sl), sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap, sl.hot, hot_thr, sl.hot_list, sl.over_list)
+                       direct_of(c, sl), sl.bkt, sl.out_idx, sl.msg, sl.msg_u_pad, sl.msg_cap, sl.msg_counts, sl.hot, hot_thr, sl.hot_list, sl.over_list)
         if (ob == 256) PIE_K2O(256);
         else if (ob == 512) PIE_K2O(512);
         else PIE_K2O(1024);
@@ -642,7 +658,7 @@ void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long z
     }
     hipLaunchKernelGGL((k_offsets<8, false, 256>), dim3(c->n_tiles), dim3(256), 0, s, sl.counts, sl.counts_ord, c->n_users, sl.tile_pub, sl.ctl,
                        sl.offsets, sl.seg_list, sl.small_list, sl.big_list, sl.sum, sl.h_sum_dev, sl.seq, zero_span, zero_vec16,
-                       direct_of(c, sl), sl.bkt, (int*)nullptr, (int*)nullptr, 0, 0LL, sl.hot, hot_thr, sl.hot_list, sl.over_list);
+                       direct_of(c, sl), sl.bkt, (int*)nullptr, (int*)nullptr, 0, 0LL, (int*)nullptr, sl.hot, hot_thr, sl.hot_list, sl.over_list);
     sl.msg_by_k2 = false;
     if (sl.direct) launch_sort_tiny(c, sl, s);
 }
@@ -670,7 +686,7 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
     t.offsets = tail.offsets; t.seg_list = tail.seg_list; t.small_list = tail.small_list; t.big_list = tail.big_list;
     t.summary = tail.sum; t.host = tail.h_sum_dev; t.seq = tail.seq; t.zero_span = tail.zero_span;
     t.zero_vec16 = (long long)(counts_span(c) / 16); t.direct = direct_of(c, tail); t.bkt = tail.bkt; t.out_idx = tail.out_idx;
-    t.msg = tail.msg; t.u_pad = tail.msg_u_pad; t.msg_cap = tail.msg_cap; t.hot = tail.hot; t.hot_thr = hot_threshold(c);
+    t.msg = tail.msg; t.u_pad = tail.msg_u_pad; t.msg_cap = tail.msg_cap; t.msg_counts = tail.msg_counts; t.hot = tail.hot; t.hot_thr = hot_threshold(c);
     t.hot_list = tail.hot_list; t.over_list = tail.over_list;
     t.n_tail = (c->n_users + kK1Threads - 1) / kK1Threads;
     tail.msg_by_k2 = tail.msg != nullptr;
@@ -691,7 +707,8 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
 }
 
 // Head of a scan: K1 and K2 on the stream (plus the tiny-bucket order kernel when buckets have direct slots).  No host wait.
-int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, int msg_u_pad = 0, long long msg_cap = 0)
+int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, int msg_u_pad = 0, long long msg_cap = 0,
+               int* msg_counts = nullptr)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n_flight >= 2) return fail(c, PIE_E_STATE, "two scans are already in flight: call pie_scan_finish first");
@@ -775,6 +792,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     sl.msg = msg;
     sl.msg_u_pad = msg_u_pad;
     sl.msg_cap = msg_cap;
+    sl.msg_counts = msg_counts;
     sl.msg_by_k2 = false;
 
     // this scan's histogram span (zeroed by the previous scan's K2, or by the load) and the one K2 will zero
@@ -871,27 +889,64 @@ int scan_finish(pie_ctx* c)
         PIE_HIP(c, hipGetLastError());
         sl.k2_pending = false;
     }
-    sl.in_flight = false;
-    c->n_flight--;
-    // wait for K2's last block to publish the summary in mapped host memory (no copy node, no event wait);
-    // the event is only the fallback if the mapped write is not observed
+    // wait for K2's last block to publish the summary in mapped host memory (no copy node, no event wait).  The wait is
+    // bounded (PIE_WAIT_DEADLINE_MS, default 20 s): a kernel that never finishes must not hang the caller — in the Node
+    // host that is the JS main thread.  The slot stays in flight until its summary has been read, so an error return
+    // leaves the context consistent: the failed scan is dropped (no result), the stream is left to drain.
     {
         volatile unsigned long long* seq = &sl.h_sum->seq;
         unsigned long long spins = 0;
+        bool from_device = false;
+        timespec t0{};
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         while (*seq != sl.seq) {
             __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0) { // ~every few ms: make sure the stream is still healthy
+            if ((++spins & 0x3FFFF) == 0) { // every ~1 ms: is the stream still healthy, is the deadline up?
                 hipError_t q = hipStreamQuery(c->stream);
-                if (q != hipSuccess && q != hipErrorNotReady) return fail(c, PIE_E_HIP, "scan failed: %s", hipGetErrorString(q));
                 if (q == hipSuccess && *seq != sl.seq) {
                     // the stream drained but the mapped write is not visible: read the device copy instead
-                    PIE_HIP(c, hipMemcpy(&sl.h_sum->s, sl.sum, sizeof(Summary), hipMemcpyDeviceToHost));
+                    from_device = true;
                     break;
+                }
+                timespec t1{};
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                const double waited_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+                if ((q != hipSuccess && q != hipErrorNotReady) || waited_ms > c->wait_deadline_ms) {
+                    sl.in_flight = false;
+                    sl.have_result = false;
+                    c->n_flight--;
+                    if (c->res == &sl) c->res = nullptr;
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(c, PIE_E_HIP, "scan failed: %s", hipGetErrorString(q));
+                    return fail(c, PIE_E_HIP, "scan summary not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", c->wait_deadline_ms);
                 }
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (from_device) {
+            // K2 writes live / amb only to the host copy: take every other field from the device Summary and the row
+            // statistics from their slots (the same sum K2's last block makes)
+            std::vector<unsigned char> raw(span_stats_bytes());
+            hipError_t e = hipMemcpy(raw.data(), sl.sum, raw.size(), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                sl.in_flight = false;
+                c->n_flight--;
+                return fail(c, PIE_E_HIP, "summary read-back: %s", hipGetErrorString(e));
+            }
+            Summary dev;
+            memcpy(&dev, raw.data(), sizeof dev);
+            dev.live = dev.amb = dev.cand = 0;
+            for (int k = 0; k < kStatSlots; ++k) {
+                StatSlot st;
+                memcpy(&st, raw.data() + kSummaryBytes + (size_t)k * sizeof(StatSlot), sizeof st);
+                dev.live += st.live;
+                dev.amb += st.amb;
+                dev.cand += st.cand;
+            }
+            sl.h_sum->s = dev;
+        }
     }
+    sl.in_flight = false;
+    c->n_flight--;
     sl.last = sl.h_sum->s;
     if (sl.fast) {
         if (sl.last.pad & 1u) {
@@ -1117,6 +1172,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
+    if (const char* v = getenv("PIE_WAIT_DEADLINE_MS")) { const double d = atof(v); if (d > 0) c->wait_deadline_ms = d; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);
         c->keyed_enabled = k != 0;
@@ -1453,6 +1509,14 @@ int pie_scan_begin_packed(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32
     return scan_begin(c, now, cutoff, (int*)dst_i32, (int)u_pad, (long long)idx_cap);
 }
 
+int pie_scan_begin_packed2(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32, size_t u_pad, size_t idx_cap, void* counts_dst_i32)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    return scan_begin(c, now, cutoff, (int*)dst_i32, (int)u_pad, (long long)idx_cap, (int*)counts_dst_i32);
+}
+
 int pie_scan_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
 {
     if (!c) return PIE_E_INVAL;
@@ -1470,6 +1534,9 @@ int pie_scan_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
         if (ready_out) *ready_out = 1;
         return PIE_OK;
     }
+    // the unfused K2 wrote neither destination; the fused one wrote the counts but not the rows of the outgrown buckets
+    if (sl.msg_counts && !sl.msg_by_k2)
+        PIE_HIP(c, hipMemcpyAsync(sl.msg_counts, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDefault, c->stream));
     return pie_pack_results_device(c, sl.msg, (size_t)sl.msg_u_pad, (size_t)sl.msg_cap);
 }
 
@@ -1755,6 +1822,68 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
     return PIE_OK;
 }
 
+int pie_set_scan_form(pie_ctx* c, int form)
+{
+    if (!c) return PIE_E_INVAL;
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (form < 0) {
+        c->k1_pinned = false;
+        c->k1_variant = 0x03;
+    } else {
+        c->k1_pinned = true;
+        c->k1_variant = form;
+    }
+    return PIE_OK;
+}
+
+int pie_table_info_get(pie_ctx* c, pie_table_info* out)
+{
+    if (!c || !out) return PIE_E_INVAL;
+    if (out->struct_size != sizeof(pie_table_info)) return fail(c, PIE_E_INVAL, "pie_table_info.struct_size mismatch");
+    const size_t rows = (size_t)c->cap_rows, users = (size_t)c->cap_users;
+    out->has_keys = (c->key_ok && c->d_key && c->d_pay && c->d_fkey) ? 1u : 0u;
+    out->rows = (uint64_t)c->n;
+    out->users = (uint64_t)c->n_users;
+    out->table_bytes = (uint64_t)rows * 24u;
+    out->derived_bytes = (c->d_key && c->d_pay && c->d_fkey) ? (uint64_t)rows * (sizeof(lkey_t) + sizeof(fkey_t) + sizeof(PayRec)) + 128u : 0u;
+    // mirrors ensure_capacity(): per slot sel + sel_rank + bkt + out_idx (row-sized), the direct slots, the per-user arrays
+    uint64_t per_slot = 0;
+    if (rows) {
+        per_slot += (uint64_t)(rows + 256) * (sizeof(SelRec) + 4) + (uint64_t)rows * (sizeof(BktRec) + 4);
+        per_slot += (uint64_t)users * (8 + 4 + 4 + sizeof(Segment) * 2 + 4) + (uint64_t)(rows / kSegMax) * sizeof(Segment);
+        if (c->slot[0].direct) per_slot += ((uint64_t)users << c->dshift) * sizeof(BktRec);
+        per_slot += (uint64_t)kPartMax * kPartCap * sizeof(SelRec);
+    }
+    out->workspace_bytes = rows ? 2 * per_slot + 3 * (uint64_t)counts_span(c) : 0;
+    out->index_build_ms = c->index_build_ms;
+    return PIE_OK;
+}
+
+int pie_host_alloc(pie_ctx* c, size_t bytes, void** host_out, void** dev_out)
+{
+    if (!c || !host_out || !dev_out || bytes == 0) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    void* h = nullptr;
+    void* d = nullptr;
+    PIE_HIP(c, hipHostMalloc(&h, bytes, hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); return fail(c, PIE_E_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    memset(h, 0, bytes);
+    *host_out = h;
+    *dev_out = d;
+    return PIE_OK;
+}
+
+int pie_host_free(pie_ctx* c, void* host_ptr)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!host_ptr) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    PIE_HIP(c, hipStreamSynchronize(c->stream)); // a scan may still be writing it
+    PIE_HIP(c, hipHostFree(host_ptr));
+    return PIE_OK;
+}
+
 int pie_set_profiling(pie_ctx* c, int enabled)
 {
     if (!c) return PIE_E_INVAL;
@@ -1785,6 +1914,7 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
     out->k1_variant = sl ? (uint32_t)sl->variant : 0;
     out->key_ambiguous = (c->res && (c->res->variant & 0x400)) ? (uint32_t)(c->res->last.amb > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->res->last.amb) : 0u;
     out->live = sl ? sl->last.live : 0;
+    out->candidates = (sl && (sl->variant & 0x400)) ? sl->last.cand : 0;
     return PIE_OK;
 }
 
