@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--mode", choices=["scan", "expired"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic)")
+    ap.add_argument("--queries-per-launch", type=int, default=1,
+                    help="Q > 1: every step is ONE batched scan of Q queries (Q feed requests with their own `now`, one table pass: "
+                         "pie_scan_batch_*); value counts Q x U feeds per step")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="scans in flight: 2 = the table pass of step i+1 overlaps the scatter/order tail of step i")
     args = ap.parse_args()
@@ -264,6 +267,10 @@ def main():
     feeds = ShardedFeeds(backend, rank, world, u_local, always_collective=gather, batch=args.gather_batch) if gather else None
 
     expired_window = (T0_MS - 30 * DAY, T0_MS - 29 * DAY)   # one day of expiries: ~0.83 % of the rows queue up
+    Q = max(1, min(args.queries_per_launch, pie.PIE_BATCH_MAX))
+    # the batch: Q requests that arrived within a few seconds of each other — each samples its own clock (sessionStore.js:67),
+    # same day's cutoff, same role mask; query 0 is the single-query workload
+    batch_queries = [(now - 977 * q, cutoff, mask) for q in range(Q)]
 
     def run_steps(k):
         """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1."""
@@ -273,6 +280,8 @@ def main():
                 last = ctx.expired_queue(expired_window[0], expired_window[1], fetch=False)
             return last
         if not gather:
+            if Q > 1:
+                return ctx.scan_batch_pipelined(k, batch_queries)
             if args.depth == 1:
                 for _ in range(k):
                     last = ctx.scan_device(now, cutoff)
@@ -323,6 +332,10 @@ def main():
         ctx.stats_reset()
     ctx.set_profiling(0)
     st = ctx.stats()
+    batch_ms = None
+    if Q > 1 and not gather and args.mode == "scan":
+        batch_ms = list(last)
+        last = batch_ms[0]
     m = last if not gather else int(last["lengths"][rank])
     ms_per_step = statistics.median(region_ms)
     k1_ms = statistics.median(kernel_ms_regions) if kernel_ms_regions else 0.0
@@ -358,6 +371,8 @@ def main():
         variant = st["k1_variant"]
         rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
         kname = kernel_name(variant, rides, args.mode)
+        if batch_ms is not None:
+            kname = "k_scan_batch_with_tail<8, true, %s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local
@@ -366,20 +381,25 @@ def main():
         # byte model from the run's own counters (keyed form): key stream + one 128-B sector per candidate payload record
         # and per ambiguous `end` + one 64-B write per selected row (bucket slot) + K2's outputs
         model = None
-        if args.mode == "scan" and variant & 0x400:
+        if batch_ms is not None:
+            kb = 1 if variant & 0x800 else 2
+            model = n_local * kb + st["candidates"] * 128 + sum(batch_ms) * (64 + 4) + Q * u_local * 12
+        elif args.mode == "scan" and variant & 0x400:
             kb = 1 if variant & 0x800 else 2
             model = n_local * kb + st["candidates"] * 128 + st["key_ambiguous"] * 128 + int(m) * 64 + u_local * 12 + int(m) * 4
         elif args.mode == "scan" and not variant & 4:
             model = n_local * (24 if not variant & 2 else 20) + int(m) * (64 + 4 + (4 if variant & 2 else 0)) + u_local * 12
         basis = traffic if traffic else model
         achieved = (basis / (k1_ms * 1e-3) / 1e9) if basis and k1_ms > 0 else None
-        per_step_units = (tot_users if args.mode == "scan" else tot_rows)
+        per_step_units = (tot_users * (Q if batch_ms is not None else 1) if args.mode == "scan" else tot_rows)
         line = {
             "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X" if args.mode == "scan" else
                       "expired-queue pass (SURVEY 8f-1): sessions scanned/sec; value counts table rows, not feeds",
             "value": per_step_units / (ms_per_step * 1e-3),
             "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
-            "sessions_per_sec": tot_rows / (ms_per_step * 1e-3),
+            "sessions_per_sec": tot_rows * (Q if batch_ms is not None else 1) / (ms_per_step * 1e-3),
+            "queries_per_launch": Q if batch_ms is not None else 1,
+            "table_passes_per_sec": 1.0 / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "timing": {"timed_regions": len(region_ms), "steps_per_region": args.steps, "ms_per_step": spread(region_ms),
                        "ms_per_step_all": region_ms,
@@ -395,7 +415,7 @@ def main():
                              "" if world == 1 else (" sharded by user hash over %d GPUs" % world if strong else " per GPU (weak)"),
                              args.order, args.users_dist, args.variant, args.query),
                 "sessions_total": tot_rows, "users_total": tot_users, "sessions_rank0": n_local, "users_rank0": u_local,
-                "disciplines": D, "selected_rows_rank0": int(m),
+                "disciplines": D, "selected_rows_rank0": int(m), "selected_rows_per_query": batch_ms,
                 "parallelism": "user-hash shards x%d (device-side partition of one corpus), RCCL all-gather of per-user offsets + row "
                                "lists (%d scans per collective), overlapped with the next scans" % (world, args.gather_batch) if world > 1 else "single GPU",
             },

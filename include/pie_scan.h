@@ -58,7 +58,8 @@ typedef struct pie_stats {
     uint32_t n_big;        /* buckets that needed the multi-pass merge in the last scan */
     uint32_t k1_blocks;    /* grid of the scan kernel */
     uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first,
-                              0x400 keyed: streams the 2-byte liveness key instead of the `end` column) */
+                              0x400 keyed: streams the 2-byte liveness key instead of the `end` column, 0x800 the 1-byte key,
+                              0x1000 batched: the last finished call was a batch, `selected` sums its queries) */
     uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
     uint64_t live;         /* rows with end > now seen by the last scan */
     uint64_t candidates;   /* keyed form: rows whose key was >= the query's, i.e. payload records the table pass gathered */
@@ -160,6 +161,34 @@ int pie_scan_begin_packed2(pie_ctx *ctx, int64_t now, int64_t cutoff, void *dst_
  * kernel (or pie_scan_begin_packed*) uses for the same bytes. */
 int pie_host_alloc(pie_ctx *ctx, size_t bytes, void **host_out, void **dev_out);
 int pie_host_free(pie_ctx *ctx, void *host_ptr);
+/* ---- batched scan: many feed requests, one table pass (SURVEY.md section 7 "batch many queries per launch"; the
+ * north_star's "calendarFeed per-request loop -> batched GPU scan").  Every query has its own `now` (the request's clock,
+ * server/sessionStore.js:67 samples one per scan), `cutoff` (server/calendarFeed.js:33-38) and discipline mask
+ * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Results are bit for bit those of
+ * n_q separate pie_scan calls.  Up to two batches may be in flight (begin(i+1) before finish(i)), like two scans; single
+ * scans and batches do not mix in flight.  A query the batched pass cannot finish (a dense query, a bucket of more than
+ * 16 rows) is rerun inside pie_scan_batch_finish on the general path. */
+#define PIE_BATCH_MAX 16
+typedef struct pie_query {
+    int64_t now, cutoff;
+    uint64_t mask;
+} pie_query;
+int pie_scan_batch_begin(pie_ctx *ctx, const pie_query *queries, int n_q);
+/* m_out: n_q selected-row counts (may be NULL) */
+int pie_scan_batch_finish(pie_ctx *ctx, size_t *m_out);
+/* begin + finish */
+int pie_scan_batch(pie_ctx *ctx, const pie_query *queries, int n_q, size_t *m_out);
+/* The same with one result message per query (layout of pie_pack_results_device) written to msg_i32 + q * msg_stride_words
+ * and, optionally, counts[U] to counts_i32 + q * counts_stride_words; both device-visible (device or mapped host memory).
+ * *ready_out = 1: every message was complete when the call returned; 0: order the consumer behind the context's stream. */
+int pie_scan_batch_begin_packed(pie_ctx *ctx, const pie_query *queries, int n_q, void *msg_i32, size_t msg_stride_words,
+                                size_t u_pad, size_t idx_cap, void *counts_i32, size_t counts_stride_words);
+int pie_scan_batch_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
+/* Results of query `qi` of the last finished batch (as pie_read_results / pie_result_device_ptrs). */
+int pie_batch_read_results(pie_ctx *ctx, int qi, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
+                           size_t *m_out);
+int pie_batch_result_device_ptrs(pie_ctx *ctx, int qi, void **counts_dev, void **offsets_dev, void **idx_dev);
+
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                      size_t *m_out);

@@ -31,6 +31,13 @@ class PieTableInfo(C.Structure):
     ]
 
 
+class PieQuery(C.Structure):
+    _fields_ = [("now", C.c_int64), ("cutoff", C.c_int64), ("mask", C.c_uint64)]
+
+
+PIE_BATCH_MAX = 16
+
+
 class PieStats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("n_profiled", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
@@ -73,6 +80,13 @@ _SIGS = [
     ("pie_host_free", C.c_int, [_P, _P]),
     ("pie_set_scan_form", C.c_int, [_P, C.c_int]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
+    ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
+    ("pie_scan_batch_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    ("pie_scan_batch", C.c_int, [_P, C.POINTER(PieQuery), C.c_int, C.POINTER(C.c_size_t)]),
+    ("pie_scan_batch_begin_packed", C.c_int, [_P, C.POINTER(PieQuery), C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),
+    ("pie_scan_batch_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    ("pie_batch_read_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_batch_result_device_ptrs", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_read_user_feed", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
@@ -340,6 +354,74 @@ class PieScan:
                 self.scan_begin(now, cutoff)
             m = self.scan_finish()
         return m
+
+    # ---- batched scan: Q queries (now, cutoff, mask), one table pass
+    @staticmethod
+    def _queries(queries):
+        arr = (PieQuery * len(queries))()
+        for k, (now, cutoff, mask) in enumerate(queries):
+            arr[k].now, arr[k].cutoff, arr[k].mask = int(now), int(cutoff), int(mask) & (2 ** 64 - 1)
+        return arr
+
+    def scan_batch_begin(self, queries):
+        """queries: sequence of (now, cutoff, mask), at most PIE_BATCH_MAX.  Up to two batches may be in flight."""
+        arr = self._queries(queries)
+        self._check(self._lib.pie_scan_batch_begin(self._ctx, arr, len(queries)))
+        self._batches = getattr(self, "_batches", [])
+        self._batches.append(len(queries))
+
+    def scan_batch_begin_packed(self, queries, msg_ptr, msg_stride, u_pad, idx_cap, counts_ptr=None, counts_stride=0):
+        arr = self._queries(queries)
+        self._check(self._lib.pie_scan_batch_begin_packed(self._ctx, arr, len(queries), msg_ptr, int(msg_stride), int(u_pad),
+                                                          int(idx_cap), counts_ptr, int(counts_stride)))
+        self._batches = getattr(self, "_batches", [])
+        self._batches.append(len(queries))
+
+    def scan_batch_finish(self, packed=False):
+        """-> list of M per query of the oldest batch in flight (packed: (list, ready))."""
+        nq = self._batches[0] if getattr(self, "_batches", None) else PIE_BATCH_MAX
+        m = (C.c_size_t * PIE_BATCH_MAX)()
+        ready = C.c_int(0)
+        rc = self._lib.pie_scan_batch_finish_packed(self._ctx, m, C.byref(ready))
+        if getattr(self, "_batches", None) and rc != -6:
+            self._batches.pop(0)
+        self._check(rc)
+        ms = [int(m[k]) for k in range(nq)]
+        return (ms, bool(ready.value)) if packed else ms
+
+    def batch_read_results(self, qi):
+        """Host copies (counts, offsets, idx) of query qi of the last finished batch."""
+        U = self.n_users
+        counts, offsets = np.empty(U, np.int32), np.empty(U + 1, np.int64)
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_batch_read_results(self._ctx, int(qi), _ptr(counts), _ptr(offsets), None, 0, C.byref(m)))
+        idx = np.empty(max(m.value, 1), np.int32)
+        if m.value:
+            self._check(self._lib.pie_batch_read_results(self._ctx, int(qi), None, None, _ptr(idx), m.value, C.byref(m)))
+        return counts, offsets, idx[: m.value]
+
+    def scan_batch(self, queries):
+        """-> [(counts, offsets, idx)] per query; bit for bit what scan() gives for each (now, cutoff) under its mask."""
+        self.scan_batch_begin(queries)
+        self.scan_batch_finish()
+        return [self.batch_read_results(k) for k in range(len(queries))]
+
+    def batch_result_device_ptrs(self, qi):
+        a, b, c = _P(), _P(), _P()
+        self._check(self._lib.pie_batch_result_device_ptrs(self._ctx, int(qi), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def scan_batch_pipelined(self, k, queries):
+        """k batches of the same queries with two in flight.  -> list of M of the last batch."""
+        ms = []
+        if k <= 0:
+            return ms
+        self.scan_batch_begin(queries)
+        for i in range(k):
+            if i + 1 < k:
+                self.scan_batch_begin(queries)
+            ms = self.scan_batch_finish()
+        return ms
 
     def result_device_ptrs(self):
         a, b, c = _P(), _P(), _P()

@@ -1405,7 +1405,10 @@ __device__ __forceinline__ unsigned wave_list_slot(unsigned int* counter, unsign
     return base + before;
 }
 
-template <int UPT, bool ORDER, int BLOCK>
+//   LISTS  false: the batched scan (pie_scan_batch_begin): its table pass keeps no staged route, so a bucket of more than
+//          kTinyMax rows cannot be completed here; it is only counted (Summary::n_over) and the host reruns that query on
+//          the general path.  out_cap bounds the row list such a query may still write (its result is discarded).
+template <int UPT, bool ORDER, int BLOCK, bool LISTS = true>
 __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
@@ -1416,7 +1419,8 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
                                                  DirectSlots direct, BktRec* __restrict__ bkt,
                                                  int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap,
                                                  int* __restrict__ msg_counts, const HotSet& hot,
-                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk)
+                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk,
+                                                 long long out_cap = INT64_MAX)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     (void)bkt; // the direct part of outgrown buckets is moved by k_copy_direct, not here
@@ -1528,7 +1532,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
             const int n = c[k];
             if constexpr (ORDER) {
                 if (msg) msg_store(msg + u, (int)run);
-                if (n >= 1 && n <= 8 && !is_hot[k]) {
+                if (n >= 1 && n <= 8 && !is_hot[k] && (LISTS || run + n <= out_cap)) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if (i < n) {
@@ -1540,7 +1544,9 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
             // buckets K2 does not order itself: more than kTinyMax rows (without ORDER: every bucket that is not read from
             // the direct slots by k_sort_tiny), and every bucket of a hot user
             const bool listed = n > kTinyMax || (is_hot[k] && n > 0);
-            if (listed) {
+            if (!LISTS) {
+                if (listed) (void)wave_list_slot(&summary->n_over); // counted only: the host reruns this query
+            } else if (listed) {
                 // whole bucket still in its direct slots?  then the wave that orders it reads it from there (flags bit 1,
                 // the user id above it) and nothing of it was staged; otherwise its direct part joins the staged rest in bkt
                 const int dcap = 1 << direct.shift;
@@ -1589,7 +1595,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
         // buckets of 9..16 rows, one at a time with the whole wave: lane i < n holds record i and counts the records that
         // sort before it; that count is its place.  (`run` was advanced past this thread's bucket above: UPT == 1.)
         const int n_mine = c[0];
-        const bool mid = u0 < n_users && n_mine > 8 && n_mine <= kTinyMax && !is_hot[0];
+        const bool mid = u0 < n_users && n_mine > 8 && n_mine <= kTinyMax && !is_hot[0] && (LISTS || run <= out_cap);
         unsigned long long todo = __ballot(mid);
         if (__popcll(todo) > 6) {
             // many such buckets in this wave (users of similar weight sit together): one pass of the 16-slot network
@@ -1758,6 +1764,260 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
                                                       a.n_users, a.counts, a.sel, a.sel_rank, a.blk_count, a.summary, a.direct, a.hot,
                                                       a.blk_hot_base, (int)blockIdx.x - t.n_tail);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ batched scan: Q queries, one table pass
+//
+// SURVEY.md section 7 ("batch many queries per launch") / the north_star's "batched GPU scan": a server answers many
+// feed requests, each with its own `now` (millisecond clock), `cutoff` and discipline mask.  The table pass is the same
+// for all of them up to the last compare, so ONE launch streams the key column once, finds the rows that are candidates
+// for ANY of the Q queries (key >= the smallest key(now)), gathers each candidate's payload record once, and then
+// evaluates the Q predicates on it: per query one histogram atomic (its return value is the row's rank in the bucket)
+// and one direct-slot store.  The fixed costs of a scan — the launch, the offsets kernel's ticket / look-back chain, the
+// host's summary round trip — are paid once per batch instead of once per query, and the atomics of different queries
+// are independent, so their round trips overlap.  Per-query state (histogram span, direct slots, counts, offsets, row
+// list) lives in arrays with a fixed stride per query.  There is no staged route here: a query that finds a bucket of more
+// than kTinyMax rows is reported (Summary::n_over) and the host reruns it on the general path, bit for bit the same result.
+constexpr int kBatchMax = 16;
+
+struct BatchQueryScalars {
+    long long now, cutoff;
+    unsigned long long mask;
+    unsigned now_key;
+    unsigned pad;
+};
+
+template <class KT>
+struct BatchScanArgs {
+    const PayRec* pay;
+    const long long* end;
+    const KT* key;
+    long long n, rows_per_block;
+    int n_users;
+    int n_q;
+    unsigned min_key;          // smallest now_key of the batch: a row below it is dead for every query
+    char* span;                // query q's histogram span starts at span + q * span_stride (counts first)
+    long long span_stride;     // bytes
+    long long summary_off;     // byte offset of the Summary inside a span
+    BktRec* direct;            // query q's direct slots: direct + q * direct_stride (kTinyMax slots per user)
+    long long direct_stride;   // records
+    BatchQueryScalars q[kBatchMax];
+};
+
+template <int UNROLL, bool NT, class KT>
+__device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int bid)
+{
+    __shared__ int ring_row[kK1Waves][kLiveRing];
+    __shared__ int ring_key[kK1Waves][kLiveRing];
+    __shared__ int blk_cand;
+    constexpr int kPerLane = 16 / (int)sizeof(KT);
+    constexpr int kRowsPerLoad = kPerLane * kWave;
+    constexpr int kTile = kRowsPerLoad * UNROLL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) blk_cand = 0;
+    __syncthreads();
+    const long long c0 = (long long)bid * a.rows_per_block;
+    long long c1 = c0 + a.rows_per_block;
+    if (c1 > a.n) c1 = a.n;
+    int* rrow = ring_row[wave];
+    int* rkey = ring_key[wave];
+    int lhead = 0, lfill = 0, ncand = 0; // wave-uniform
+    const int nq = a.n_q;
+
+    // evaluate `cnt` queued candidates (cnt <= 64), one per lane, against every query of the batch
+    auto drain = [&](int cnt) {
+        const bool valid = lane < cnt;
+        int row = 0;
+        unsigned key = 0;
+        PayRec pr;
+        pr.start = 0; pr.user = 0; pr.disc = -1;
+        if (valid) {
+            const int slot = (lhead + lane) & (kLiveRing - 1);
+            row = rrow[slot];
+            key = (unsigned)rkey[slot];
+            pr = a.pay[row]; // ONE gather per candidate, shared by all queries
+        }
+        bool amb_any = false;
+        for (int q = 0; q < nq; ++q) amb_any |= key == a.q[q].now_key;
+        long long ev = 0;
+        if (valid && amb_any) ev = a.end[row]; // the 8-byte `end` only where some query's key cannot decide
+        const bool user_ok = (unsigned)pr.user < (unsigned)a.n_users;
+        const bool disc_ok = (unsigned)pr.disc < 64u;
+        const int hidx = hist_index(user_ok ? pr.user : 0, a.n_users);
+        BktRec rec;
+        rec.start = pr.start;
+        rec.idx = row;
+        rec.pad = 0;
+        // four queries at a time: their histogram atomics are independent, so the round trips overlap
+        for (int q0 = 0; q0 < nq; q0 += 4) {
+            int rank[4];
+            bool p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = q0 + j;
+                p[j] = false;
+                rank[j] = 0;
+                if (q < nq) { // wave-uniform
+                    const BatchQueryScalars& Q = a.q[q];
+                    const bool live = key > Q.now_key || (key == Q.now_key && ev > Q.now);
+                    p[j] = valid & live & (pr.start >= Q.cutoff) & disc_ok & (((Q.mask >> (pr.disc & 63)) & 1ull) != 0);
+                    int* counts = reinterpret_cast<int*>(a.span + (long long)q * a.span_stride);
+                    if (p[j] && !user_ok) {
+                        atomicAdd(&reinterpret_cast<Summary*>(a.span + (long long)q * a.span_stride + a.summary_off)->bad_rows, 1u);
+                        p[j] = false;
+                    }
+                    if (p[j]) rank[j] = atomicAdd(&counts[hidx], 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = q0 + j;
+                if (q < nq && p[j] && (unsigned)rank[j] < (unsigned)kTinyMax)
+                    a.direct[(long long)q * a.direct_stride + ((long long)pr.user << 4) + rank[j]] = rec;
+            }
+        }
+        ncand += cnt;
+        lhead = (lhead + cnt) & (kLiveRing - 1);
+        lfill -= cnt;
+    };
+    auto push = [&](bool cand, int row, unsigned key) {
+        const unsigned long long b = __ballot(cand);
+        if (b == 0) return false;
+        if (cand) {
+            const int slot = (lhead + lfill + prefix_in_ballot(b)) & (kLiveRing - 1);
+            rrow[slot] = row;
+            rkey[slot] = (int)key;
+        }
+        lfill += __popcll(b);
+        __builtin_amdgcn_wave_barrier();
+        if (lfill >= kWave) drain(kWave);
+        __builtin_amdgcn_wave_barrier();
+        return true;
+    };
+
+    // SWAR candidate test against the batch's smallest key(now) (see scan_keyed_body)
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
+    const unsigned mk = a.min_key;
+    const unsigned nkr = sizeof(KT) == 2 ? (mk | (mk << 16)) : mk * 0x01010101u;
+    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
+        if (t + kTile <= c1) {
+            u4_t kv[UNROLL];
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(a.key + t + j * kRowsPerLoad + kPerLane * lane));
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) {
+                const int r0 = (int)(t + j * kRowsPerLoad + kPerLane * lane);
+                const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
+                const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
+                if constexpr (sizeof(KT) == 2) {
+                    unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
+                                           (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
+                    for (;;) {
+                        const bool has = m != 0;
+                        const int pbit = __ffsll((long long)m) - 1;
+                        const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);
+                        const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
+                        const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
+                        if (!push(has, r0 + q, kq)) break;
+                        m &= m - 1;
+                    }
+                } else {
+                    unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
+                    for (;;) {
+                        const bool has = m != 0;
+                        const int pbit = __ffs((int)m) - 1;
+                        const int w = pbit & 7, b = pbit >> 3;
+                        const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
+                        const unsigned kq = (word >> (8 * b)) & 0xFFu;
+                        if (!push(has, r0 + 4 * w + b, kq)) break;
+                        m &= m - 1;
+                    }
+                }
+            }
+        } else {
+            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
+            for (long long r0 = t; r0 < t1; r0 += kWave) {
+                const long long r = r0 + lane;
+                const unsigned kq = r < t1 ? a.key[r] : 0u;
+                push(r < t1 && kq >= mk, (int)r, kq);
+            }
+        }
+    }
+    if (lfill > 0) drain(lfill);
+    if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
+    __syncthreads();
+    // candidates are a property of the batch: reported on query 0's statistics slots
+    if (threadIdx.x == 0) add_row_stats(reinterpret_cast<Summary*>(a.span + a.summary_off), 0, 0, bid, blk_cand);
+}
+
+// K2 of a batch: blocks [q * tiles, (q + 1) * tiles) run the fused offsets + order kernel of query q (256 users per block)
+struct BatchTailArgs {
+    int n_q;
+    int n_users;
+    int tiles;                 // blocks per query
+    char* span;                // the spans of the batch this tail belongs to
+    long long span_stride, tiles_off, ctl_off, summary_off; // byte offsets inside a span
+    char* zero_span;           // the span SET the batch after the next will use: zeroed here, all kBatchMax spans of it
+    long long zero_vec16;      // 16-byte vectors per tile group (group q zeroes vectors [q * zero_vec16, (q + 1) * zero_vec16))
+    long long zero_total16;    // ... clamped to the set's total
+    int* counts_ord;           // + q * users_stride
+    long long* offsets;        // + q * (users_stride)
+    long long users_stride;    // elements (>= n_users + 1)
+    BktRec* direct;
+    long long direct_stride;
+    int* out_idx;              // + q * out_stride
+    long long out_stride;      // = capacity of a query's row list
+    HostSummary* host;         // [n_q], mapped host memory
+    unsigned long long seq;
+    int* msg;                  // optional per-query result messages: msg + q * msg_stride
+    long long msg_stride;
+    int u_pad;
+    long long msg_cap;
+    int* msg_counts;           // optional per-query counts copies: msg_counts + q * msg_counts_stride
+    long long msg_counts_stride;
+};
+
+__device__ __forceinline__ void batch_tail_body(const BatchTailArgs& t, int bid)
+{
+    const int q = bid / t.tiles, tile_bid = bid - q * t.tiles;
+    char* sp = t.span + (long long)q * t.span_stride;
+    HotSet none;
+    none.n = 0;
+    DirectSlots d;
+    d.p = t.direct + (long long)q * t.direct_stride;
+    d.shift = 4;
+    const long long z0 = (long long)q * t.zero_vec16;
+    long long zcount = t.zero_total16 - z0;
+    zcount = zcount < 0 ? 0 : (zcount > t.zero_vec16 ? t.zero_vec16 : zcount);
+    int4* zspan = (t.zero_span && zcount > 0) ? reinterpret_cast<int4*>(t.zero_span) + z0 : nullptr;
+    offsets_body<1, true, kK1Threads, false>(
+        reinterpret_cast<const int*>(sp), t.counts_ord + (long long)q * t.users_stride, t.n_users,
+        reinterpret_cast<unsigned long long*>(sp + t.tiles_off), reinterpret_cast<ScanCtl*>(sp + t.ctl_off),
+        t.offsets + (long long)q * t.users_stride, nullptr, nullptr, nullptr, reinterpret_cast<Summary*>(sp + t.summary_off),
+        t.host + q, t.seq, zspan, zcount, d,
+        nullptr, t.out_idx + (long long)q * t.out_stride, t.msg ? t.msg + (long long)q * t.msg_stride : nullptr, t.u_pad, t.msg_cap,
+        t.msg_counts ? t.msg_counts + (long long)q * t.msg_counts_stride : nullptr, none, 0, nullptr, nullptr, tile_bid, t.tiles,
+        t.out_stride);
+}
+
+__global__ __launch_bounds__(kK1Threads) void k_offsets_batch(BatchTailArgs t) { batch_tail_body(t, (int)blockIdx.x); }
+
+template <int UNROLL, bool NT, class KT>
+__global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
+{
+    scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x);
+}
+
+// table pass of batch i+1 with the offsets kernels of batch i in its first blocks (see k_scan_keyed_with_tail)
+template <int UNROLL, bool NT, class KT>
+__global__ __launch_bounds__(kK1Threads) void k_scan_batch_with_tail(BatchScanArgs<KT> a, BatchTailArgs t)
+{
+    const int n_tail = t.n_q * t.tiles;
+    if ((int)blockIdx.x < n_tail) batch_tail_body(t, (int)blockIdx.x);
+    else scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x - n_tail);
 }
 
 // ------------------------------------------------------------------------------------------------ K3 scatter

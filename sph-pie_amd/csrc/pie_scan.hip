@@ -95,6 +95,36 @@ struct Slot {
     int ev_index = -1; // index into the event ring, -1 = not profiled
 };
 
+// everything one batch of queries owns (see pie_kernels.h "batched scan"); per-query arrays have a fixed stride
+struct BatchSlot {
+    int n_q = 0;
+    bool in_flight = false, k2_pending = false, have_result = false;
+    bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
+    bool fine_key = false;
+    unsigned long long seq = 0;
+    char* span = nullptr;              // this batch's span set
+    char* zero_span = nullptr;         // the set its K2 zeroes
+    int* counts_ord = nullptr;         // [kBatchMax][users_stride]
+    long long* offsets = nullptr;      // [kBatchMax][users_stride]
+    BktRec* direct = nullptr;          // [kBatchMax][cap_users << 4]
+    int* out_idx = nullptr;            // [kBatchMax][out_stride]
+    HostSummary* h_sum = nullptr;      // [kBatchMax] mapped pinned
+    HostSummary* h_sum_dev = nullptr;
+    pie_query q[kBatchMax];
+    bool fallback[kBatchMax];          // rerun on the general path (dense query, outgrown bucket, bad rows)
+    Summary last[kBatchMax];
+    int* over_idx[kBatchMax] = {};     // row list of a fallback query that outgrew out_stride
+    long long over_cap[kBatchMax] = {};
+    int* idx_of[kBatchMax] = {};       // where query q's row list lives after finish
+    int* msg = nullptr;                // optional per-query messages (caller-owned device-visible memory)
+    long long msg_stride = 0, msg_cap = 0;
+    int msg_u_pad = 0;
+    int* msg_counts = nullptr;
+    long long msg_counts_stride = 0;
+    int k1_blocks = 0;
+    int ev_index = -1;
+};
+
 } // namespace
 
 struct pie_ctx {
@@ -161,6 +191,15 @@ struct pie_ctx {
     bool fast_env = false;     // path (0.179 vs 0.177 ms/step), so the simpler path stays the default; an overflow turns it off for the table
 
     Slot slot[2];
+    BatchSlot bslot[2];         // batched scans (pie_scan_batch_begin): two batches may be in flight, like two scans
+    char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating span SETS: kBatchMax spans each, query q at q * counts_span()
+    int bspan_next = 0;
+    int b_next = 0;             // batch slot the next begin uses
+    int b_flight = 0;           // batches begun and not finished (0..2)
+    BatchSlot* bres = nullptr;  // last finished batch
+    bool batch_alloc = false;
+    bool last_was_batch = false; // pie_stats_get describes the last finished batch rather than the last single scan
+    unsigned long long bseq_counter = 0;
     char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
     int span_next = 0;
     int profile_every = 1;   // with profiling on, every n-th scan carries timing events
@@ -237,8 +276,25 @@ void free_slots(pie_ctx* c)
     c->next_slot = 0;
 }
 
+void free_batch(pie_ctx* c)
+{
+    for (BatchSlot& b : c->bslot) {
+        dfree(b.counts_ord); dfree(b.offsets); dfree(b.direct); dfree(b.out_idx);
+        for (int q = 0; q < kBatchMax; ++q) { dfree(b.over_idx[q]); b.over_cap[q] = 0; b.idx_of[q] = nullptr; }
+        b.in_flight = b.k2_pending = b.have_result = false;
+        b.n_q = 0;
+    }
+    for (char*& sp : c->bspan) dfree(sp);
+    c->bspan_next = 0;
+    c->b_next = 0;
+    c->b_flight = 0;
+    c->bres = nullptr;
+    c->batch_alloc = false;
+}
+
 void free_table(pie_ctx* c)
 {
+    free_batch(c);
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
     c->key_ok = false;
     dfree(c->d_blk_off);
@@ -304,7 +360,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
 {
     if (n < 0 || n >= (1LL << 31) - 1) return fail(c, PIE_E_INVAL, "row count %lld outside [0, 2^31 - 1)", n);
     if (n_users < 1) return fail(c, PIE_E_INVAL, "n_users must be >= 1 (got %d)", n_users);
-    if (c->n_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     int rc = sync_all(c);
     if (rc) return rc;
     long long rows = n > 0 ? n : 1;
@@ -1064,6 +1120,7 @@ int scan_finish(pie_ctx* c)
     if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, a));
     sl.have_result = true;
     c->res = &sl;
+    c->last_was_batch = false;
     if (sl.last.bad_rows)
         return fail(c, PIE_E_INVAL, "%u selected rows carry a user id outside [0, %d)", sl.last.bad_rows, c->n_users);
     return PIE_OK;
@@ -1085,7 +1142,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     if (k_out) *k_out = 0;
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n == 0) return PIE_OK;
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = sync_all(c); // the workspace below is shared with the scans' tails
     if (rc) return rc;
@@ -1111,6 +1168,312 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
         PIE_HIP(c, hipMemcpyAsync(out, sl.out_idx, k * 4, hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
     }
+    return PIE_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- batched scans
+// Q queries in one table pass (pie_kernels.h "batched scan").  Buffers are allocated on first use for kBatchMax queries:
+// per batch slot counts / offsets / 16 direct slots per user / a row list of 16 rows per user, per query.
+
+long long batch_users_stride(const pie_ctx* c) { return (((long long)c->cap_users + 1 + 31) / 32) * 32; }
+long long batch_out_stride(const pie_ctx* c) { return (long long)c->cap_users * kTinyMax; }
+
+bool batch_supported(const pie_ctx* c)
+{
+    const int tiles = (c->n_users + kK1Threads - 1) / kK1Threads;
+    return c->key_ok && c->d_key && c->d_fkey && c->d_pay && c->slot[0].direct != nullptr && tiles <= kOrderMaxTiles && c->n > 0 &&
+           (long long)c->cap_users * kTinyMax < (1LL << 31);
+}
+
+// full = false: only the per-query counts / offsets arrays (tables the batched pass cannot run on: every query goes
+// through the general path and its row list lives in a buffer of its own)
+int ensure_batch(pie_ctx* c, bool full)
+{
+    const size_t us = (size_t)batch_users_stride(c), os = (size_t)batch_out_stride(c);
+    if (!c->bslot[0].counts_ord) {
+        for (BatchSlot& b : c->bslot) {
+            PIE_HIP(c, hipMalloc(&b.counts_ord, (size_t)kBatchMax * us * 4));
+            PIE_HIP(c, hipMalloc(&b.offsets, (size_t)kBatchMax * us * 8));
+        }
+    }
+    if (!full || c->batch_alloc) return PIE_OK;
+    for (BatchSlot& b : c->bslot) {
+        PIE_HIP(c, hipMalloc(&b.direct, (size_t)kBatchMax * ((size_t)c->cap_users << 4) * sizeof(BktRec)));
+        PIE_HIP(c, hipMalloc(&b.out_idx, (size_t)kBatchMax * (os > 0 ? os : 1) * 4));
+    }
+    for (char*& sp : c->bspan) {
+        PIE_HIP(c, hipMalloc(&sp, (size_t)kBatchMax * counts_span(c)));
+        PIE_HIP(c, hipMemsetAsync(sp, 0, (size_t)kBatchMax * counts_span(c), c->stream));
+    }
+    c->bspan_next = 0;
+    c->batch_alloc = true;
+    return PIE_OK;
+}
+
+BatchSlot* oldest_batch(pie_ctx* c)
+{
+    if (c->b_flight == 0) return nullptr;
+    return &c->bslot[c->b_flight == 2 ? c->b_next : (c->b_next ^ 1)];
+}
+
+void fill_tail_args(pie_ctx* c, BatchSlot& b, BatchTailArgs& t)
+{
+    t.n_q = b.n_q;
+    t.n_users = c->n_users;
+    t.tiles = (c->n_users + kK1Threads - 1) / kK1Threads;
+    t.span = b.span;
+    t.span_stride = (long long)counts_span(c);
+    t.tiles_off = (long long)span_counts_bytes(c);
+    t.ctl_off = (long long)(span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes());
+    t.summary_off = t.ctl_off + 128;
+    // the whole next-but-one span set (all kBatchMax spans, whatever the batch sizes) is zeroed by this batch's n_q tile
+    // groups: group q takes the q-th share, cut at span boundaries' 16-byte vectors
+    t.zero_span = b.zero_span;
+    const long long total16 = (long long)kBatchMax * (long long)(counts_span(c) / 16);
+    t.zero_vec16 = (total16 + b.n_q - 1) / b.n_q; // per group; the kernel clamps the last group (see zero_total16)
+    t.counts_ord = b.counts_ord;
+    t.offsets = b.offsets;
+    t.users_stride = batch_users_stride(c);
+    t.direct = b.direct;
+    t.direct_stride = (long long)c->cap_users << 4;
+    t.out_idx = b.out_idx;
+    t.out_stride = batch_out_stride(c);
+    t.host = b.h_sum_dev;
+    t.seq = b.seq;
+    t.msg = b.msg;
+    t.msg_stride = b.msg_stride;
+    t.u_pad = b.msg_u_pad;
+    t.msg_cap = b.msg_cap;
+    t.msg_counts = b.msg_counts;
+    t.msg_counts_stride = b.msg_counts_stride;
+    t.zero_total16 = total16;
+}
+
+void launch_batch_k2(pie_ctx* c, BatchSlot& b, hipStream_t s)
+{
+    BatchTailArgs t;
+    fill_tail_args(c, b, t);
+    hipLaunchKernelGGL(k_offsets_batch, dim3((unsigned)(t.n_q * t.tiles)), dim3(kK1Threads), 0, s, t);
+    b.k2_pending = false;
+}
+
+int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long msg_stride, int u_pad, long long msg_cap,
+                int* msg_counts, long long msg_counts_stride)
+{
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (!qs || n_q < 1 || n_q > kBatchMax) return fail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", kBatchMax, n_q);
+    if (c->n_flight) return fail(c, PIE_E_STATE, "a single scan is in flight: finish it before beginning a batch");
+    if (c->b_flight >= 2) return fail(c, PIE_E_STATE, "two batches are already in flight: call pie_scan_batch_finish first");
+    if (c->key_rebuild && c->b_flight == 0) {
+        int rc = build_keys(c, 0, true);
+        if (rc) return rc;
+    }
+    BatchSlot& b = c->bslot[c->b_next];
+    hipStream_t s = c->stream;
+    b.n_q = n_q;
+    b.have_result = false;
+    if (c->bres == &b) c->bres = nullptr;
+    b.msg = msg; b.msg_stride = msg_stride; b.msg_u_pad = u_pad; b.msg_cap = msg_cap;
+    b.msg_counts = msg_counts; b.msg_counts_stride = msg_counts_stride;
+    for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; }
+    b.ev_index = -1;
+    b.unsupported = !batch_supported(c) || c->key_poor;
+    if (b.unsupported) { // finish() runs every query on the general path
+        for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
+        b.in_flight = true;
+        b.k2_pending = false;
+        c->b_flight++;
+        c->b_next ^= 1;
+        return PIE_OK;
+    }
+    int rc = ensure_batch(c, true);
+    if (rc) return rc;
+    // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
+    // they would make every row a candidate for all queries; they run on the general path
+    int n_batched = 0;
+    bool fine = (c->k1_keyed & 0x800) && !c->fkey_poor;
+    for (int q = 0; q < n_q; ++q) {
+        bool dense = false;
+        if (!c->key_dirty && c->key_hist_rows == c->n) {
+            const int bin = (int)(host_key_of(c, qs[q].now) >> 3);
+            unsigned long long at_or_above = 0;
+            for (int k = bin; k < kKeyHistBins; ++k) at_or_above += c->key_hist[(size_t)k];
+            dense = (double)at_or_above >= kLiveFirstBelow * (double)c->n;
+        }
+        b.fallback[q] = dense;
+        if (!dense) {
+            ++n_batched;
+            if (qs[q].now < c->fkey_base) fine = false;
+        }
+    }
+    b.fine_key = fine;
+    // spans: this batch's set and the one its K2 zeroes
+    b.span = c->bspan[c->bspan_next];
+    c->bspan_next = (c->bspan_next + 1) % 3;
+    b.zero_span = c->bspan[(c->bspan_next + 1) % 3];
+    b.seq = ++c->bseq_counter;
+    const int plan = fine ? 3 : 2;
+    b.k1_blocks = c->plan_blocks[plan];
+    if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
+        if (c->ring_used == kEventRing) {
+            rc = resolve_events(c);
+            if (rc) return rc;
+        }
+        if (c->ring_used < kEventRing) {
+            if ((int)c->ring.size() <= c->ring_used) {
+                ScanEvents e{};
+                PIE_HIP(c, hipEventCreate(&e.e0));
+                PIE_HIP(c, hipEventCreate(&e.e1));
+                PIE_HIP(c, hipEventCreate(&e.e2));
+                c->ring.push_back(e);
+            }
+            b.ev_index = c->ring_used++;
+        }
+    }
+    c->scans_begun++;
+    BatchSlot& other = c->bslot[c->b_next ^ 1];
+    const bool ride = c->b_flight == 1 && other.in_flight && other.k2_pending && !c->no_ride;
+    if (c->b_flight == 1 && other.in_flight && other.k2_pending && !ride) launch_batch_k2(c, other, s);
+    if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
+#define PIE_BATCH(KT, KEYPTR, KEYFN, IMPOSSIBLE)                                                                         \
+    do {                                                                                                                \
+        BatchScanArgs<KT> a;                                                                                            \
+        a.pay = c->d_pay; a.end = c->d_end; a.key = KEYPTR; a.n = c->n; a.rows_per_block = c->plan_rows[plan];          \
+        a.n_users = c->n_users; a.n_q = n_q; a.span = b.span; a.span_stride = (long long)counts_span(c);                \
+        a.summary_off = (long long)(span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128);             \
+        a.direct = b.direct; a.direct_stride = (long long)c->cap_users << 4;                                            \
+        unsigned mk = IMPOSSIBLE;                                                                                       \
+        for (int q = 0; q < n_q; ++q) {                                                                                 \
+            a.q[q].now = qs[q].now; a.q[q].cutoff = qs[q].cutoff; a.q[q].pad = 0;                                       \
+            a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));                   \
+            a.q[q].now_key = b.fallback[q] ? (unsigned)(IMPOSSIBLE) : KEYFN(c, qs[q].now);                              \
+            if (a.q[q].now_key < mk) mk = a.q[q].now_key;                                                               \
+        }                                                                                                               \
+        a.min_key = mk;                                                                                                 \
+        if (ride) {                                                                                                     \
+            BatchTailArgs t;                                                                                            \
+            fill_tail_args(c, other, t);                                                                                \
+            hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT>), dim3((unsigned)(b.k1_blocks + t.n_q * t.tiles)),  \
+                               dim3(kK1Threads), 0, s, a, t);                                                           \
+            other.k2_pending = false;                                                                                   \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL((k_scan_batch<8, true, KT>), dim3((unsigned)b.k1_blocks), dim3(kK1Threads), 0, s, a);    \
+        }                                                                                                               \
+    } while (0)
+    // a query that falls back carries a key no row can reach: it selects nothing here
+    if (fine) PIE_BATCH(fkey_t, c->d_fkey, host_fine_key_of, 0xFFu);
+    else PIE_BATCH(lkey_t, c->d_key, host_key_of, 0xFFFFu);
+#undef PIE_BATCH
+    PIE_HIP(c, hipGetLastError());
+    if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e1, s));
+    (void)n_batched;
+    b.k2_pending = true;
+    b.in_flight = true;
+    c->b_flight++;
+    c->b_next ^= 1;
+    return PIE_OK;
+}
+
+// one query of a batch on the general path; its results are copied into the batch's arrays
+int batch_fallback(pie_ctx* c, BatchSlot& b, int q)
+{
+    const unsigned long long keep_mask = c->disc_mask;
+    c->disc_mask = b.q[q].mask;
+    int rc = run_scan(c, b.q[q].now, b.q[q].cutoff);
+    c->disc_mask = keep_mask;
+    if (rc) return rc;
+    Slot& sl = *c->res;
+    hipStream_t s = c->stream;
+    const long long us = batch_users_stride(c);
+    rc = ensure_batch(c, false);
+    if (rc) return rc;
+    PIE_HIP(c, hipMemcpyAsync(b.counts_ord + (long long)q * us, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, s));
+    PIE_HIP(c, hipMemcpyAsync(b.offsets + (long long)q * us, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, s));
+    const long long m = (long long)sl.last.m;
+    int* dst = b.out_idx ? b.out_idx + (long long)q * batch_out_stride(c) : nullptr;
+    if (!dst || m > batch_out_stride(c)) {
+        if (b.over_cap[q] < m || !b.over_idx[q]) {
+            dfree(b.over_idx[q]);
+            b.over_cap[q] = 0;
+            PIE_HIP(c, hipMalloc(&b.over_idx[q], (size_t)(m > 0 ? m : 1) * 4));
+            b.over_cap[q] = m > 0 ? m : 1;
+        }
+        dst = b.over_idx[q];
+    }
+    if (m) PIE_HIP(c, hipMemcpyAsync(dst, sl.out_idx, (size_t)m * 4, hipMemcpyDeviceToDevice, s));
+    b.idx_of[q] = dst;
+    if (b.msg) {
+        rc = pie_pack_results_device(c, b.msg + (long long)q * b.msg_stride, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
+        if (rc) return rc;
+    }
+    if (b.msg_counts)
+        PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDefault, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    b.last[q] = sl.last;
+    sl.have_result = false; // an implementation detail of the batch, not a feed result of its own
+    c->res = nullptr;
+    return PIE_OK;
+}
+
+int batch_finish(pie_ctx* c, int* ready_out)
+{
+    if (ready_out) *ready_out = 0;
+    BatchSlot* bp = oldest_batch(c);
+    if (!bp) return fail(c, PIE_E_STATE, "pie_scan_batch_finish without pie_scan_batch_begin");
+    BatchSlot& b = *bp;
+    hipStream_t s = c->stream;
+    bool all_ready = true;
+    if (!b.unsupported) {
+        if (b.k2_pending) {
+            launch_batch_k2(c, b, s);
+            PIE_HIP(c, hipGetLastError());
+        }
+        // wait for every query's summary (mapped host memory, seq last); bounded like the single-scan wait
+        timespec t0{};
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int q = 0; q < b.n_q; ++q) {
+            volatile unsigned long long* seq = &b.h_sum[q].seq;
+            unsigned long long spins = 0;
+            while (*seq != b.seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0x3FFFF) == 0) {
+                    hipError_t e = hipStreamQuery(s);
+                    timespec t1{};
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    const double waited_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+                    const bool bad = e != hipSuccess && e != hipErrorNotReady;
+                    if (bad || waited_ms > c->wait_deadline_ms || (e == hipSuccess && *seq != b.seq && waited_ms > 1000.0)) {
+                        b.in_flight = false;
+                        c->b_flight--;
+                        if (bad) return fail(c, PIE_E_HIP, "batched scan failed: %s", hipGetErrorString(e));
+                        return fail(c, PIE_E_HIP, "batch summary %d not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", q, waited_ms);
+                    }
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int q = 0; q < b.n_q; ++q) {
+            b.last[q] = b.h_sum[q].s;
+            if (b.last[q].n_over > 0 || b.last[q].bad_rows > 0) b.fallback[q] = true;
+            b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
+        }
+        if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
+    }
+    b.in_flight = false;
+    c->b_flight--;
+    for (int q = 0; q < b.n_q; ++q) {
+        if (!b.fallback[q]) continue;
+        all_ready = false;
+        int rc = batch_fallback(c, b, q);
+        if (rc) return rc;
+    }
+    b.have_result = true;
+    c->bres = &b;
+    c->last_was_batch = true;
+    if (ready_out) *ready_out = (all_ready && b.msg) ? 1 : (b.msg ? 0 : 1);
+    for (int q = 0; q < b.n_q; ++q)
+        if (b.last[q].bad_rows) return fail(c, PIE_E_INVAL, "query %d: %u selected rows carry a user id outside [0, %d)", q, b.last[q].bad_rows, c->n_users);
     return PIE_OK;
 }
 
@@ -1160,6 +1523,11 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
              (e = hipHostGetDevicePointer((void**)&s.h_sum_dev, s.h_sum, 0)) == hipSuccess;
         if (ok) memset(s.h_sum, 0, sizeof(HostSummary));
     }
+    for (BatchSlot& b : c->bslot) {
+        ok = ok && (e = hipHostMalloc(&b.h_sum, sizeof(HostSummary) * kBatchMax, hipHostMallocMapped)) == hipSuccess &&
+             (e = hipHostGetDevicePointer((void**)&b.h_sum_dev, b.h_sum, 0)) == hipSuccess;
+        if (ok) memset(b.h_sum, 0, sizeof(HostSummary) * kBatchMax);
+    }
     if (!ok) {
         fail(nullptr, PIE_E_NODEVICE, "context setup: %s", hipGetErrorString(e));
         delete c; // the few handles created so far go with the process: it has no usable GPU anyway
@@ -1194,6 +1562,9 @@ int pie_ctx_destroy(pie_ctx* c)
     for (Slot& s : c->slot) {
         if (s.h_sum) (void)hipHostFree(s.h_sum);
     }
+    for (BatchSlot& b : c->bslot) {
+        if (b.h_sum) (void)hipHostFree(b.h_sum);
+    }
     if (c->d_summary) (void)hipFree(c->d_summary);
     if (c->d_range) (void)hipFree(c->d_range);
     if (c->d_hist) (void)hipFree(c->d_hist);
@@ -1206,7 +1577,7 @@ int pie_ctx_destroy(pie_ctx* c)
 int pie_ctx_set_stream(pie_ctx* c, void* hip_stream)
 {
     if (!c) return PIE_E_INVAL;
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     int rc = sync_all(c);
     if (rc) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1332,7 +1703,7 @@ int pie_save_columns(pie_ctx* c, const char* dir)
 {
     if (!c || !dir) return PIE_E_INVAL;
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     PIE_HIP(c, hipSetDevice(c->device));
     (void)mkdir(dir, 0755);
     const size_t n = (size_t)c->n;
@@ -1416,7 +1787,7 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     if (!c) return PIE_E_INVAL;
     if (k == 0) return PIE_OK;
     if (!rows || !new_end) return fail(c, PIE_E_INVAL, "NULL pointer");
-    if (c->n_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     for (size_t i = 0; i < k; ++i)
         if (rows[i] < 0 || rows[i] >= c->n) return fail(c, PIE_E_INVAL, "row %d outside the table", rows[i]);
     PIE_HIP(c, hipSetDevice(c->device));
@@ -1479,6 +1850,7 @@ int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)
 int pie_scan_device(pie_ctx* c, int64_t now, int64_t cutoff, size_t* m_out)
 {
     if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = run_scan(c, now, cutoff);
     if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
@@ -1488,6 +1860,7 @@ int pie_scan_device(pie_ctx* c, int64_t now, int64_t cutoff, size_t* m_out)
 int pie_scan_begin(pie_ctx* c, int64_t now, int64_t cutoff)
 {
     if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
     PIE_HIP(c, hipSetDevice(c->device));
     return scan_begin(c, now, cutoff);
 }
@@ -1504,6 +1877,7 @@ int pie_scan_finish(pie_ctx* c, size_t* m_out)
 int pie_scan_begin_packed(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32, size_t u_pad, size_t idx_cap)
 {
     if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
     if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users");
     PIE_HIP(c, hipSetDevice(c->device));
     return scan_begin(c, now, cutoff, (int*)dst_i32, (int)u_pad, (long long)idx_cap);
@@ -1512,6 +1886,7 @@ int pie_scan_begin_packed(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32
 int pie_scan_begin_packed2(pie_ctx* c, int64_t now, int64_t cutoff, void* dst_i32, size_t u_pad, size_t idx_cap, void* counts_dst_i32)
 {
     if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
     if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users");
     PIE_HIP(c, hipSetDevice(c->device));
     return scan_begin(c, now, cutoff, (int*)dst_i32, (int)u_pad, (long long)idx_cap, (int*)counts_dst_i32);
@@ -1538,6 +1913,80 @@ int pie_scan_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
     if (sl.msg_counts && !sl.msg_by_k2)
         PIE_HIP(c, hipMemcpyAsync(sl.msg_counts, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDefault, c->stream));
     return pie_pack_results_device(c, sl.msg, (size_t)sl.msg_u_pad, (size_t)sl.msg_cap);
+}
+
+int pie_scan_batch_begin(pie_ctx* c, const pie_query* queries, int n_q)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    return batch_begin(c, queries, n_q, nullptr, 0, 0, 0, nullptr, 0);
+}
+
+int pie_scan_batch_begin_packed(pie_ctx* c, const pie_query* queries, int n_q, void* msg_i32, size_t msg_stride_words, size_t u_pad,
+                                size_t idx_cap, void* counts_i32, size_t counts_stride_words)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!msg_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u || msg_stride_words < u_pad + 2 + idx_cap)
+        return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users / stride below u_pad + 2 + idx_cap");
+    if (counts_i32 && counts_stride_words < (size_t)c->n_users) return fail(c, PIE_E_INVAL, "counts stride below n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    return batch_begin(c, queries, n_q, (int*)msg_i32, (long long)msg_stride_words, (int)u_pad, (long long)idx_cap, (int*)counts_i32,
+                       (long long)counts_stride_words);
+}
+
+int pie_scan_batch_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = batch_finish(c, ready_out);
+    if (rc) return rc;
+    if (m_out)
+        for (int q = 0; q < c->bres->n_q; ++q) m_out[q] = (size_t)c->bres->last[q].m;
+    return PIE_OK;
+}
+
+int pie_scan_batch_finish(pie_ctx* c, size_t* m_out) { return pie_scan_batch_finish_packed(c, m_out, nullptr); }
+
+int pie_scan_batch(pie_ctx* c, const pie_query* queries, int n_q, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
+    int rc = pie_scan_batch_begin(c, queries, n_q);
+    if (rc) return rc;
+    return pie_scan_batch_finish(c, m_out);
+}
+
+int pie_batch_result_device_ptrs(pie_ctx* c, int qi, void** counts_dev, void** offsets_dev, void** idx_dev)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (qi < 0 || qi >= c->bres->n_q) return fail(c, PIE_E_INVAL, "query %d outside the batch of %d", qi, c->bres->n_q);
+    const long long us = batch_users_stride(c);
+    if (counts_dev) *counts_dev = c->bres->counts_ord + (long long)qi * us;
+    if (offsets_dev) *offsets_dev = c->bres->offsets + (long long)qi * us;
+    if (idx_dev) *idx_dev = c->bres->idx_of[qi];
+    return PIE_OK;
+}
+
+int pie_batch_read_results(pie_ctx* c, int qi, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    void *dc = nullptr, *dof = nullptr, *di = nullptr;
+    int rc = pie_batch_result_device_ptrs(c, qi, &dc, &dof, &di);
+    if (rc) return rc;
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t a = c->stream;
+    const size_t m = (size_t)c->bres->last[qi].m;
+    if (m_out) *m_out = m;
+    if (counts_out) PIE_HIP(c, hipMemcpyAsync(counts_out, dc, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, a));
+    if (offsets_out) PIE_HIP(c, hipMemcpyAsync(offsets_out, dof, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, a));
+    if (idx_out && m > idx_cap) {
+        PIE_HIP(c, hipStreamSynchronize(a));
+        return fail(c, PIE_E_CAPACITY, "idx_cap %zu < selected rows %zu", idx_cap, m);
+    }
+    if (idx_out && m) PIE_HIP(c, hipMemcpyAsync(idx_out, di, m * 4, hipMemcpyDeviceToHost, a));
+    PIE_HIP(c, hipStreamSynchronize(a));
+    return PIE_OK;
 }
 
 int pie_read_results(pie_ctx* c, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)
@@ -1584,6 +2033,7 @@ int pie_scan(pie_ctx* c, int64_t now, int64_t cutoff, int32_t* counts_out, int64
              size_t idx_cap, size_t* m_out)
 {
     if (!c) return PIE_E_INVAL;
+    if (c->b_flight) return fail(c, PIE_E_STATE, "a batch is in flight: finish it first");
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = run_scan(c, now, cutoff);
     if (m_out) *m_out = c->res ? (size_t)c->res->last.m : 0;
@@ -1672,7 +2122,7 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
     if (q_out) *q_out = 0;
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n == 0) return PIE_OK;
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     if (getenv("PIE_EXPIRED_TWO_PASS")) // the count / prefix / write form, kept for A-B runs
         return run_row_list<0>(c, (long long)prev_now, (long long)now, queue_out, cap, q_out);
     PIE_HIP(c, hipSetDevice(c->device));
@@ -1730,7 +2180,7 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
     if (q_out) *q_out = 0;
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n == 0) return PIE_OK;
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
@@ -1825,7 +2275,7 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
 int pie_set_scan_form(pie_ctx* c, int form)
 {
     if (!c) return PIE_E_INVAL;
-    if (c->n_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
     if (form < 0) {
         c->k1_pinned = false;
         c->k1_variant = 0x03;
@@ -1915,6 +2365,21 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
     out->key_ambiguous = (c->res && (c->res->variant & 0x400)) ? (uint32_t)(c->res->last.amb > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->res->last.amb) : 0u;
     out->live = sl ? sl->last.live : 0;
     out->candidates = (sl && (sl->variant & 0x400)) ? sl->last.cand : 0;
+    if (c->last_was_batch && c->bres && c->bres->have_result) {
+        // the last finished thing was a batch: selected = rows over all its queries, form = keyed | 0x1000 (batched)
+        const BatchSlot& b = *c->bres;
+        uint64_t m = 0;
+        uint32_t mx = 0;
+        for (int q = 0; q < b.n_q; ++q) { m += b.last[q].m; mx = mx > b.last[q].max_count ? mx : b.last[q].max_count; }
+        out->selected = m;
+        out->max_bucket = mx;
+        out->n_segments = out->n_big = 0;
+        out->k1_blocks = (uint32_t)b.k1_blocks;
+        out->k1_variant = b.unsupported ? 0u : (0x1485u | (b.fine_key ? 0x800u : 0u));
+        out->key_ambiguous = 0;
+        out->live = 0;
+        out->candidates = b.unsupported ? 0 : b.last[0].cand;
+    }
     return PIE_OK;
 }
 

@@ -1,0 +1,218 @@
+"""GPU: the batched scan (pie_scan_batch_*: Q queries, one table pass) against Q oracle scans on the same seeded inputs —
+bit-exact counts / offsets / idx per query — including the queries a batch hands to the general path (dense queries,
+buckets of more than 16 rows), mixed now / cutoff / mask, ragged sizes, two batches in flight and the per-query result
+messages.  Through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT64_MIN = -(2 ** 63)
+ALL = 2 ** 64 - 1
+DAY = 86400 * 1000
+HOUR = 3600 * 1000
+SEED = 0x5EED5EED
+
+
+def assert_same(got, want, tag=""):
+    for name, a, b in zip(("counts", "offsets", "idx"), got, want):
+        assert a.dtype == b.dtype, (tag, name)
+        assert np.array_equal(a, b), (tag, name)
+
+
+def oracle_answers(oracle, cols, U, D, queries):
+    s, e, u, d = cols
+    lim = ALL if D >= 64 else (1 << D) - 1
+    return [oracle.scan(s, e, u, d, U, now, cutoff, mask & lim) for now, cutoff, mask in queries]
+
+
+def mixed_queries(oracle, k):
+    """k sparse queries with distinct now / cutoff / mask (the request mix of a feed server: every request samples its own
+    clock; cutoffs change daily; masks follow the caller's role)."""
+    t0 = oracle.T0_MS
+    masks = [0x5555555555555555, 0xAAAAAAAAAAAAAAAA, ALL, 0x00000000FFFF0000, 0x1, 0x8000000000000001]
+    return [(t0 - 6 * HOUR - 977 * i - (i % 3) * HOUR, t0 - (61 + i % 4) * DAY - 13 * i, masks[i % len(masks)]) for i in range(k)]
+
+
+@pytest.mark.parametrize("n,U,D,flags", [
+    (1, 1, 1, 0), (65, 3, 2, 0), (4097, 9, 7, 1), (100003, 97, 32, 0), (1 << 20, 10 ** 4, 32, 0), (3000017, 20011, 64, 1),
+])
+@pytest.mark.parametrize("nq", [1, 3, 16])
+def test_batch_equals_separate_scans(gpu_ctx, oracle, n, U, D, flags, nq):
+    cols = oracle.gen(SEED, n, 0, n, U, D, flags)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    queries = mixed_queries(oracle, nq)
+    got = gpu_ctx.scan_batch(queries)
+    for k, (g, w) in enumerate(zip(got, oracle_answers(oracle, cols, U, D, queries))):
+        assert_same(g, w, "query %d" % k)
+    # the same through single scans of the product (mask per query through set_disciplines)
+    for k in (0, nq - 1):
+        gpu_ctx.set_disciplines(queries[k][2], D)
+        assert_same(gpu_ctx.scan(queries[k][0], queries[k][1]), got[k], "single %d" % k)
+
+
+def test_batch_with_queries_that_fall_back(gpu_ctx, oracle):
+    """One batch holding sparse queries, a dense one (25 % of the rows selected: handed to the general path up front from the
+    key histogram), an everything-selected one, a nothing-selected one and — on a table with few users — buckets of more
+    than 16 rows (found by the batch's own offsets kernel, rerun on the general path).  Every answer equals the oracle's."""
+    n, U, D = 1 << 20, 5000, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    t0 = oracle.T0_MS
+    queries = [
+        (t0 - 6 * HOUR, t0 - 61 * DAY, 0x5555555555555555),
+        (t0 - 100 * DAY, t0 - 61 * DAY, 0xAAAAAAAAAAAAAAAA),   # dense
+        (INT64_MIN, INT64_MIN, ALL),                            # everything
+        (2 ** 62, INT64_MIN, ALL),                              # nothing
+        (t0 - 5 * HOUR, INT64_MIN, ALL),
+        (t0 - 7 * HOUR + 1, t0 - 30 * DAY, 0x3),
+    ]
+    got = gpu_ctx.scan_batch(queries)
+    want = oracle_answers(oracle, cols, U, D, queries)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert_same(g, w, "query %d" % k)
+    assert got[2][2].size == n and got[3][2].size == 0
+    # few users: sparse queries whose buckets outgrow the 16 direct slots
+    n, U = 300000, 7
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    queries = mixed_queries(oracle, 5)
+    got = gpu_ctx.scan_batch(queries)
+    want = oracle_answers(oracle, cols, U, D, queries)
+    assert max(int(w[0].max()) for w in want) > 16
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert_same(g, w, "query %d" % k)
+
+
+def test_batch_edge_tables(gpu_ctx, oracle):
+    """Tombstoned and sentinel ends, disciplines outside the table, equal `end` values (every key ambiguous), queries whose
+    `now` sits exactly on an `end`, and a query below the fine key's base next to ones above it (the batch then streams the
+    2-byte key)."""
+    n, U, D = 200000, 300, 40
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 1)
+    e = e.copy()
+    d = d.copy()
+    e[::7] = INT64_MIN
+    d[::11] = 64 + (np.arange(d[::11].size) % 5)
+    d[5::13] = -1
+    cols = (s, e, u, d)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, 64)
+    t0 = oracle.T0_MS
+    live_ends = np.sort(e[e != INT64_MIN])
+    top = int(live_ends[-1])
+    queries = [(top - 1, INT64_MIN, ALL), (top, INT64_MIN, ALL), (int(live_ends[-50]), INT64_MIN, ALL),
+               (int(live_ends[-50]) - 1, t0 - 3 * DAY, 0xF0F0F0F0F0F0F0F0), (t0 - 2 * HOUR, INT64_MIN, ALL),
+               (int(live_ends[int(live_ends.size * 0.95)]), INT64_MIN, 0xFF)]
+    for g, w in zip(gpu_ctx.scan_batch(queries), oracle_answers(oracle, cols, U, 64, queries)):
+        assert_same(g, w)
+    # all rows end at the same instant
+    e2 = np.full(n, t0, np.int64)
+    cols = (s, e2, u, d)
+    gpu_ctx.load_columns(*cols, U)
+    queries = [(t0 - 1, t0 - 119 * DAY, ALL), (t0, INT64_MIN, ALL), (t0 + 1, INT64_MIN, ALL)]
+    for g, w in zip(gpu_ctx.scan_batch(queries), oracle_answers(oracle, cols, U, 64, queries)):
+        assert_same(g, w)
+
+
+def test_two_batches_in_flight_and_table_changes(gpu_ctx, oracle):
+    """begin(i+1) before finish(i): the offsets kernels of batch i ride in the launch of batch i+1's table pass; batches of
+    different sizes alternate (every span set is cleaned whatever the sizes); appends and touches between batches are seen
+    by the next one."""
+    n, U, D = 600011, 4099, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    sizes = [16, 2, 7, 16, 1, 9, 3]
+    batches = [mixed_queries(oracle, k)[::-1] if i % 2 else mixed_queries(oracle, k) for i, k in enumerate(sizes)]
+    wants = [oracle_answers(oracle, cols, U, D, qs) for qs in batches]
+    gpu_ctx.scan_batch_begin(batches[0])
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            gpu_ctx.scan_batch_begin(batches[i + 1])
+        ms = gpu_ctx.scan_batch_finish()
+        assert ms == [int(w[2].size) for w in wants[i]]
+        for k in range(len(batches[i])):
+            assert_same(gpu_ctx.batch_read_results(k), wants[i][k], "batch %d query %d" % (i, k))
+    # single scans and batches do not mix in flight
+    gpu_ctx.scan_batch_begin(batches[1])
+    with pytest.raises(Exception):
+        gpu_ctx.scan_begin(*batches[1][0][:2])
+    gpu_ctx.scan_batch_finish()
+    # table changes between batches
+    s, e, u, d = (c.copy() for c in cols)
+    rows = np.arange(0, n, 1013, dtype=np.int32)
+    new_end = np.full(rows.size, oracle.T0_MS + HOUR, np.int64)
+    gpu_ctx.set_end(rows, new_end)
+    e[rows] = new_end
+    s2, e2, u2, d2 = oracle.gen(SEED + 1, 5000, 0, 5000, U, D, 0)
+    e2 = e2 + 119 * DAY
+    gpu_ctx.append_rows(s2, e2, u2, d2, U)
+    cols2 = (np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]), np.concatenate([d, d2]))
+    qs = mixed_queries(oracle, 6)
+    for g, w in zip(gpu_ctx.scan_batch(qs), oracle_answers(oracle, cols2, U, D, qs)):
+        assert_same(g, w)
+
+
+def test_batch_messages_equal_the_pack_kernel(pie, gpu_ctx, oracle):
+    """pie_scan_batch_begin_packed: every query's result message [off[0..u_pad] | M | rows] and counts copy, written by the
+    batch's offsets kernels into caller-owned memory (here mapped pinned host memory), equal what the results say."""
+    n, U, D = 400009, 3001, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    qs = mixed_queries(oracle, 5) + [(oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, ALL)]   # the last one falls back
+    want = oracle_answers(oracle, cols, U, D, qs)
+    cap = max(int(w[2].size) for w in want) + 7
+    u_pad = U + 5
+    stride = u_pad + 2 + cap
+    msg_h, msg_d, msg_addr = gpu_ctx.host_alloc(len(qs) * stride)
+    cnt_h, cnt_d, cnt_addr = gpu_ctx.host_alloc(len(qs) * U)
+    try:
+        gpu_ctx.scan_batch_begin_packed(qs, msg_d, stride, u_pad, cap, cnt_d, U)
+        ms, ready = gpu_ctx.scan_batch_finish(packed=True)
+        assert not ready   # one query went through the general path: its message came from the pack kernel
+        gpu_ctx.synchronize()
+        for k, w in enumerate(want):
+            m = msg_h[k * stride:(k + 1) * stride]
+            assert ms[k] == w[2].size
+            assert np.array_equal(m[: U + 1], w[1].astype(np.int32))
+            assert np.all(m[U + 1: u_pad + 2] == w[2].size)
+            assert np.array_equal(m[u_pad + 2: u_pad + 2 + w[2].size], w[2])
+            assert np.array_equal(cnt_h[k * U:(k + 1) * U], w[0])
+        gpu_ctx.scan_batch_begin_packed(qs[:5], msg_d, stride, u_pad, cap, cnt_d, U)
+        ms, ready = gpu_ctx.scan_batch_finish(packed=True)
+        assert ready
+        for k, w in enumerate(want[:5]):
+            m = msg_h[k * stride:(k + 1) * stride]
+            assert np.array_equal(m[: U + 1], w[1].astype(np.int32)) and np.array_equal(m[u_pad + 2: u_pad + 2 + w[2].size], w[2])
+    finally:
+        gpu_ctx.host_free(msg_addr)
+        gpu_ctx.host_free(cnt_addr)
+
+
+def test_batch_argument_errors(gpu_ctx, oracle):
+    cols = oracle.gen(SEED, 1000, 0, 1000, 10, 3, 0)
+    gpu_ctx.load_columns(*cols, 10)
+    with pytest.raises(Exception):
+        gpu_ctx.scan_batch_begin([])
+    with pytest.raises(Exception):
+        gpu_ctx.scan_batch_begin(mixed_queries(oracle, 17))
+    with pytest.raises(Exception):
+        gpu_ctx.scan_batch_finish()
+    with pytest.raises(Exception):
+        gpu_ctx.batch_read_results(99)
+
+
+def test_batch_cfg2_exact(gpu_ctx, oracle):
+    """BASELINE config 2 (10^7 sessions / 10^4 users / 32 disciplines): 16 queries in one pass against 16 oracle scans."""
+    n, U, D = 10 ** 7, 10 ** 4, 32
+    gpu_ctx.gen_synthetic(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.set_disciplines(ALL, D)
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    qs = mixed_queries(oracle, 16)
+    got = gpu_ctx.scan_batch(qs)
+    for k, (g, w) in enumerate(zip(got, oracle_answers(oracle, cols, U, D, qs))):
+        assert_same(g, w, "query %d" % k)
