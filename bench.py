@@ -383,7 +383,8 @@ def main():
         model = None
         if batch_ms is not None:
             kb = 1 if variant & 0x800 else 2
-            model = n_local * kb + st["candidates"] * 128 + sum(batch_ms) * (64 + 4) + Q * u_local * 12
+            # one union bucket store per selected row (whatever Q), Q sets of counts / offsets / row lists
+            model = n_local * kb + st["candidates"] * 128 + max(batch_ms) * 64 + sum(batch_ms) * 4 + Q * u_local * 12
         elif args.mode == "scan" and variant & 0x400:
             kb = 1 if variant & 0x800 else 2
             model = n_local * kb + st["candidates"] * 128 + st["key_ambiguous"] * 128 + int(m) * 64 + u_local * 12 + int(m) * 4

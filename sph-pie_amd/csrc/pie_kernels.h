@@ -1405,10 +1405,7 @@ __device__ __forceinline__ unsigned wave_list_slot(unsigned int* counter, unsign
     return base + before;
 }
 
-//   LISTS  false: the batched scan (pie_scan_batch_begin): its table pass keeps no staged route, so a bucket of more than
-//          kTinyMax rows cannot be completed here; it is only counted (Summary::n_over) and the host reruns that query on
-//          the general path.  out_cap bounds the row list such a query may still write (its result is discarded).
-template <int UPT, bool ORDER, int BLOCK, bool LISTS = true>
+template <int UPT, bool ORDER, int BLOCK>
 __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int* __restrict__ counts_ord, int n_users,
                                                  unsigned long long* __restrict__ tile_pub, ScanCtl* __restrict__ ctl,
                                                  long long* __restrict__ offsets,
@@ -1419,8 +1416,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
                                                  DirectSlots direct, BktRec* __restrict__ bkt,
                                                  int* __restrict__ out_idx, int* __restrict__ msg, int u_pad, long long msg_cap,
                                                  int* __restrict__ msg_counts, const HotSet& hot,
-                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk,
-                                                 long long out_cap = INT64_MAX)
+                                                 int hot_thr, int* __restrict__ hot_list, int* __restrict__ over_list, int bid, int nblk)
 {
     static_assert(UPT == 8 || UPT == 1, "tile shapes: 2048 users (8 per thread) or one user per thread");
     (void)bkt; // the direct part of outgrown buckets is moved by k_copy_direct, not here
@@ -1532,7 +1528,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
             const int n = c[k];
             if constexpr (ORDER) {
                 if (msg) msg_store(msg + u, (int)run);
-                if (n >= 1 && n <= 8 && !is_hot[k] && (LISTS || run + n <= out_cap)) {
+                if (n >= 1 && n <= 8 && !is_hot[k]) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         if (i < n) {
@@ -1544,9 +1540,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
             // buckets K2 does not order itself: more than kTinyMax rows (without ORDER: every bucket that is not read from
             // the direct slots by k_sort_tiny), and every bucket of a hot user
             const bool listed = n > kTinyMax || (is_hot[k] && n > 0);
-            if (!LISTS) {
-                if (listed) (void)wave_list_slot(&summary->n_over); // counted only: the host reruns this query
-            } else if (listed) {
+            if (listed) {
                 // whole bucket still in its direct slots?  then the wave that orders it reads it from there (flags bit 1,
                 // the user id above it) and nothing of it was staged; otherwise its direct part joins the staged rest in bkt
                 const int dcap = 1 << direct.shift;
@@ -1595,7 +1589,7 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
         // buckets of 9..16 rows, one at a time with the whole wave: lane i < n holds record i and counts the records that
         // sort before it; that count is its place.  (`run` was advanced past this thread's bucket above: UPT == 1.)
         const int n_mine = c[0];
-        const bool mid = u0 < n_users && n_mine > 8 && n_mine <= kTinyMax && !is_hot[0] && (LISTS || run <= out_cap);
+        const bool mid = u0 < n_users && n_mine > 8 && n_mine <= kTinyMax && !is_hot[0];
         unsigned long long todo = __ballot(mid);
         if (__popcll(todo) > 6) {
             // many such buckets in this wave (users of similar weight sit together): one pass of the 16-slot network
@@ -1769,16 +1763,20 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
 // ------------------------------------------------------------------------------------------------ batched scan: Q queries, one table pass
 //
 // SURVEY.md section 7 ("batch many queries per launch") / the north_star's "batched GPU scan": a server answers many
-// feed requests, each with its own `now` (millisecond clock), `cutoff` and discipline mask.  The table pass is the same
-// for all of them up to the last compare, so ONE launch streams the key column once, finds the rows that are candidates
-// for ANY of the Q queries (key >= the smallest key(now)), gathers each candidate's payload record once, and then
-// evaluates the Q predicates on it: per query one histogram atomic (its return value is the row's rank in the bucket)
-// and one direct-slot store.  The fixed costs of a scan — the launch, the offsets kernel's ticket / look-back chain, the
-// host's summary round trip — are paid once per batch instead of once per query, and the atomics of different queries
-// are independent, so their round trips overlap.  Per-query state (histogram span, direct slots, counts, offsets, row
-// list) lives in arrays with a fixed stride per query.  There is no staged route here: a query that finds a bucket of more
-// than kTinyMax rows is reported (Summary::n_over) and the host reruns it on the general path, bit for bit the same result.
+// feed requests, each with its own `now` (millisecond clock), `cutoff` and discipline mask.  Requests that arrive
+// together select almost the same rows, so the batch works on the UNION of their selections:
+//   table pass   streams the key column once, takes the rows that are candidates for ANY query (key >= the smallest
+//                key(now)), gathers each candidate's payload record once, evaluates the Q predicates into a Q-bit query
+//                mask, and — if any bit is set — issues ONE histogram atomic (rank in the user's union bucket) and ONE
+//                bucket-slot store {start, row, query mask}: the same atomics and stores as a single query, whatever Q
+//   offsets      one thread per user loads and orders its union bucket once, counts the rows of every query in it, runs Q
+//                prefix scans side by side (tile granules per query), and writes Q sets of counts / offsets / row lists.
+// (A first version kept one histogram and one bucket set per query: every extra query then cost its own ~3 x 10^5
+// returning atomics, ~10 us at the chip's scattered-atomic rate, plus its own offsets kernel — profiles/r02_b_*.)
+// There is no staged route here: a user whose union bucket outgrows its slots is reported (Summary::n_over) and the host
+// reruns the batch's queries on the general path, bit for bit the same result; the slot capacity then grows (up to 64).
 constexpr int kBatchMax = 16;
+constexpr int kUnionShiftMax = 6; // union bucket slots per user: 16 .. 64 (one wave orders a bucket by ranking)
 
 struct BatchQueryScalars {
     long long now, cutoff;
@@ -1796,11 +1794,10 @@ struct BatchScanArgs {
     int n_users;
     int n_q;
     unsigned min_key;          // smallest now_key of the batch: a row below it is dead for every query
-    char* span;                // query q's histogram span starts at span + q * span_stride (counts first)
-    long long span_stride;     // bytes
-    long long summary_off;     // byte offset of the Summary inside a span
-    BktRec* direct;            // query q's direct slots: direct + q * direct_stride (kTinyMax slots per user)
-    long long direct_stride;   // records
+    int dshift;                // log2 of the union bucket's slot capacity
+    int* counts;               // union histogram (transposed user order, hist_index)
+    Summary* summary;          // query 0's summary: bad rows and the row statistics of the pass
+    BktRec* direct;            // union bucket slots, (1 << dshift) per user; BktRec::pad = the queries that selected the row
     BatchQueryScalars q[kBatchMax];
 };
 
@@ -1824,6 +1821,7 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     int* rkey = ring_key[wave];
     int lhead = 0, lfill = 0, ncand = 0; // wave-uniform
     const int nq = a.n_q;
+    const int cap = 1 << a.dshift;
 
     // evaluate `cnt` queued candidates (cnt <= 64), one per lane, against every query of the batch
     auto drain = [&](int cnt) {
@@ -1842,39 +1840,26 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
         for (int q = 0; q < nq; ++q) amb_any |= key == a.q[q].now_key;
         long long ev = 0;
         if (valid && amb_any) ev = a.end[row]; // the 8-byte `end` only where some query's key cannot decide
-        const bool user_ok = (unsigned)pr.user < (unsigned)a.n_users;
         const bool disc_ok = (unsigned)pr.disc < 64u;
-        const int hidx = hist_index(user_ok ? pr.user : 0, a.n_users);
-        BktRec rec;
-        rec.start = pr.start;
-        rec.idx = row;
-        rec.pad = 0;
-        // four queries at a time: their histogram atomics are independent, so the round trips overlap
-        for (int q0 = 0; q0 < nq; q0 += 4) {
-            int rank[4];
-            bool p[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = q0 + j;
-                p[j] = false;
-                rank[j] = 0;
-                if (q < nq) { // wave-uniform
-                    const BatchQueryScalars& Q = a.q[q];
-                    const bool live = key > Q.now_key || (key == Q.now_key && ev > Q.now);
-                    p[j] = valid & live & (pr.start >= Q.cutoff) & disc_ok & (((Q.mask >> (pr.disc & 63)) & 1ull) != 0);
-                    int* counts = reinterpret_cast<int*>(a.span + (long long)q * a.span_stride);
-                    if (p[j] && !user_ok) {
-                        atomicAdd(&reinterpret_cast<Summary*>(a.span + (long long)q * a.span_stride + a.summary_off)->bad_rows, 1u);
-                        p[j] = false;
-                    }
-                    if (p[j]) rank[j] = atomicAdd(&counts[hidx], 1);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = q0 + j;
-                if (q < nq && p[j] && (unsigned)rank[j] < (unsigned)kTinyMax)
-                    a.direct[(long long)q * a.direct_stride + ((long long)pr.user << 4) + rank[j]] = rec;
+        unsigned qmask = 0;
+        for (int q = 0; q < nq; ++q) { // wave-uniform loop over the queries' scalars (SGPRs)
+            const BatchQueryScalars& Q = a.q[q];
+            const bool live = key > Q.now_key || (key == Q.now_key && ev > Q.now);
+            const bool p = valid & live & (pr.start >= Q.cutoff) & disc_ok & (((Q.mask >> (pr.disc & 63)) & 1ull) != 0);
+            qmask |= (p ? 1u : 0u) << q;
+        }
+        if (qmask && (unsigned)pr.user >= (unsigned)a.n_users) {
+            atomicAdd(&a.summary->bad_rows, 1u);
+            qmask = 0;
+        }
+        if (qmask) {
+            const int rank = atomicAdd(&a.counts[hist_index(pr.user, a.n_users)], 1);
+            if (rank < cap) {
+                BktRec rec;
+                rec.start = pr.start;
+                rec.idx = row;
+                rec.pad = (int)qmask;
+                a.direct[((long long)pr.user << a.dshift) + rank] = rec;
             }
         }
         ncand += cnt;
@@ -1949,27 +1934,28 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     if (lfill > 0) drain(lfill);
     if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
     __syncthreads();
-    // candidates are a property of the batch: reported on query 0's statistics slots
-    if (threadIdx.x == 0) add_row_stats(reinterpret_cast<Summary*>(a.span + a.summary_off), 0, 0, bid, blk_cand);
+    if (threadIdx.x == 0) add_row_stats(a.summary, 0, 0, bid, blk_cand);
 }
 
-// K2 of a batch: blocks [q * tiles, (q + 1) * tiles) run the fused offsets + order kernel of query q (256 users per block)
+// offsets + order kernel of a batch: blocks of 256 users; see the section header
 struct BatchTailArgs {
     int n_q;
     int n_users;
-    int tiles;                 // blocks per query
-    char* span;                // the spans of the batch this tail belongs to
+    int tiles;                 // blocks (256 users each) per query group; a batch of more than 8 queries runs as two groups
+                               // of <= 8 (queries 0..7 and 8..), each a complete offsets kernel of its own over the same union
+                               // buckets: 16 queries' worth of per-thread state would halve the occupancy of the launch
+    int dshift;
+    char* span;                // the batch's span set: span 0 holds the union histogram and the ticket / done words,
+                               // span q (at q * span_stride) query q's tile granules and Summary
     long long span_stride, tiles_off, ctl_off, summary_off; // byte offsets inside a span
     char* zero_span;           // the span SET the batch after the next will use: zeroed here, all kBatchMax spans of it
-    long long zero_vec16;      // 16-byte vectors per tile group (group q zeroes vectors [q * zero_vec16, (q + 1) * zero_vec16))
-    long long zero_total16;    // ... clamped to the set's total
+    long long zero_total16;    // 16-byte vectors of a set
     int* counts_ord;           // + q * users_stride
-    long long* offsets;        // + q * (users_stride)
+    long long* offsets;        // + q * users_stride
     long long users_stride;    // elements (>= n_users + 1)
-    BktRec* direct;
-    long long direct_stride;
+    const BktRec* direct;      // union bucket slots
     int* out_idx;              // + q * out_stride
-    long long out_stride;      // = capacity of a query's row list
+    long long out_stride;      // capacity of a query's row list
     HostSummary* host;         // [n_q], mapped host memory
     unsigned long long seq;
     int* msg;                  // optional per-query result messages: msg + q * msg_stride
@@ -1980,30 +1966,305 @@ struct BatchTailArgs {
     long long msg_counts_stride;
 };
 
-__device__ __forceinline__ void batch_tail_body(const BatchTailArgs& t, int bid)
+__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane)
 {
-    const int q = bid / t.tiles, tile_bid = bid - q * t.tiles;
-    char* sp = t.span + (long long)q * t.span_stride;
-    HotSet none;
-    none.n = 0;
-    DirectSlots d;
-    d.p = t.direct + (long long)q * t.direct_stride;
-    d.shift = 4;
-    const long long z0 = (long long)q * t.zero_vec16;
-    long long zcount = t.zero_total16 - z0;
-    zcount = zcount < 0 ? 0 : (zcount > t.zero_vec16 ? t.zero_vec16 : zcount);
-    int4* zspan = (t.zero_span && zcount > 0) ? reinterpret_cast<int4*>(t.zero_span) + z0 : nullptr;
-    offsets_body<1, true, kK1Threads, false>(
-        reinterpret_cast<const int*>(sp), t.counts_ord + (long long)q * t.users_stride, t.n_users,
-        reinterpret_cast<unsigned long long*>(sp + t.tiles_off), reinterpret_cast<ScanCtl*>(sp + t.ctl_off),
-        t.offsets + (long long)q * t.users_stride, nullptr, nullptr, nullptr, reinterpret_cast<Summary*>(sp + t.summary_off),
-        t.host + q, t.seq, zspan, zcount, d,
-        nullptr, t.out_idx + (long long)q * t.out_stride, t.msg ? t.msg + (long long)q * t.msg_stride : nullptr, t.u_pad, t.msg_cap,
-        t.msg_counts ? t.msg_counts + (long long)q * t.msg_counts_stride : nullptr, none, 0, nullptr, nullptr, tile_bid, t.tiles,
-        t.out_stride);
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(v, o, kWave);
+        if (lane >= o) v += t;
+    }
+    return v;
 }
 
-__global__ __launch_bounds__(kK1Threads) void k_offsets_batch(BatchTailArgs t) { batch_tail_body(t, (int)blockIdx.x); }
+// QT = compile-time bound on the queries of one group (4 / 8): per-query state lives in registers
+template <int QT>
+__device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int gbid)
+{
+    constexpr int BLOCK = kK1Threads;
+    constexpr int kWaves = kK1Waves;
+    __shared__ long long s_sum[QT][kWaves];
+    __shared__ unsigned int s_max[QT][kWaves];
+    __shared__ long long s_part[QT][kWaves];
+    __shared__ unsigned int s_pmax[QT][kWaves];
+    __shared__ long long s_total[QT];
+    __shared__ unsigned int tile_s;
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = t.tiles, U = t.n_users;
+    const int grp = gbid / nblk, n_grp = t.n_q > 8 ? 2 : 1;
+    const int q_lo = grp * 8;
+    const int nq = (t.n_q - q_lo) < QT ? (t.n_q - q_lo) : QT;   // queries of this group
+    if (t.zero_span) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        int4* zs = reinterpret_cast<int4*>(t.zero_span);
+        for (long long i = (long long)gbid * BLOCK + threadIdx.x; i < t.zero_total16; i += (long long)nblk * n_grp * BLOCK) zs[i] = z;
+    }
+    // the group's ticket / done words and its overflow count live in the span of its first query; the table pass's
+    // statistics (bad rows, candidates) in span 0
+    char* gspan = t.span + (long long)q_lo * t.span_stride;
+    ScanCtl* ctl = reinterpret_cast<ScanCtl*>(gspan + t.ctl_off);
+    Summary* sumg = reinterpret_cast<Summary*>(gspan + t.summary_off);
+    Summary* sum0 = reinterpret_cast<Summary*>(t.span + t.summary_off);
+    if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int tile = (int)tile_s;
+    const int u = tile * BLOCK + (int)threadIdx.x;
+    const bool in_u = u < U;
+    const int* counts = reinterpret_cast<const int*>(t.span);
+    const int cap = 1 << t.dshift;
+    const int n_raw = in_u ? counts[hist_index(u, U)] : 0;
+    const int nn = n_raw < cap ? n_raw : cap;
+    const BktRec* src = t.direct + ((long long)(in_u ? u : 0) << t.dshift);
+
+    // the user's union bucket: up to 8 rows ordered in this thread's registers; 9 .. 64 rows by the whole wave (below)
+    long long ks[8];
+    int ki[8];
+    unsigned km[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        BktRec r;
+        r.start = INT64_MAX;
+        r.idx = INT32_MAX;
+        r.pad = 0;
+        if (nn <= 8 && k < nn) r = src[k];
+        ks[k] = r.start;
+        ki[k] = r.idx;
+        km[k] = (unsigned)r.pad >> q_lo; // this group's queries at bits 0 ..
+    }
+    if (nn >= 2 && nn <= 8) {
+#pragma unroll
+        for (int k = 2; k <= 8; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k) == 0;
+                        const bool lt = key_less(ks[l], ki[l], ks[i], ki[i]);
+                        const bool sw = up ? lt : !lt;
+                        const long long s0 = sw ? ks[l] : ks[i], s1 = sw ? ks[i] : ks[l];
+                        const int i0 = sw ? ki[l] : ki[i], i1 = sw ? ki[i] : ki[l];
+                        const unsigned m0 = sw ? km[l] : km[i], m1 = sw ? km[i] : km[l];
+                        ks[i] = s0; ks[l] = s1; ki[i] = i0; ki[l] = i1; km[i] = m0; km[l] = m1;
+                    }
+                }
+            }
+        }
+    }
+    int cq[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) cq[q] = 0;
+    if (nn <= 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < nn) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q) cq[q] += (int)((km[k] >> q) & 1u);
+            }
+    }
+    // larger buckets, phase A: per-query row counts (the prefix scans need them before anything can be placed)
+    const bool mid = nn > 8;
+    {
+        unsigned long long todo = __ballot(mid);
+        while (todo) {
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int nb = __shfl(nn, src_lane, kWave);
+            const int ub = __shfl(u, src_lane, kWave);
+            unsigned qm = 0;
+            if (lane < nb) qm = (unsigned)(t.direct + ((long long)ub << t.dshift))[lane].pad >> q_lo;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const int cnt = __popcll(__ballot((qm >> q) & 1u));
+                if (lane == src_lane) cq[q] = cnt;
+            }
+        }
+    }
+    // Q prefix scans side by side
+    int incl[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        incl[q] = wave_incl_scan_i32(cq[q], lane);
+        unsigned mx = (unsigned)cq[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, kWave));
+        if (lane == 63) s_sum[q][wave] = incl[q];
+        if (lane == 0) s_max[q][wave] = mx;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nq) { // one granule per query: its tile sum (bits 0..30) and largest bucket (bits 31..61)
+        const int q = (int)threadIdx.x;
+        long long tot = 0;
+        unsigned mx = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { tot += s_sum[q][w]; mx = max(mx, s_max[q][w]); }
+        unsigned long long* pub = reinterpret_cast<unsigned long long*>(t.span + (long long)(q_lo + q) * t.span_stride + t.tiles_off);
+        __hip_atomic_store(&pub[tile], kTileReady | ((unsigned long long)mx << 31) | (unsigned long long)tot, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // base of every query = sum of its granules of the tiles in front of this one
+    long long part[QT];
+    unsigned pmax[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { part[q] = 0; pmax[q] = 0; }
+    for (int tt = threadIdx.x; tt < tile; tt += BLOCK) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if (q < nq) {
+                const unsigned long long* pub = reinterpret_cast<const unsigned long long*>(t.span + (long long)(q_lo + q) * t.span_stride + t.tiles_off);
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(&pub[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(v & kTileReady)) __builtin_amdgcn_s_sleep(1);
+                } while (!(v & kTileReady));
+                part[q] += (long long)(v & 0x7FFFFFFFull);
+                pmax[q] = max(pmax[q], (unsigned)((v >> 31) & 0x7FFFFFFFull));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            part[q] += __shfl_xor(part[q], o, kWave);
+            pmax[q] = max(pmax[q], (unsigned)__shfl_xor((int)pmax[q], o, kWave));
+        }
+        if (lane == 0) { s_part[q][wave] = part[q]; s_pmax[q][wave] = pmax[q]; }
+    }
+    __syncthreads();
+    long long run[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        long long base = 0;
+        unsigned pm = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { base += s_part[q][w]; pm = max(pm, s_pmax[q][w]); }
+        pmax[q] = pm;
+        run[q] = base + incl[q] - cq[q];
+        for (int w = 0; w < wave; ++w) run[q] += s_sum[q][w];
+    }
+    const long long us = t.users_stride;
+    if (in_u) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if (q < nq) {
+                t.counts_ord[(long long)(q_lo + q) * us + u] = cq[q];
+                t.offsets[(long long)(q_lo + q) * us + u] = run[q];
+                if (t.msg_counts) msg_store(t.msg_counts + (long long)(q_lo + q) * t.msg_counts_stride + u, cq[q]);
+                int* msg = t.msg ? t.msg + (long long)(q_lo + q) * t.msg_stride : nullptr;
+                if (msg) msg_store(msg + u, (int)run[q]);
+                // this query's rows of a small bucket, in bucket order
+                if (nn >= 1 && nn <= 8 && cq[q] > 0 && run[q] + cq[q] <= t.out_stride) {
+                    int* out = t.out_idx + (long long)(q_lo + q) * t.out_stride;
+                    long long pos = run[q];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < nn && ((km[k] >> q) & 1u)) {
+                            out[pos] = ki[k];
+                            if (msg && pos < t.msg_cap) msg_store(msg + t.u_pad + 2 + pos, ki[k]);
+                            ++pos;
+                        }
+                }
+            }
+        }
+    }
+    // larger buckets, phase B: lane i < n holds record i and counts, per query, the query's records that sort before it
+    {
+        unsigned long long todo = __ballot(mid && in_u);
+        while (todo) {
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int nb = __shfl(nn, src_lane, kWave);
+            const int ub = __shfl(u, src_lane, kWave);
+            BktRec r;
+            r.start = INT64_MAX;
+            r.idx = INT32_MAX;
+            r.pad = 0;
+            if (lane < nb) r = (t.direct + ((long long)ub << t.dshift))[lane];
+            // byte q of lo (q < 8) / hi (q >= 8) counts the records of query q that sort before this lane's record
+            unsigned long long lo = 0, hi = 0;
+            for (int j = 0; j < nb; ++j) {
+                const long long sj = __shfl(r.start, j, kWave);
+                const int ij = __shfl(r.idx, j, kWave);
+                const unsigned mj = (unsigned)__shfl(r.pad, j, kWave) >> q_lo;
+                if (key_less(sj, ij, r.start, r.idx)) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const unsigned long long one = (unsigned long long)((mj >> q) & 1u) << (8 * (q & 7));
+                        if (q < 8) lo += one; else hi += one;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const long long rq = __shfl(run[q], src_lane, kWave);
+                const int cnt = __shfl(cq[q], src_lane, kWave);
+                if (q < nq && lane < nb && (((unsigned)r.pad >> (q_lo + q)) & 1u) && rq + cnt <= t.out_stride) {
+                    const long long pos = rq + (long long)(((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFull);
+                    t.out_idx[(long long)(q_lo + q) * t.out_stride + pos] = r.idx;
+                    int* msg = t.msg ? t.msg + (long long)(q_lo + q) * t.msg_stride : nullptr;
+                    if (msg && pos < t.msg_cap) msg_store(msg + t.u_pad + 2 + pos, r.idx);
+                }
+            }
+        }
+    }
+    if (in_u && n_raw > cap) (void)wave_list_slot(&sumg->n_over); // a bucket outgrew its slots: the host reruns the queries
+    if (in_u && u == U - 1) { // the thread holding the last user sits in the last tile, which has seen every granule
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            if (q < nq) {
+                unsigned tmax = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) tmax = max(tmax, s_max[q][w]);
+                const long long m_all = run[q] + cq[q];
+                t.offsets[(long long)(q_lo + q) * us + U] = m_all;
+                Summary* sq = reinterpret_cast<Summary*>(t.span + (long long)(q_lo + q) * t.span_stride + t.summary_off);
+                __hip_atomic_store(&sq->m, (unsigned long long)m_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sq->max_count, max(pmax[q], tmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_total[q] = m_all;
+            }
+        }
+    }
+    if (t.msg && tile == nblk - 1) { // message tails: off[u] = M for the padding users, then the M word
+        __syncthreads();
+        for (int q = 0; q < nq; ++q) {
+            int* msg = t.msg + (long long)(q_lo + q) * t.msg_stride;
+            const long long m_all = s_total[q];
+            for (int uu = U + threadIdx.x; uu <= t.u_pad + 1; uu += BLOCK) msg_store(msg + uu, (int)m_all);
+        }
+    }
+    // completion: the last block hands every query's summary to the host (see offsets_body)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == (unsigned)nblk - 1u && t.host) ? 1 : 0;
+    __syncthreads();
+    if (is_last && threadIdx.x < 64) {
+        unsigned long long live = 0, amb = 0, cand = 0;
+        sum_row_stats(sum0, (int)threadIdx.x, live, amb, &cand);
+        if ((int)threadIdx.x < nq) {
+            const int q = (int)threadIdx.x;
+            Summary* sq = reinterpret_cast<Summary*>(t.span + (long long)(q_lo + q) * t.span_stride + t.summary_off);
+            Summary out;
+            out.m = __hip_atomic_load(&sq->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.n_seg = out.n_big = out.n_small = 0;
+            out.max_count = __hip_atomic_load(&sq->max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.bad_rows = __hip_atomic_load(&sum0->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.q = 0;
+            out.live = 0;
+            out.pad = 0;
+            out.amb = 0;
+            out.n_hot = 0;
+            out.n_over = __hip_atomic_load(&sumg->n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out.cand = cand;
+            t.host[q_lo + q].s = out;
+            __hip_atomic_store(&t.host[q_lo + q].seq, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(kK1Threads) void k_offsets_batch(BatchTailArgs t) { offsets_union_body<QT>(t, (int)blockIdx.x); }
 
 template <int UNROLL, bool NT, class KT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
@@ -2011,12 +2272,12 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
     scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x);
 }
 
-// table pass of batch i+1 with the offsets kernels of batch i in its first blocks (see k_scan_keyed_with_tail)
-template <int UNROLL, bool NT, class KT>
+// table pass of batch i+1 with the offsets kernel of batch i in its first blocks (see k_scan_keyed_with_tail)
+template <int UNROLL, bool NT, class KT, int QT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_batch_with_tail(BatchScanArgs<KT> a, BatchTailArgs t)
 {
-    const int n_tail = t.n_q * t.tiles;
-    if ((int)blockIdx.x < n_tail) batch_tail_body(t, (int)blockIdx.x);
+    const int n_tail = t.tiles * (t.n_q > 8 ? 2 : 1);
+    if ((int)blockIdx.x < n_tail) offsets_union_body<QT>(t, (int)blockIdx.x);
     else scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x - n_tail);
 }
 

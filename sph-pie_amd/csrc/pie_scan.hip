@@ -106,7 +106,7 @@ struct BatchSlot {
     char* zero_span = nullptr;         // the set its K2 zeroes
     int* counts_ord = nullptr;         // [kBatchMax][users_stride]
     long long* offsets = nullptr;      // [kBatchMax][users_stride]
-    BktRec* direct = nullptr;          // [kBatchMax][cap_users << 4]
+    BktRec* direct = nullptr;          // union bucket slots: [cap_users << bdshift]; BktRec::pad = the queries that selected the row
     int* out_idx = nullptr;            // [kBatchMax][out_stride]
     HostSummary* h_sum = nullptr;      // [kBatchMax] mapped pinned
     HostSummary* h_sum_dev = nullptr;
@@ -198,6 +198,8 @@ struct pie_ctx {
     int b_flight = 0;           // batches begun and not finished (0..2)
     BatchSlot* bres = nullptr;  // last finished batch
     bool batch_alloc = false;
+    int bdshift = 4;            // log2 of the union bucket capacity of the batched pass (16 .. 64 slots per user)
+    int bdshift_want = 4;       // capacity the last finished batch asked for (applied at the next begin with nothing in flight)
     bool last_was_batch = false; // pie_stats_get describes the last finished batch rather than the last single scan
     unsigned long long bseq_counter = 0;
     char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
@@ -1199,7 +1201,7 @@ int ensure_batch(pie_ctx* c, bool full)
     }
     if (!full || c->batch_alloc) return PIE_OK;
     for (BatchSlot& b : c->bslot) {
-        PIE_HIP(c, hipMalloc(&b.direct, (size_t)kBatchMax * ((size_t)c->cap_users << 4) * sizeof(BktRec)));
+        PIE_HIP(c, hipMalloc(&b.direct, ((size_t)c->cap_users << c->bdshift) * sizeof(BktRec)));
         PIE_HIP(c, hipMalloc(&b.out_idx, (size_t)kBatchMax * (os > 0 ? os : 1) * 4));
     }
     for (char*& sp : c->bspan) {
@@ -1222,21 +1224,19 @@ void fill_tail_args(pie_ctx* c, BatchSlot& b, BatchTailArgs& t)
     t.n_q = b.n_q;
     t.n_users = c->n_users;
     t.tiles = (c->n_users + kK1Threads - 1) / kK1Threads;
+    t.dshift = c->bdshift;
     t.span = b.span;
     t.span_stride = (long long)counts_span(c);
     t.tiles_off = (long long)span_counts_bytes(c);
     t.ctl_off = (long long)(span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes());
     t.summary_off = t.ctl_off + 128;
-    // the whole next-but-one span set (all kBatchMax spans, whatever the batch sizes) is zeroed by this batch's n_q tile
-    // groups: group q takes the q-th share, cut at span boundaries' 16-byte vectors
+    // the whole next-but-one span set (all kBatchMax spans, whatever the batch sizes) is zeroed by this batch's tail
     t.zero_span = b.zero_span;
-    const long long total16 = (long long)kBatchMax * (long long)(counts_span(c) / 16);
-    t.zero_vec16 = (total16 + b.n_q - 1) / b.n_q; // per group; the kernel clamps the last group (see zero_total16)
+    t.zero_total16 = (long long)kBatchMax * (long long)(counts_span(c) / 16);
     t.counts_ord = b.counts_ord;
     t.offsets = b.offsets;
     t.users_stride = batch_users_stride(c);
     t.direct = b.direct;
-    t.direct_stride = (long long)c->cap_users << 4;
     t.out_idx = b.out_idx;
     t.out_stride = batch_out_stride(c);
     t.host = b.h_sum_dev;
@@ -1247,14 +1247,15 @@ void fill_tail_args(pie_ctx* c, BatchSlot& b, BatchTailArgs& t)
     t.msg_cap = b.msg_cap;
     t.msg_counts = b.msg_counts;
     t.msg_counts_stride = b.msg_counts_stride;
-    t.zero_total16 = total16;
 }
 
 void launch_batch_k2(pie_ctx* c, BatchSlot& b, hipStream_t s)
 {
     BatchTailArgs t;
     fill_tail_args(c, b, t);
-    hipLaunchKernelGGL(k_offsets_batch, dim3((unsigned)(t.n_q * t.tiles)), dim3(kK1Threads), 0, s, t);
+    const unsigned grid = (unsigned)(t.tiles * (t.n_q > 8 ? 2 : 1)); // more than 8 queries: two groups (pie_kernels.h)
+    if (t.n_q <= 4) hipLaunchKernelGGL(k_offsets_batch<4>, dim3(grid), dim3(kK1Threads), 0, s, t);
+    else hipLaunchKernelGGL(k_offsets_batch<8>, dim3(grid), dim3(kK1Threads), 0, s, t);
     b.k2_pending = false;
 }
 
@@ -1286,6 +1287,25 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         c->b_flight++;
         c->b_next ^= 1;
         return PIE_OK;
+    }
+    if (c->bdshift_want > c->bdshift && c->b_flight == 0 && c->batch_alloc) {
+        // larger union buckets for every user (a finished batch found one that outgrew its slots): both slots' arrays are
+        // replaced; their contents are per-batch scratch
+        int rc0 = sync_all(c);
+        if (rc0) return rc0;
+        BktRec* fresh[2] = {nullptr, nullptr};
+        const size_t bytes = ((size_t)c->cap_users << c->bdshift_want) * sizeof(BktRec);
+        if (bytes <= kDirectMaxBytes && hipMalloc(&fresh[0], bytes) == hipSuccess && hipMalloc(&fresh[1], bytes) == hipSuccess) {
+            for (int k = 0; k < 2; ++k) {
+                (void)hipFree(c->bslot[k].direct);
+                c->bslot[k].direct = fresh[k];
+            }
+            c->bdshift = c->bdshift_want;
+        } else {
+            (void)hipGetLastError();
+            if (fresh[0]) (void)hipFree(fresh[0]);
+            c->bdshift_want = c->bdshift;
+        }
     }
     int rc = ensure_batch(c, true);
     if (rc) return rc;
@@ -1336,13 +1356,17 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     const bool ride = c->b_flight == 1 && other.in_flight && other.k2_pending && !c->no_ride;
     if (c->b_flight == 1 && other.in_flight && other.k2_pending && !ride) launch_batch_k2(c, other, s);
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
+#define PIE_BATCH_RIDE(KT, QT)                                                                                          \
+    hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT, QT>), dim3((unsigned)(b.k1_blocks + t.tiles * (t.n_q > 8 ? 2 : 1))), \
+                       dim3(kK1Threads), 0, s, a, t)
 #define PIE_BATCH(KT, KEYPTR, KEYFN, IMPOSSIBLE)                                                                         \
     do {                                                                                                                \
         BatchScanArgs<KT> a;                                                                                            \
         a.pay = c->d_pay; a.end = c->d_end; a.key = KEYPTR; a.n = c->n; a.rows_per_block = c->plan_rows[plan];          \
-        a.n_users = c->n_users; a.n_q = n_q; a.span = b.span; a.span_stride = (long long)counts_span(c);                \
-        a.summary_off = (long long)(span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128);             \
-        a.direct = b.direct; a.direct_stride = (long long)c->cap_users << 4;                                            \
+        a.n_users = c->n_users; a.n_q = n_q; a.dshift = c->bdshift;                                                     \
+        a.counts = reinterpret_cast<int*>(b.span);                                                                      \
+        a.summary = reinterpret_cast<Summary*>(b.span + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128); \
+        a.direct = b.direct;                                                                                            \
         unsigned mk = IMPOSSIBLE;                                                                                       \
         for (int q = 0; q < n_q; ++q) {                                                                                 \
             a.q[q].now = qs[q].now; a.q[q].cutoff = qs[q].cutoff; a.q[q].pad = 0;                                       \
@@ -1354,8 +1378,8 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         if (ride) {                                                                                                     \
             BatchTailArgs t;                                                                                            \
             fill_tail_args(c, other, t);                                                                                \
-            hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT>), dim3((unsigned)(b.k1_blocks + t.n_q * t.tiles)),  \
-                               dim3(kK1Threads), 0, s, a, t);                                                           \
+            if (t.n_q <= 4) PIE_BATCH_RIDE(KT, 4);                                                                      \
+            else PIE_BATCH_RIDE(KT, 8);                                                                                 \
             other.k2_pending = false;                                                                                   \
         } else {                                                                                                        \
             hipLaunchKernelGGL((k_scan_batch<8, true, KT>), dim3((unsigned)b.k1_blocks), dim3(kK1Threads), 0, s, a);    \
@@ -1365,6 +1389,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     if (fine) PIE_BATCH(fkey_t, c->d_fkey, host_fine_key_of, 0xFFu);
     else PIE_BATCH(lkey_t, c->d_key, host_key_of, 0xFFFFu);
 #undef PIE_BATCH
+#undef PIE_BATCH_RIDE
     PIE_HIP(c, hipGetLastError());
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e1, s));
     (void)n_batched;
@@ -1455,9 +1480,18 @@ int batch_finish(pie_ctx* c, int* ready_out)
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         for (int q = 0; q < b.n_q; ++q) {
             b.last[q] = b.h_sum[q].s;
-            if (b.last[q].n_over > 0 || b.last[q].bad_rows > 0) b.fallback[q] = true;
+            // a union bucket outgrew its slots (or a row list its capacity): rows were dropped, and nothing says which
+            // queries they belonged to, so every query of the batch is rerun on the general path
+            if (b.last[q].n_over > 0 || b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
             b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
         }
+        if (b.n_q > 8 && b.last[8].n_over > 0) { // the second query group found the overflow: it holds for the whole batch
+            for (int q = 0; q < b.n_q; ++q) b.fallback[q] = true;
+        }
+        if (b.n_q > 8 && b.last[0].n_over > 0) {
+            for (int q = 8; q < b.n_q; ++q) b.fallback[q] = true;
+        }
+        if ((b.last[0].n_over > 0 || (b.n_q > 8 && b.last[8].n_over > 0)) && c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
     }
     b.in_flight = false;

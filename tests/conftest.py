@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch ships its own copy of the HIP runtime.  In a process that uses both, torch must be imported BEFORE libpie_hip.so
+# initialises HIP (the other order leaves torch with "No HIP GPUs are available" on this image); the tests that pass torch
+# tensors to the C ABI rely on this import, whatever subset of the test files is collected.
+try:
+    import torch  # noqa: F401
+except Exception:  # torch is only needed by the exchange-step tests
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
