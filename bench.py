@@ -213,7 +213,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sph_pie_amd as pie
-    from sph_pie_amd.shard import HipShardBackend, ShardedFeeds
+    from sph_pie_amd.shard import BatchedFeeds, HipShardBackend, ShardedFeeds
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the scan path has no CPU fallback")
@@ -271,6 +271,7 @@ def main():
     # the batch: Q requests that arrived within a few seconds of each other — each samples its own clock (sessionStore.js:67),
     # same day's cutoff, same role mask; query 0 is the single-query workload
     batch_queries = [(now - 977 * q, cutoff, mask) for q in range(Q)]
+    bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather) if gather and Q > 1 else None
 
     def run_steps(k):
         """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1."""
@@ -287,6 +288,11 @@ def main():
                     last = ctx.scan_device(now, cutoff)
                 return last
             return ctx.scan_pipelined(k, now, cutoff)
+        if bfeeds is not None:
+            last = bfeeds.run_steps(k, batch_queries)
+            if last is None:  # a row list outgrew the messages: capacity was raised, once more
+                last = bfeeds.run_steps(1, batch_queries)
+            return last
         last = feeds.run_steps(k, now, cutoff)
         if last is None:  # a row list outgrew the message: capacity was raised, redo synchronously once
             last = feeds.scan_and_gather(now, cutoff)
@@ -336,7 +342,9 @@ def main():
     if Q > 1 and not gather and args.mode == "scan":
         batch_ms = list(last)
         last = batch_ms[0]
-    m = last if not gather else int(last["lengths"][rank])
+    elif Q > 1 and gather and args.mode == "scan":
+        batch_ms = [int(x) for x in last["lengths"][rank]]
+    m = batch_ms[0] if (batch_ms is not None and gather) else (last if not gather else int(last["lengths"][rank]))
     ms_per_step = statistics.median(region_ms)
     k1_ms = statistics.median(kernel_ms_regions) if kernel_ms_regions else 0.0
 
@@ -344,11 +352,22 @@ def main():
     gather_ok = None
     if gather and args.mode == "scan":
         # the gathered lists of this rank (as every rank received them) against this rank's own result of the same query
-        ctx.scan_device(now, cutoff)
-        _, own_off, own_idx = ctx.read_results()
-        ok = int(last["lengths"][rank]) == own_idx.size and \
-            np.array_equal(last["offsets"][rank].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
-            np.array_equal(last["rows"][rank].cpu().numpy()[: own_idx.size], own_idx)
+        if bfeeds is not None:
+            ok = True
+            for q, (qn, qc, qm) in enumerate(batch_queries):
+                ctx.set_disciplines(qm, D)
+                ctx.scan_device(qn, qc)
+                _, own_off, own_idx = ctx.read_results()
+                ok = ok and int(last["lengths"][rank, q]) == own_idx.size and \
+                    np.array_equal(last["offsets"][rank, q].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
+                    np.array_equal(last["rows"][rank, q].cpu().numpy()[: own_idx.size], own_idx)
+            ctx.set_disciplines(mask, D)
+        else:
+            ctx.scan_device(now, cutoff)
+            _, own_off, own_idx = ctx.read_results()
+            ok = int(last["lengths"][rank]) == own_idx.size and \
+                np.array_equal(last["offsets"][rank].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
+                np.array_equal(last["rows"][rank].cpu().numpy()[: own_idx.size], own_idx)
         t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         gather_ok = bool(int(t_ok.item()))
@@ -356,7 +375,8 @@ def main():
             log("WARNING: rank %d: gathered lists differ from the local result" % rank)
         # scan-only throughput beside scan + gather — the same K steps without the exchange, after the
         # timed regions (not part of value); max over ranks like the headline
-        so = [timed_region(lambda k: ctx.scan_pipelined(k, now, cutoff), args.steps)[0] * 1e3 / args.steps for _ in range(3)]
+        scan_only = (lambda k: ctx.scan_batch_pipelined(k, batch_queries)) if Q > 1 else (lambda k: ctx.scan_pipelined(k, now, cutoff))
+        so = [timed_region(scan_only, args.steps)[0] * 1e3 / args.steps for _ in range(3)]
         scan_only_ms = spread(so)
 
     # totals over the ranks (strong scaling: every rank holds a different number of rows / users)
@@ -372,7 +392,7 @@ def main():
         rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
         kname = kernel_name(variant, rides, args.mode)
         if batch_ms is not None:
-            kname = "k_scan_batch_with_tail<8, true, %s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
+            kname = "k_scan_batch_with_tail<8, true, %s, %d>" % ("unsigned char" if variant & 0x800 else "unsigned short", 4 if Q <= 4 else 8)
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local
@@ -418,7 +438,7 @@ def main():
                 "sessions_total": tot_rows, "users_total": tot_users, "sessions_rank0": n_local, "users_rank0": u_local,
                 "disciplines": D, "selected_rows_rank0": int(m), "selected_rows_per_query": batch_ms,
                 "parallelism": "user-hash shards x%d (device-side partition of one corpus), RCCL all-gather of per-user offsets + row "
-                               "lists (%d scans per collective), overlapped with the next scans" % (world, args.gather_batch) if world > 1 else "single GPU",
+                               "lists (%d queries per collective), overlapped with the next scans" % (world, Q if Q > 1 else args.gather_batch) if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant),

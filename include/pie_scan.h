@@ -246,6 +246,13 @@ int pie_stats_reset(pie_ctx *ctx);
 int pie_synchronize(pie_ctx *ctx);
 /* user-hash sharding rule: shard = splitmix64(user) mod n_shards.  Pure host function. */
 int32_t pie_shard_of(int32_t user, int32_t n_shards);
+/* Shard the RESIDENT table on the device: keep only the rows whose user hashes to `rank` of `world` (pie_shard_of), in table
+ * order, users re-numbered densely in ascending global id (a shard with no user keeps n_users = 1).  Every rank loads or
+ * generates the same whole table and calls this with its own rank; nothing crosses PCIe.  *n_rows_out / *n_users_out = the
+ * shard's size.  pie_shard_maps copies the maps back: rows_global_out[i] = the global row of local row i (n_rows),
+ * users_global_out[k] = the global id of local user k (n_users); either may be NULL. */
+int pie_shard_table(pie_ctx *ctx, int32_t rank, int32_t world, size_t *n_rows_out, int32_t *n_users_out);
+int pie_shard_maps(pie_ctx *ctx, int32_t *rows_global_out, int32_t *users_global_out);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,8 @@ _SIGS = [
     ("pie_stats_reset", C.c_int, [_P]),
     ("pie_synchronize", C.c_int, [_P]),
     ("pie_shard_of", C.c_int32, [C.c_int32, C.c_int32]),
+    ("pie_shard_table", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
+    ("pie_shard_maps", C.c_int, [_P, _P, _P]),
 ]
 ABI_SYMBOLS = [s[0] for s in _SIGS]
 
@@ -460,6 +462,21 @@ class PieScan:
         out = np.empty(max(self.n, 1), np.int32)
         self._check(self._lib.pie_archive_queue(self._ctx, int(now), int(window_ms), _ptr(out), self.n, C.byref(q)))
         return out[: q.value].copy()
+
+    # ---- sharding on the device
+    def shard_table(self, rank, world):
+        """Keep only the rows of the users that hash to `rank` of `world`, users re-numbered densely.  -> (n_rows, n_users)"""
+        n, u = C.c_size_t(0), C.c_int32(0)
+        self._check(self._lib.pie_shard_table(self._ctx, int(rank), int(world), C.byref(n), C.byref(u)))
+        self.n, self.n_users = int(n.value), int(u.value)
+        return self.n, self.n_users
+
+    def shard_maps(self, n_users_real=None):
+        """-> (rows_global[n] int32, users_global[k] int32): local row -> global row, local user -> global user."""
+        rows = np.empty(max(self.n, 1), np.int32)
+        users = np.full(max(self.n_users, 1), -1, np.int32)
+        self._check(self._lib.pie_shard_maps(self._ctx, _ptr(rows), _ptr(users)))
+        return rows[: self.n], users
 
     # ---- measurement / plumbing
     def set_stream(self, hip_stream):

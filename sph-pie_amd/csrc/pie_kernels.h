@@ -2837,6 +2837,92 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ user-hash sharding on the device
+//
+// rows are partitioned by gpu = splitmix64(user) mod G (pie_shard_of; the same function in the oracle).
+// A rank that holds the whole table keeps the rows of its own users, in table order, with the users re-numbered densely
+// in ascending global id — all on the device: user flags -> prefix (= the local ids), per-block row counts -> prefix ->
+// order-preserving compaction of the four columns.  The maps back (local row -> global row, local user -> global user)
+// stay on the device for pie_shard_maps.
+__device__ __forceinline__ int shard_of_user(int user, int n_shards)
+{
+    unsigned long long z = (unsigned long long)(unsigned int)user + 0x9E3779B97F4A7C15ULL;
+    return (int)(mix64(z) % (unsigned long long)n_shards);
+}
+
+__global__ __launch_bounds__(256) void k_shard_user_flags(int n_users, int rank, int world, int* __restrict__ flag)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u < n_users) flag[u] = shard_of_user(u, world) == rank ? 1 : 0;
+}
+
+// local_of_global[u] = dense local id (exclusive prefix of the flags) or -1; users_global[local id] = u
+__global__ __launch_bounds__(256) void k_shard_user_ids(int n_users, const int* __restrict__ flag, const long long* __restrict__ off,
+                                                        int* __restrict__ local_of_global, int* __restrict__ users_global)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const int l = (int)off[u];
+    local_of_global[u] = flag[u] ? l : -1;
+    if (flag[u]) users_global[l] = u;
+}
+
+__global__ __launch_bounds__(256) void k_shard_row_count(const int* __restrict__ user, long long n, long long rows_per_block,
+                                                         const int* __restrict__ local_of_global, int n_users, int* __restrict__ blk_count)
+{
+    __shared__ long long lds4[4];
+    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    const long long c1 = min(n, c0 + rows_per_block);
+    long long local = 0;
+    for (long long r = c0 + threadIdx.x; r < c1; r += blockDim.x) {
+        const int u = user[r];
+        local += ((unsigned)u < (unsigned)n_users && local_of_global[u] >= 0) ? 1 : 0;
+    }
+    local = block_sum_256(local, lds4);
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = (int)local;
+}
+
+__global__ __launch_bounds__(256) void k_shard_row_write(const long long* __restrict__ start, const long long* __restrict__ end,
+                                                         const int* __restrict__ user, const int* __restrict__ disc, long long n,
+                                                         long long rows_per_block, const int* __restrict__ local_of_global, int n_users,
+                                                         const long long* __restrict__ blk_off, long long* __restrict__ o_start,
+                                                         long long* __restrict__ o_end, int* __restrict__ o_user, int* __restrict__ o_disc,
+                                                         int* __restrict__ o_row)
+{
+    __shared__ int wcount[4];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    const long long c1 = min(n, c0 + rows_per_block);
+    if (threadIdx.x == 0) carry_s = blk_off[blockIdx.x];
+    __syncthreads();
+    for (long long r0 = c0; r0 < c1; r0 += blockDim.x) {
+        const long long r = r0 + threadIdx.x;
+        int lu = -1;
+        if (r < c1) {
+            const int u = user[r];
+            if ((unsigned)u < (unsigned)n_users) lu = local_of_global[u];
+        }
+        const bool hit = lu >= 0;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        long long base = carry_s;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        const long long pos = base + prefix_in_ballot(bal);
+        if (hit) {
+            o_start[pos] = start[r];
+            o_end[pos] = end[r];
+            o_user[pos] = lu;
+            o_disc[pos] = disc[r];
+            o_row[pos] = (int)r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+}
+
 // exclusive prefix over blk[0..nb) by ONE block of 1024 threads in a single sweep: thread t owns the contiguous
 // chunk [t*per, (t+1)*per), so 16 K wave counts cost one block-wide scan instead of 64 of them
 __global__ __launch_bounds__(1024) void k_block_prefix_wide(const int* __restrict__ blk, int nb, long long* __restrict__ off,

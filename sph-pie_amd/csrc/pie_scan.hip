@@ -164,6 +164,10 @@ struct pie_ctx {
     bool no_fused_order = false; // PIE_FUSED_ORDER=0: K2 and the tiny-bucket order as two kernels (A/B runs)
     int k1_keyed = 0xC85;       // keyed liveness-first form (bit 0x400; 0x800: the 1-byte fine key where the query allows), unroll 8
     long long* d_range = nullptr;
+    int* d_shard_rows = nullptr;   // pie_shard_table: local row -> global row
+    int* d_shard_users = nullptr;  // ... local user -> global user
+    long long shard_rows_n = 0;
+    int shard_users_n = 0;
 
     // predicate table
     unsigned long long disc_mask = ~0ull;
@@ -1590,6 +1594,8 @@ int pie_ctx_destroy(pie_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_table(c);
+    dfree(c->d_shard_rows);
+    dfree(c->d_shard_users);
     for (auto& e : c->ring) {
         (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2);
     }
@@ -2431,6 +2437,110 @@ int pie_synchronize(pie_ctx* c)
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
     return sync_all(c);
+}
+
+int pie_shard_table(pie_ctx* c, int32_t rank, int32_t world, size_t* n_rows_out, int32_t* n_users_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, PIE_E_INVAL, "rank %d outside [0, %d)", rank, world);
+    if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = sync_all(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const long long n = c->n;
+    const int U = c->n_users;
+    int *d_flag = nullptr, *d_local = nullptr, *d_users = nullptr, *d_blk = nullptr, *o_user = nullptr, *o_disc = nullptr, *o_row = nullptr;
+    long long *d_uoff = nullptr, *d_boff = nullptr, *o_start = nullptr, *o_end = nullptr;
+    auto cleanup = [&]() {
+        dfree(d_flag); dfree(d_local); dfree(d_blk); dfree(d_uoff); dfree(d_boff);
+        dfree(o_start); dfree(o_end); dfree(o_user); dfree(o_disc);
+    };
+#define PIE_TRY(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            cleanup();                                                                                \
+            dfree(d_users);                                                                           \
+            dfree(o_row);                                                                             \
+            return fail(c, e_ == hipErrorOutOfMemory ? PIE_E_NOMEM : PIE_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                             \
+    } while (0)
+    // 1. which users stay, and their local ids
+    const unsigned ub = (unsigned)((U + 255) / 256);
+    PIE_TRY(hipMalloc(&d_flag, (size_t)U * 4));
+    PIE_TRY(hipMalloc(&d_local, (size_t)U * 4));
+    PIE_TRY(hipMalloc(&d_users, (size_t)U * 4));
+    PIE_TRY(hipMalloc(&d_uoff, ((size_t)U + 1) * 8));
+    hipLaunchKernelGGL(k_shard_user_flags, dim3(ub), dim3(256), 0, s, U, (int)rank, (int)world, d_flag);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, d_flag, U, d_uoff, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_shard_user_ids, dim3(ub), dim3(256), 0, s, U, d_flag, d_uoff, d_local, d_users);
+    PIE_TRY(hipGetLastError());
+    long long u_local = 0;
+    PIE_TRY(hipMemcpyAsync(&u_local, d_uoff + U, 8, hipMemcpyDeviceToHost, s));
+    // 2. rows: per-block counts -> prefix -> order-preserving compaction into fresh columns
+    const long long rpb = 256LL * 64;
+    const int blocks = (int)((n + rpb - 1) / rpb) > 0 ? (int)((n + rpb - 1) / rpb) : 1;
+    PIE_TRY(hipMalloc(&d_blk, (size_t)blocks * 4));
+    PIE_TRY(hipMalloc(&d_boff, ((size_t)blocks + 1) * 8));
+    hipLaunchKernelGGL(k_shard_row_count, dim3(blocks), dim3(256), 0, s, c->d_user, n, rpb, d_local, U, d_blk);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, d_blk, blocks, d_boff, (unsigned long long*)nullptr);
+    PIE_TRY(hipGetLastError());
+    long long n_local = 0;
+    PIE_TRY(hipMemcpyAsync(&n_local, d_boff + blocks, 8, hipMemcpyDeviceToHost, s));
+    PIE_TRY(hipStreamSynchronize(s));
+    const size_t rows = (size_t)(n_local > 0 ? n_local : 1);
+    PIE_TRY(hipMalloc(&o_start, rows * 8));
+    PIE_TRY(hipMalloc(&o_end, rows * 8));
+    PIE_TRY(hipMalloc(&o_user, rows * 4));
+    PIE_TRY(hipMalloc(&o_disc, rows * 4));
+    PIE_TRY(hipMalloc(&o_row, rows * 4));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_shard_row_write, dim3(blocks), dim3(256), 0, s, c->d_start, c->d_end, c->d_user, c->d_disc, n, rpb, d_local, U,
+                           d_boff, o_start, o_end, o_user, o_disc, o_row);
+        PIE_TRY(hipGetLastError());
+        PIE_TRY(hipStreamSynchronize(s));
+    }
+    // 3. a right-sized table takes the shard (the whole-table buffers and their workspace are released first)
+    free_table(c);
+    const int users_new = u_local > 0 ? (int)u_local : 1;
+    rc = ensure_capacity(c, n_local, users_new);
+    if (rc) { cleanup(); dfree(d_users); dfree(o_row); return rc; }
+    if (n_local > 0) {
+        PIE_TRY(hipMemcpyAsync(c->d_start, o_start, (size_t)n_local * 8, hipMemcpyDeviceToDevice, s));
+        PIE_TRY(hipMemcpyAsync(c->d_end, o_end, (size_t)n_local * 8, hipMemcpyDeviceToDevice, s));
+        PIE_TRY(hipMemcpyAsync(c->d_user, o_user, (size_t)n_local * 4, hipMemcpyDeviceToDevice, s));
+        PIE_TRY(hipMemcpyAsync(c->d_disc, o_disc, (size_t)n_local * 4, hipMemcpyDeviceToDevice, s));
+        PIE_TRY(hipStreamSynchronize(s));
+    }
+#undef PIE_TRY
+    cleanup();
+    dfree(c->d_shard_rows);
+    dfree(c->d_shard_users);
+    c->d_shard_rows = o_row;
+    c->d_shard_users = d_users;
+    c->shard_rows_n = n_local;
+    c->shard_users_n = (int)u_local;
+    if (n_rows_out) *n_rows_out = (size_t)n_local;
+    if (n_users_out) *n_users_out = users_new;
+    rc = build_keys(c, 0);
+    if (rc) return rc;
+    PIE_HIP(c, hipStreamSynchronize(s));
+    return PIE_OK;
+}
+
+int pie_shard_maps(pie_ctx* c, int32_t* rows_global_out, int32_t* users_global_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->d_shard_rows || !c->d_shard_users) return fail(c, PIE_E_STATE, "pie_shard_maps without pie_shard_table");
+    PIE_HIP(c, hipSetDevice(c->device));
+    if (rows_global_out && c->shard_rows_n)
+        PIE_HIP(c, hipMemcpyAsync(rows_global_out, c->d_shard_rows, (size_t)c->shard_rows_n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (users_global_out && c->shard_users_n)
+        PIE_HIP(c, hipMemcpyAsync(users_global_out, c->d_shard_users, (size_t)c->shard_users_n * 4, hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
 }
 
 int32_t pie_shard_of(int32_t user, int32_t n_shards)

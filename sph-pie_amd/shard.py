@@ -65,6 +65,17 @@ class HipShardBackend:
         self.ctx.pack_results_device(dst.data_ptr(), u_pad, cap)
         return m, False
 
+    # batched scans: Q queries, one table pass, Q messages back to back in dst (stride words each)
+    def batch_begin(self, queries, dst=None, stride=0, u_pad=0, cap=0):
+        if dst is None:
+            self.ctx.scan_batch_begin(queries)
+        else:
+            self.ctx.scan_batch_begin_packed(queries, dst.data_ptr(), stride, u_pad, cap)
+
+    def batch_finish(self):
+        """-> ([M per query], ready)"""
+        return self.ctx.scan_batch_finish(packed=True)
+
 
 N_SETS = 4
 
@@ -383,6 +394,137 @@ def _run_steps_batched(self, k, now, cutoff):
 
 
 ShardedFeeds._run_steps_batched = _run_steps_batched
+
+
+class BatchedFeeds:
+    """Per-rank driver of the BATCHED exchange: every step is one batched scan of Q queries over the local shard (one table
+    pass, pie_scan_batch_*), whose offsets kernel writes the Q result messages back to back, and ONE all-gather moves them
+    all — the "fewer, larger collectives" of a point-to-point fabric come with the batch.  Same pipeline as
+    ShardedFeeds.run_steps: begin(i+1) | gather(i-1) issued on the side stream | gather(i-2) collected | finish(i); four
+    rotating buffer sets.
+
+    backend.batch_begin(queries[, dst, stride, u_pad, cap]) / backend.batch_finish() -> ([M], ready)."""
+
+    def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False):
+        self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self.q_max = int(q_max)
+        self.collective = world > 1 or always_collective
+        self.device = torch.device(getattr(backend, "device", "cpu"))
+        self.cuda = self.device.type == "cuda"
+        self.n_users_local = int(n_users_local)
+        self.u_pad = self._all_max(self.n_users_local)
+        self.cap = cap
+        self.sets = None
+        if self.cuda:
+            self.comm_stream = torch.cuda.Stream(self.device)
+            self.rs = getattr(backend, "result_stream", None) or torch.cuda.current_stream(self.device)
+
+    def _all_max(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        if self.collective:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _sets(self):
+        if self.sets is None or self.sets["cap"] != self.cap:
+            L = self.u_pad + 2 + self.cap
+            Q, W = self.q_max, self.world
+            self.sets = {
+                "cap": self.cap, "L": L,
+                "msg": [torch.zeros(Q * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
+                "out": [torch.zeros(W * Q * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
+                "len_host": [torch.zeros(W, Q, dtype=torch.int32, pin_memory=self.cuda) for _ in range(N_SETS)],
+            }
+            self.sets["len_dev"] = [o.view(W, Q, L)[:, :, self.u_pad + 1] for o in self.sets["out"]]
+            if self.cuda:
+                self.sets["ev_packed"] = [torch.cuda.Event() for _ in range(N_SETS)]
+                self.sets["ev_done"] = [torch.cuda.Event() for _ in range(N_SETS)]
+                torch.cuda.current_stream(self.device).synchronize()
+        return self.sets
+
+    def _negotiate(self, queries):
+        """First use: one batch without messages learns the largest row list; every rank agrees on the capacity."""
+        self.backend.batch_begin(queries)
+        ms, _ = self.backend.batch_finish()
+        self.cap = ShardedFeeds._grow(self._all_max(max(ms) if ms else 0))
+
+    def _issue(self, st, p, ready):
+        if not self.collective:
+            if self.cuda and not ready:
+                torch.cuda.current_stream(self.device).wait_event(st["ev_packed"][p])
+            st["out"][p].copy_(st["msg"][p])
+            return
+        if self.cuda:
+            prev = torch.cuda.current_stream(self.device)
+            torch.cuda.set_stream(self.comm_stream)
+            try:
+                if not ready:
+                    self.comm_stream.wait_event(st["ev_packed"][p])
+                dist.all_gather_into_tensor(st["out"][p], st["msg"][p], group=self.group)
+                st["len_host"][p].copy_(st["len_dev"][p], non_blocking=True)
+                st["ev_done"][p].record(self.comm_stream)
+            finally:
+                torch.cuda.set_stream(prev)
+        else:
+            dist.all_gather_into_tensor(st["out"][p], st["msg"][p], group=self.group)
+
+    def _collect(self, st, p, nq):
+        if self.cuda and self.collective:
+            st["ev_done"][p].synchronize()
+        else:
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()
+            st["len_host"][p].copy_(st["len_dev"][p])
+        need = int(st["len_host"][p][:, :nq].max())
+        if need > st["cap"]:
+            self.cap = max(self.cap, ShardedFeeds._grow(need))
+            return None
+        g = st["out"][p].view(self.world, self.q_max, st["L"])
+        return {"offsets": g[:, :nq, : self.u_pad + 1], "lengths": st["len_host"][p][:, :nq].clone(), "rows": g[:, :nq, self.u_pad + 2:]}
+
+    def run_steps(self, k, queries):
+        """k steps of the same batch of queries, software-pipelined.  -> last collected result: offsets [world, Q, U_pad+1],
+        lengths [world, Q], rows [world, Q, cap]; Feed(r, q, u) = rows[r, q, offsets[r,q,u] : offsets[r,q,u+1]].  None when a
+        row list outgrew the capacity (raised: call again)."""
+        if k <= 0:
+            return None
+        nq = len(queries)
+        if nq > self.q_max:
+            raise ValueError("batch of %d queries exceeds q_max %d" % (nq, self.q_max))
+        if self.cap is None:
+            self._negotiate(queries)
+        st = self._sets()
+        L, cap = st["L"], st["cap"]
+        overflow, last = False, None
+        finished, flying = None, None   # (set, ready)
+
+        def begin(i):
+            self.backend.batch_begin(queries, st["msg"][i % N_SETS], L, self.u_pad, cap)
+
+        begin(0)
+        for i in range(k):
+            if i + 1 < k:
+                begin(i + 1)
+            if finished is not None:
+                self._issue(st, *finished)
+            if flying is not None:
+                res = self._collect(st, flying[0], nq)
+                overflow = overflow or res is None
+                last = res if res is not None else last
+            flying, finished = finished, None
+            _, ready = self.backend.batch_finish()
+            p = i % N_SETS
+            if self.cuda and not ready:
+                st["ev_packed"][p].record(self.rs)
+            finished = (p, ready)
+        if finished is not None:
+            self._issue(st, *finished)
+        for t in (flying, finished):
+            if t is not None:
+                res = self._collect(st, t[0], nq)
+                overflow = overflow or res is None
+                last = res if res is not None else last
+        return None if overflow else last
 
 
 def gather_expired_queues(local_queue, local_to_global_rows, rank, world, device="cpu", group=None):

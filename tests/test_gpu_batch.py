@@ -216,3 +216,82 @@ def test_batch_cfg2_exact(gpu_ctx, oracle):
     got = gpu_ctx.scan_batch(qs)
     for k, (g, w) in enumerate(zip(got, oracle_answers(oracle, cols, U, D, qs))):
         assert_same(g, w, "query %d" % k)
+
+
+def test_device_sharding_equals_the_host_partition(pie, oracle):
+    """pie_shard_table: the whole table sharded on the device by pie_shard_of — rows kept in table order, users re-numbered
+    densely — equals the numpy partition of shard.partition_by_user_hash for every rank of worlds 1, 2, 3 and 8, maps back
+    included; the shards' scans reassemble the oracle's scan of the whole table."""
+    from sph_pie_amd.shard import partition_by_user_hash
+    n, U, D = 700001, 2311, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    now, cutoff, mask = oracle.T0_MS - 6 * HOUR, oracle.T0_MS - 61 * DAY, 0x5555555555555555
+    wc, wo, wi = oracle.scan(*cols, U, now, cutoff, mask & 0xFFFFFFFF)
+    with pie.PieScan(0) as ctx:
+        for world in (1, 2, 3, 8):
+            shards = partition_by_user_hash(*cols, U, world)
+            got_counts = np.zeros(U, np.int32)
+            for rank in range(world):
+                ctx.gen_synthetic(SEED, n, 0, n, U, D, 0)
+                n_loc, u_loc = ctx.shard_table(rank, world)
+                sh = shards[rank]
+                assert n_loc == sh["rows"].size and u_loc == sh["n_users"]
+                s, e, u, d = ctx.read_columns()
+                assert np.array_equal(s, sh["start"]) and np.array_equal(e, sh["end"])
+                assert np.array_equal(u, sh["user"]) and np.array_equal(d, sh["disc"])
+                rows_g, users_g = ctx.shard_maps()
+                assert np.array_equal(rows_g.astype(np.int64), sh["rows"])
+                assert np.array_equal(users_g[: sh["users"].size], sh["users"])
+                ctx.set_disciplines(mask, D)
+                c, off, idx = ctx.scan(now, cutoff)
+                for lu, gu in enumerate(sh["users"]):
+                    got_counts[gu] = c[lu]
+                    assert np.array_equal(rows_g[idx[off[lu]:off[lu + 1]]], wi[wo[gu]:wo[gu + 1]])
+            assert np.array_equal(got_counts, wc)
+        # a world with more shards than users: some shards are empty
+        ctx.load_columns(cols[0][:10], cols[1][:10], np.zeros(10, np.int32), cols[3][:10], 1)
+        n_loc, u_loc = ctx.shard_table(1 - pie.shard_of(0, 2), 2)
+        assert n_loc == 0 and u_loc == 1
+        assert ctx.scan(now, cutoff)[2].size == 0
+
+
+def test_exchange_over_rccl_one_rank(pie, oracle):
+    """The exchange step over a real RCCL communicator (backend "nccl", world_size 1 on this one-GPU box): ShardedFeeds
+    (one query per step, also several scans per collective) and BatchedFeeds (Q queries per step) — the gathered offsets
+    and row lists equal the oracle's for every query."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from sph_pie_amd.shard import BatchedFeeds, HipShardBackend, ShardedFeeds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, U, D = 1 << 20, 5000, 32
+        cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+        with pie.PieScan(0) as ctx:
+            ctx.load_columns(*cols, U)
+            ctx.set_disciplines(ALL, D)
+            backend = HipShardBackend(ctx, dev)
+            feeds = ShardedFeeds(backend, 0, 1, U, always_collective=True, batch=4)
+            q1 = (oracle.T0_MS - 6 * HOUR, INT64_MIN)
+            want = oracle.scan(*cols, U, q1[0], q1[1], 0xFFFFFFFF)
+            for res in (feeds.scan_and_gather(*q1), feeds.run_steps(9, *q1)):
+                assert int(res["lengths"][0]) == want[2].size
+                assert np.array_equal(res["offsets"][0].cpu().numpy(), want[1].astype(np.int32))
+                assert np.array_equal(res["rows"][0].cpu().numpy()[: want[2].size], want[2])
+            queries = mixed_queries(oracle, 7)
+            bf = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True)
+            wants = oracle_answers(oracle, cols, U, D, queries)
+            for k in (1, 5):
+                res = bf.run_steps(k, queries)
+                assert res is not None
+                for q, w in enumerate(wants):
+                    m = w[2].size
+                    assert int(res["lengths"][0, q]) == m
+                    assert np.array_equal(res["offsets"][0, q].cpu().numpy(), w[1].astype(np.int32))
+                    assert np.array_equal(res["rows"][0, q].cpu().numpy()[:m], w[2])
+    finally:
+        dist.destroy_process_group()
