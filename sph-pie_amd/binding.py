@@ -113,7 +113,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or HIP_LIB
+    path = path or os.environ.get("PIE_HIP_LIB") or HIP_LIB   # PIE_HIP_LIB: A/B builds of the same source (tuning runs)
     if not os.path.exists(path):
         raise RuntimeError("%s is missing — build it first: python -c 'import __graft_entry__ as g; g.build()' "
                            "(there is no CPU fallback for the scan path)" % path)

@@ -1943,6 +1943,8 @@ struct BatchTailArgs {
     int n_users;
     int tiles;                 // blocks (256 users each) per query group; a batch of more than 8 queries runs as two groups
                                // of <= 8 (queries 0..7 and 8..), each a complete offsets kernel of its own over the same union
+                               // buckets: 16 queries' worth of per-thread state would halve the occupancy of the launch per query group; a batch of more than 8 queries runs as two groups
+                               // of <= 8 (queries 0..7 and 8..), each a complete offsets kernel of its own over the same union
                                // buckets: 16 queries' worth of per-thread state would halve the occupancy of the launch
     int dshift;
     char* span;                // the batch's span set: span 0 holds the union histogram and the ticket / done words,

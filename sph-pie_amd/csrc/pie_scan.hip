@@ -1489,11 +1489,8 @@ int batch_finish(pie_ctx* c, int* ready_out)
             if (b.last[q].n_over > 0 || b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
             b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
         }
-        if (b.n_q > 8 && b.last[8].n_over > 0) { // the second query group found the overflow: it holds for the whole batch
+        if (b.n_q > 8 && (b.last[8].n_over > 0 || b.last[0].n_over > 0)) { // either query group found the overflow: it holds for the whole batch
             for (int q = 0; q < b.n_q; ++q) b.fallback[q] = true;
-        }
-        if (b.n_q > 8 && b.last[0].n_over > 0) {
-            for (int q = 8; q < b.n_q; ++q) b.fallback[q] = true;
         }
         if ((b.last[0].n_over > 0 || (b.n_q > 8 && b.last[8].n_over > 0)) && c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
