@@ -187,9 +187,10 @@ def main():
     ap.add_argument("--mode", choices=["scan", "expired"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic)")
-    ap.add_argument("--queries-per-launch", type=int, default=1,
-                    help="Q > 1: every step is ONE batched scan of Q queries (Q feed requests with their own `now`, one table pass: "
-                         "pie_scan_batch_*); value counts Q x U feeds per step")
+    ap.add_argument("--queries-per-launch", type=int, default=16,
+                    help="every step is ONE batched scan of Q queries (Q feed requests, each with its own `now`, answered by one table "
+                         "pass: pie_scan_batch_*); value counts Q x U feeds per step; 1 = one query per step (single_query reports that "
+                         "form in every run)")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="scans in flight: 2 = the table pass of step i+1 overlaps the scatter/order tail of step i")
     args = ap.parse_args()
@@ -396,7 +397,7 @@ def main():
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local
-        traffic_doc, traffic_src = pmc_traffic(kname, default_workload)
+        traffic_doc, traffic_src = pmc_traffic(kname, default_workload and (batch_ms is None or Q == 16))
         traffic = traffic_doc["hbm_bytes_per_launch"] if traffic_doc else None
         # byte model from the run's own counters (keyed form): key stream + one 128-B sector per candidate payload record
         # and per ambiguous `end` + one 64-B write per selected row (bucket slot) + K2's outputs
@@ -471,6 +472,44 @@ def main():
         }
 
     gpu_result = None
+    if world == 1 and args.mode == "scan" and not gather and not args.no_extra and Q > 1:
+        # ---- one query per step (the unit SURVEY.md 8d defines: one scan = one query over all N rows), two scans in flight
+        ctx.scan_pipelined(max(args.warmup, 1), now, cutoff)
+        ctx.stats_reset()
+        ctx.set_profiling(profile_every)
+        sq_regions, sq_k1, sq_lat = [], [], []
+        for _ in range(max(args.repeat, 1)):
+            dt, m1 = timed_region(lambda k: ctx.scan_pipelined(k, now, cutoff), args.steps)
+            sq_regions.append(dt * 1e3 / args.steps)
+            s1 = ctx.stats()
+            if s1["n_profiled"]:
+                sq_k1.append(s1["k1_ms_sum"] / s1["n_profiled"])
+                sq_lat.append(s1["scan_ms_sum"] / s1["n_profiled"])
+            ctx.stats_reset()
+        ctx.set_profiling(0)
+        s1 = ctx.stats()
+        v1 = s1["k1_variant"]
+        rides1 = os.environ.get("PIE_K2_RIDE") != "0" and (v1 & ~0x840) == 0x485
+        k1name = kernel_name(v1, rides1, "scan")
+        t1_doc, t1_src = pmc_traffic(k1name, default_workload)
+        kb1 = 1 if v1 & 0x800 else 2
+        model1 = (N * kb1 + s1["candidates"] * 128 + s1["key_ambiguous"] * 128 + int(m1) * 64 + U * 12 + int(m1) * 4) if v1 & 0x400 else None
+        basis1 = t1_doc["hbm_bytes_per_launch"] if t1_doc else model1
+        sq_ms = statistics.median(sq_regions)
+        sq_kms = statistics.median(sq_k1) if sq_k1 else 0.0
+        ach1 = (basis1 / (sq_kms * 1e-3) / 1e9) if basis1 and sq_kms > 0 else None
+        line["single_query"] = {
+            "value": U / (sq_ms * 1e-3), "unit": "feeds/s", "ms_per_step": sq_ms, "ms_per_step_spread": spread(sq_regions),
+            "selected_rows": int(m1),
+            "roofline": {"bound": "hbm", "kernel": k1name, "kernel_variant": hex(v1), "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (ach1 / HBM_PEAK_GBS) if ach1 else None,
+                         "traffic": t1_doc["hbm_bytes_per_launch"] if t1_doc else None, "traffic_source": t1_src, "traffic_model": model1,
+                         "kernel_ms": sq_kms, "kernel_ms_regions": spread(sq_k1) if sq_k1 else None,
+                         "alg_equiv_gbs": (24.0 * N / (sq_kms * 1e-3) / 1e9) if sq_kms > 0 else None,
+                         "scan_latency_ms": statistics.median(sq_lat) if sq_lat else None},
+            "note": "one query per scan, two scans in flight (the r01 headline form); the timed launch is the keyed table pass plus, in its "
+                    "first blocks, the offsets + order kernel of the scan before it",
+        }
     if world == 1 and args.mode == "scan" and not gather and not args.no_extra:
         # ---- the every-byte form of the same query, same table, same run (SURVEY.md 8d's 24 B/row really read)
         ctx.set_scan_form(0x01)

@@ -188,6 +188,9 @@ int pie_scan_batch_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
 int pie_batch_read_results(pie_ctx *ctx, int qi, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                            size_t *m_out);
 int pie_batch_result_device_ptrs(pie_ctx *ctx, int qi, void **counts_dev, void **offsets_dev, void **idx_dev);
+/* One user's feed of query `qi` of the last finished batch (as pie_read_user_feed): the per-request read of a server that
+ * answers the requests of one event-loop turn with one batch. */
+int pie_batch_read_user_feed(pie_ctx *ctx, int qi, int32_t user, int32_t *idx_out, size_t idx_cap, size_t *k_out);
 
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
@@ -253,6 +256,44 @@ int32_t pie_shard_of(int32_t user, int32_t n_shards);
  * users_global_out[k] = the global id of local user k (n_users); either may be NULL. */
 int pie_shard_table(pie_ctx *ctx, int32_t rank, int32_t world, size_t *n_rows_out, int32_t *n_users_out);
 int pie_shard_maps(pie_ctx *ctx, int32_t *rows_global_out, int32_t *users_global_out);
+
+/* ---- communicator: the sharded table behind the C ABI (SURVEY.md 8b "pie_ctx_create(device_ids[], n, ...)", 8e) --------
+ * A pie_comm owns one scan context per GPU and one RCCL communicator; the session table is sharded by user hash
+ * (pie_shard_of) and the cross-user reassembly — every rank receives every rank's per-user offsets and row lists — is an
+ * all-gather done as grouped ncclSend / ncclRecv over the point-to-point xGMI links.  This is what lets a host that is not
+ * Python (the Node addon) use more than one GPU.  RCCL is opened at run time; without it pie_comm_create fails with
+ * PIE_E_NODEVICE.  Two ways to build one:
+ *   pie_comm_create        one process drives all n GPUs of the node (ncclCommInitAll): the Node host;
+ *   pie_comm_create_rank   one process per GPU (ncclCommInitRank): rank 0 makes the 128-byte id with pie_comm_unique_id
+ *                          and hands it to the other ranks by whatever channel the host has. */
+typedef struct pie_comm pie_comm;
+int pie_comm_create(const int32_t *device_ids, int32_t n, pie_comm **comm_out);
+int pie_comm_unique_id(void *id_out_128);
+int pie_comm_create_rank(const void *id_128, int32_t rank, int32_t world, int32_t device_id, pie_comm **comm_out);
+int pie_comm_destroy(pie_comm *comm);
+/* comm may be NULL: the last error of a failed pie_comm_create* on this thread */
+const char *pie_comm_last_error(const pie_comm *comm);
+int32_t pie_comm_world(const pie_comm *comm);
+int32_t pie_comm_local_ranks(const pie_comm *comm);
+/* The scan context of shard `rank` (NULL when that rank lives in another process): load / shard / touch / scan it through
+ * the ordinary entry points.  Owned by the communicator. */
+pie_ctx *pie_comm_ctx(pie_comm *comm, int32_t rank);
+/* Every local shard generates the synthetic corpus on its own GPU and keeps the rows of its users (pie_gen_synthetic +
+ * pie_shard_table): the sharded form of BASELINE.json configs[3]. */
+int pie_comm_gen_synthetic_sharded(pie_comm *comm, uint64_t seed, int64_t n_total, int32_t n_users, int32_t n_disc, uint32_t flags);
+/* One step: every local shard runs ONE batched scan of the n_q queries, whose offsets kernels write the shard's n_q result
+ * messages ([off[0..u_pad] | M | rows], pie_pack_results_device's layout); the messages are exchanged (direct pattern: one
+ * send and one receive per peer inside one ncclGroup); returns when every local rank holds all world x n_q messages.
+ * u_pad: 0 in a single-process communicator (the largest shard's user count is used); in a process-per-GPU communicator
+ * the value every rank agreed on, with the row capacity reserved beforehand (pie_comm_reserve) — the message length must be
+ * the same everywhere.  m_out (may be NULL): local_ranks x n_q selected-row counts. */
+int pie_comm_scan_batch_gather(pie_comm *comm, const pie_query *queries, int32_t n_q, int32_t u_pad, size_t *m_out);
+int pie_comm_reserve(pie_comm *comm, int32_t n_q, int32_t u_pad, size_t idx_cap);
+/* The gathered messages as rank `at_rank` holds them: device pointer and strides (words), or one message copied to the host. */
+int pie_comm_gathered_device_ptr(pie_comm *comm, int32_t at_rank, void **base_out, size_t *rank_stride_words,
+                                 size_t *query_stride_words, size_t *u_pad_out);
+int pie_comm_read_gathered(pie_comm *comm, int32_t at_rank, int32_t src_rank, int32_t qi, int32_t *offsets_out /* u_pad + 1 */,
+                           int32_t *idx_out, size_t idx_cap, size_t *m_out);
 
 #ifdef __cplusplus
 }

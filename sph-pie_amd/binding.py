@@ -87,6 +87,7 @@ _SIGS = [
     ("pie_scan_batch_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     ("pie_batch_read_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_batch_result_device_ptrs", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("pie_batch_read_user_feed", C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_read_user_feed", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
@@ -102,6 +103,19 @@ _SIGS = [
     ("pie_shard_of", C.c_int32, [C.c_int32, C.c_int32]),
     ("pie_shard_table", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]),
     ("pie_shard_maps", C.c_int, [_P, _P, _P]),
+    ("pie_comm_create", C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
+    ("pie_comm_unique_id", C.c_int, [_P]),
+    ("pie_comm_create_rank", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pie_comm_destroy", C.c_int, [_P]),
+    ("pie_comm_last_error", C.c_char_p, [_P]),
+    ("pie_comm_world", C.c_int32, [_P]),
+    ("pie_comm_local_ranks", C.c_int32, [_P]),
+    ("pie_comm_ctx", _P, [_P, C.c_int32]),
+    ("pie_comm_gen_synthetic_sharded", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
+    ("pie_comm_scan_batch_gather", C.c_int, [_P, C.POINTER(PieQuery), C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    ("pie_comm_reserve", C.c_int, [_P, C.c_int32, C.c_int32, C.c_size_t]),
+    ("pie_comm_gathered_device_ptr", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("pie_comm_read_gathered", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
 ]
 ABI_SYMBOLS = [s[0] for s in _SIGS]
 
@@ -408,6 +422,14 @@ class PieScan:
         self.scan_batch_finish()
         return [self.batch_read_results(k) for k in range(len(queries))]
 
+    def batch_read_user_feed(self, qi, user, cap=None):
+        """Rows of one user's feed of query qi of the last finished batch."""
+        cap = self.n if cap is None else int(cap)
+        out = np.empty(max(cap, 1), np.int32)
+        k = C.c_size_t(0)
+        self._check(self._lib.pie_batch_read_user_feed(self._ctx, int(qi), int(user), _ptr(out), cap, C.byref(k)))
+        return out[: k.value].copy()
+
     def batch_result_device_ptrs(self, qi):
         a, b, c = _P(), _P(), _P()
         self._check(self._lib.pie_batch_result_device_ptrs(self._ctx, int(qi), C.byref(a), C.byref(b), C.byref(c)))
@@ -503,6 +525,97 @@ class PieScan:
 
     def synchronize(self):
         self._check(self._lib.pie_synchronize(self._ctx))
+
+
+class PieComm:
+    """The sharded table behind the C ABI: one scan context per GPU + an RCCL communicator (pie_comm_*).
+    PieComm(device_ids) = one process drives all GPUs; PieComm.for_rank(id, rank, world, device) = one process per GPU."""
+
+    def __init__(self, device_ids=None, _handle=None):
+        self._lib = load_library()
+        self._c = _P()
+        if _handle is not None:
+            self._c = _handle
+        else:
+            ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+            rc = self._lib.pie_comm_create(ids, len(device_ids), C.byref(self._c))
+            if rc != 0:
+                text = self._lib.pie_comm_last_error(None).decode()
+                self._c = None
+                raise PieError(rc, text)
+        self.world = int(self._lib.pie_comm_world(self._c))
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.pie_comm_unique_id(buf)
+        if rc != 0:
+            raise PieError(rc, lib.pie_comm_last_error(None).decode())
+        return buf.raw
+
+    @classmethod
+    def for_rank(cls, unique_id, rank, world, device):
+        lib = load_library()
+        h = _P()
+        rc = lib.pie_comm_create_rank(C.c_char_p(unique_id), int(rank), int(world), int(device), C.byref(h))
+        if rc != 0:
+            raise PieError(rc, lib.pie_comm_last_error(None).decode())
+        return cls(_handle=h)
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._lib.pie_comm_destroy(self._c)
+            self._c = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PieError(rc, self._lib.pie_comm_last_error(self._c).decode())
+
+    def ctx(self, rank):
+        """The shard's scan context as a PieScan (owned by the communicator: do not close it)."""
+        h = self._lib.pie_comm_ctx(self._c, int(rank))
+        if not h:
+            raise PieError(-1, "rank %d is not local to this communicator" % rank)
+        p = PieScan.__new__(PieScan)
+        p._lib, p._ctx, p._begun = self._lib, _P(h), []
+        st = PieStats()
+        st.struct_size = C.sizeof(PieStats)
+        p._check(self._lib.pie_stats_get(p._ctx, C.byref(st)))
+        p.n, p.n_users = int(st.rows), int(st.users)
+        p.close = lambda: None
+        return p
+
+    def gen_synthetic_sharded(self, seed, n_total, n_users, n_disc, flags=0):
+        self._check(self._lib.pie_comm_gen_synthetic_sharded(self._c, seed, n_total, n_users, n_disc, flags))
+
+    def reserve(self, n_q, u_pad, idx_cap):
+        self._check(self._lib.pie_comm_reserve(self._c, int(n_q), int(u_pad), int(idx_cap)))
+
+    def scan_batch_gather(self, queries, u_pad=0):
+        """-> M[local rank][query]"""
+        arr = PieScan._queries(queries)
+        nl = int(self._lib.pie_comm_local_ranks(self._c))
+        m = (C.c_size_t * (nl * len(queries)))()
+        self._check(self._lib.pie_comm_scan_batch_gather(self._c, arr, len(queries), int(u_pad), m))
+        return [[int(m[k * len(queries) + q]) for q in range(len(queries))] for k in range(nl)]
+
+    def read_gathered(self, at_rank, src_rank, qi):
+        """-> (offsets[u_pad + 1] int32, idx[M] int32) of (src_rank, query qi) as rank at_rank holds it."""
+        base, rs, qs, up = _P(), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self._lib.pie_comm_gathered_device_ptr(self._c, int(at_rank), C.byref(base), C.byref(rs), C.byref(qs), C.byref(up)))
+        off = np.empty(up.value + 1, np.int32)
+        m = C.c_size_t(0)
+        self._check(self._lib.pie_comm_read_gathered(self._c, int(at_rank), int(src_rank), int(qi), _ptr(off), None, 0, C.byref(m)))
+        idx = np.empty(max(m.value, 1), np.int32)
+        self._check(self._lib.pie_comm_read_gathered(self._c, int(at_rank), int(src_rank), int(qi), None, _ptr(idx), m.value, C.byref(m)))
+        return off, idx[: m.value]
 
 
 def shard_of(user, n_shards):

@@ -6,7 +6,9 @@
  * becomes a thrown JS Error carrying `.code` (the PIE_E_* value) and the library's error text — the same
  * shape the route's 500 handler reads (/root/reference/server/index.js:526-536).  All calls are made from
  * the JS main thread; scanAsync() runs the scan on the libuv pool (napi_create_async_work) so a long scan
- * does not block the event loop, one in-flight scan per context.
+ * does not block the event loop, one in-flight scan per context: the context handle is marked busy until the worker
+ * is done and every other entry point refuses a busy (or destroyed) handle with code PIE_E_STATE.  Output arrays are
+ * checked against the lengths the ABI will write (users, users + 1, rows) before any pointer is handed over.
  *
  * Build: gcc -shared -fPIC -I/usr/include/node -Iinclude pie_napi.c -ldl -o host/pie_napi.node
  */
@@ -45,7 +47,18 @@
     X(int, pie_archive_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
     X(int, pie_stats_get, (pie_ctx *, pie_stats *))                                                                 \
-    X(int, pie_stats_reset, (pie_ctx *))
+    X(int, pie_stats_reset, (pie_ctx *))                                                                            \
+    X(int, pie_scan_batch, (pie_ctx *, const pie_query *, int, size_t *))                                           \
+    X(int, pie_batch_read_user_feed, (pie_ctx *, int, int32_t, int32_t *, size_t, size_t *))                        \
+    X(int, pie_comm_create, (const int32_t *, int32_t, pie_comm **))                                                \
+    X(int, pie_comm_destroy, (pie_comm *))                                                                          \
+    X(const char *, pie_comm_last_error, (const pie_comm *))                                                        \
+    X(int32_t, pie_comm_world, (const pie_comm *))                                                                  \
+    X(pie_ctx *, pie_comm_ctx, (pie_comm *, int32_t))                                                               \
+    X(int, pie_comm_gen_synthetic_sharded, (pie_comm *, uint64_t, int64_t, int32_t, int32_t, uint32_t))             \
+    X(int, pie_comm_scan_batch_gather, (pie_comm *, const pie_query *, int32_t, int32_t, size_t *))                 \
+    X(int, pie_comm_gathered_device_ptr, (pie_comm *, int32_t, void **, size_t *, size_t *, size_t *))              \
+    X(int, pie_comm_read_gathered, (pie_comm *, int32_t, int32_t, int32_t, int32_t *, int32_t *, size_t, size_t *))
 
 #define X(ret, name, args) static ret(*p_##name) args;
 PIE_SYMBOLS(X)
@@ -111,14 +124,72 @@ static void *typed(napi_env env, napi_value v, napi_typedarray_type want, size_t
     return data ? data : (void *)(uintptr_t)16; /* zero-length arrays may report NULL */
 }
 
-static pie_ctx *get_ctx(napi_env env, napi_value v)
+/* What a JS context handle points at.  The header asks for one thread per context: while scanAsync() runs a scan on the
+ * libuv pool the box is `busy` and every other entry point refuses it (PIE_E_STATE) instead of racing the worker on the
+ * context's state; after ctxDestroy the box stays (the external keeps pointing at it) with ctx = NULL, so a stale handle
+ * throws instead of touching freed memory.  `owned` = 0: the context belongs to a communicator (commCtx). */
+typedef struct {
+    pie_ctx *ctx;
+    int busy;
+    int owned;
+} ctx_box;
+
+static void box_finalize(napi_env env, void *data, void *hint)
+{
+    (void)env;
+    (void)hint;
+    ctx_box *b = (ctx_box *)data;
+    if (b && b->ctx && b->owned && !b->busy && p_pie_ctx_destroy) p_pie_ctx_destroy(b->ctx);
+    free(b);
+}
+
+static napi_value throw_state(napi_env env, const char *text)
+{
+    napi_value msg, err, code;
+    napi_create_string_utf8(env, text, NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_create_int32(env, PIE_E_STATE, &code);
+    napi_set_named_property(env, err, "code", code);
+    napi_throw(env, err);
+    return NULL;
+}
+
+static ctx_box *get_box(napi_env env, napi_value v)
 {
     void *p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, NULL, "expected a pie context");
         return NULL;
     }
-    return (pie_ctx *)p;
+    return (ctx_box *)p;
+}
+
+static pie_ctx *get_ctx(napi_env env, napi_value v)
+{
+    ctx_box *b = get_box(env, v);
+    if (!b) return NULL;
+    if (!b->ctx) {
+        throw_state(env, "pie_scan error -6: this context was destroyed");
+        return NULL;
+    }
+    if (b->busy) {
+        throw_state(env, "pie_scan error -6: an asynchronous scan is in flight on this context (one thread per context)");
+        return NULL;
+    }
+    return b->ctx;
+}
+
+/* rows / users of the resident table, for the length checks of caller-supplied output arrays */
+static int table_shape(pie_ctx *ctx, size_t *rows, size_t *users)
+{
+    pie_stats st;
+    memset(&st, 0, sizeof st);
+    st.struct_size = sizeof st;
+    int rc = p_pie_stats_get(ctx, &st);
+    if (rc) return rc;
+    *rows = (size_t)st.rows;
+    *users = (size_t)st.users;
+    return 0;
 }
 
 #define ARGS(n)                                                          \
@@ -182,17 +253,32 @@ static napi_value fn_ctx_create(napi_env env, napi_callback_info info)
     pie_ctx *ctx = NULL;
     int rc = p_pie_ctx_create(dev, &ctx);
     if (rc) return throw_pie(env, NULL, rc);
+    ctx_box *b = (ctx_box *)calloc(1, sizeof *b);
+    if (!b) {
+        p_pie_ctx_destroy(ctx);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    b->ctx = ctx;
+    b->owned = 1;
     napi_value ext;
-    CHECK(env, napi_create_external(env, ctx, NULL, NULL, &ext));
+    if (napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
+        p_pie_ctx_destroy(ctx);
+        free(b);
+        napi_throw_error(env, NULL, "N-API call failed: napi_create_external");
+        return NULL;
+    }
     return ext;
 }
 
 static napi_value fn_ctx_destroy(napi_env env, napi_callback_info info)
 {
     ARGS(1)
-    pie_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    p_pie_ctx_destroy(ctx);
+    ctx_box *b = get_box(env, argv[0]);
+    if (!b) return NULL;
+    if (b->busy) return throw_state(env, "pie_scan error -6: an asynchronous scan is in flight on this context");
+    if (b->ctx && b->owned) p_pie_ctx_destroy(b->ctx);
+    b->ctx = NULL; /* the handle stays valid as an object and throws on any further use */
     return js_int(env, 0);
 }
 
@@ -245,11 +331,11 @@ static napi_value fn_read_columns(napi_env env, napi_callback_info info)
     ARGS(5)
     pie_ctx *ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
-    size_t n = 0;
-    int64_t *s = typed(env, argv[1], napi_bigint64_array, &n), *e = typed(env, argv[2], napi_bigint64_array, NULL);
-    int32_t *u = typed(env, argv[3], napi_int32_array, NULL), *d = typed(env, argv[4], napi_int32_array, NULL);
-    if (!s || !e || !u || !d) {
-        napi_throw_type_error(env, NULL, "bad output arrays");
+    size_t n = 0, n1 = 0, n2 = 0, n3 = 0;
+    int64_t *s = typed(env, argv[1], napi_bigint64_array, &n), *e = typed(env, argv[2], napi_bigint64_array, &n1);
+    int32_t *u = typed(env, argv[3], napi_int32_array, &n2), *d = typed(env, argv[4], napi_int32_array, &n3);
+    if (!s || !e || !u || !d || n1 < n || n2 < n || n3 < n) {
+        napi_throw_type_error(env, NULL, "readColumns(ctx, BigInt64Array, BigInt64Array, Int32Array, Int32Array): every array at least as long as the first");
         return NULL;
     }
     int rc = p_pie_read_columns(ctx, s, e, u, d, n);
@@ -360,16 +446,18 @@ static napi_value fn_scan(napi_env env, napi_callback_info info)
         napi_throw_type_error(env, NULL, "now / cutoff must be finite integers (Number or BigInt)");
         return NULL;
     }
-    size_t cap = 0;
-    int32_t *counts = typed(env, argv[3], napi_int32_array, NULL);
-    int64_t *offsets = typed(env, argv[4], napi_bigint64_array, NULL);
+    size_t cap = 0, nc = 0, no = 0, rows = 0, users = 0;
+    int32_t *counts = typed(env, argv[3], napi_int32_array, &nc);
+    int64_t *offsets = typed(env, argv[4], napi_bigint64_array, &no);
     int32_t *idx = typed(env, argv[5], napi_int32_array, &cap);
-    if (!counts || !offsets || !idx) {
-        napi_throw_type_error(env, NULL, "scan(ctx, now, cutoff, Int32Array, BigInt64Array, Int32Array)");
+    int rc = table_shape(ctx, &rows, &users);
+    if (rc) return throw_pie(env, ctx, rc);
+    if (!counts || !offsets || !idx || nc < users || no < users + 1) { /* the ABI writes counts[U] and offsets[U + 1] */
+        napi_throw_type_error(env, NULL, "scan(ctx, now, cutoff, Int32Array[>= users], BigInt64Array[>= users + 1], Int32Array)");
         return NULL;
     }
     size_t m = 0;
-    int rc = p_pie_scan(ctx, now, cutoff, counts, offsets, idx, cap, &m);
+    rc = p_pie_scan(ctx, now, cutoff, counts, offsets, idx, cap, &m);
     if (rc) return throw_pie(env, ctx, rc);
     return js_int(env, (int64_t)m);
 }
@@ -415,6 +503,7 @@ typedef struct {
     napi_async_work work;
     napi_ref cb, keep[3];
     pie_ctx *ctx;
+    ctx_box *box;
     int64_t now, cutoff;
     int32_t *counts, *idx;
     int64_t *offsets;
@@ -435,6 +524,7 @@ static void scan_done(napi_env env, napi_status status, void *data)
 {
     scan_job *j = (scan_job *)data;
     napi_value cb, global, args[2], res;
+    j->box->busy = 0; /* the worker is done with the context: the main thread may use it again */
     napi_get_reference_value(env, j->cb, &cb);
     napi_get_global(env, &global);
     if (status != napi_ok || j->rc) {
@@ -458,28 +548,35 @@ static void scan_done(napi_env env, napi_status status, void *data)
 static napi_value fn_scan_async(napi_env env, napi_callback_info info)
 {
     ARGS(7)
-    pie_ctx *ctx = get_ctx(env, argv[0]);
+    pie_ctx *ctx = get_ctx(env, argv[0]); /* refuses a context that is already busy */
     if (!ctx) return NULL;
+    size_t nc = 0, no = 0, rows = 0, users = 0;
+    int rc0 = table_shape(ctx, &rows, &users);
+    if (rc0) return throw_pie(env, ctx, rc0);
     scan_job *j = (scan_job *)calloc(1, sizeof *j);
     if (!j) {
         napi_throw_error(env, NULL, "out of memory");
         return NULL;
     }
     j->ctx = ctx;
-    j->counts = typed(env, argv[3], napi_int32_array, NULL);
-    j->offsets = typed(env, argv[4], napi_bigint64_array, NULL);
+    j->box = get_box(env, argv[0]);
+    j->counts = typed(env, argv[3], napi_int32_array, &nc);
+    j->offsets = typed(env, argv[4], napi_bigint64_array, &no);
     j->idx = typed(env, argv[5], napi_int32_array, &j->cap);
-    if (!get_i64(env, argv[1], &j->now) || !get_i64(env, argv[2], &j->cutoff) || !j->counts || !j->offsets || !j->idx) {
+    if (!get_i64(env, argv[1], &j->now) || !get_i64(env, argv[2], &j->cutoff) || !j->counts || !j->offsets || !j->idx ||
+        nc < users || no < users + 1) {
         free(j);
-        napi_throw_type_error(env, NULL, "scanAsync(ctx, now, cutoff, Int32Array, BigInt64Array, Int32Array, cb)");
+        napi_throw_type_error(env, NULL, "scanAsync(ctx, now, cutoff, Int32Array[>= users], BigInt64Array[>= users + 1], Int32Array, cb)");
         return NULL;
     }
     napi_value name;
     napi_create_string_utf8(env, "pie_scan", NAPI_AUTO_LENGTH, &name);
     napi_create_reference(env, argv[6], 1, &j->cb);
     for (int i = 0; i < 3; ++i) napi_create_reference(env, argv[3 + i], 1, &j->keep[i]); /* keep buffers alive */
+    j->box->busy = 1;
     if (napi_create_async_work(env, NULL, name, scan_exec, scan_done, j, &j->work) != napi_ok ||
         napi_queue_async_work(env, j->work) != napi_ok) {
+        j->box->busy = 0;
         free(j);
         napi_throw_error(env, NULL, "cannot queue async work");
         return NULL;
@@ -500,9 +597,10 @@ static napi_value fn_fetch_rows(napi_env env, napi_callback_info info)
         napi_throw_type_error(env, NULL, "fetchRows(ctx, Int32Array idx, m <= idx.length, ...)");
         return NULL;
     }
-    int64_t *s = typed(env, argv[3], napi_bigint64_array, &c1), *e = typed(env, argv[4], napi_bigint64_array, NULL);
-    int32_t *u = typed(env, argv[5], napi_int32_array, NULL), *d = typed(env, argv[6], napi_int32_array, NULL);
-    if (!s || !e || !u || !d || c1 < (size_t)m) {
+    size_t c2 = 0, c3 = 0, c4 = 0;
+    int64_t *s = typed(env, argv[3], napi_bigint64_array, &c1), *e = typed(env, argv[4], napi_bigint64_array, &c2);
+    int32_t *u = typed(env, argv[5], napi_int32_array, &c3), *d = typed(env, argv[6], napi_int32_array, &c4);
+    if (!s || !e || !u || !d || c1 < (size_t)m || c2 < (size_t)m || c3 < (size_t)m || c4 < (size_t)m) {
         napi_throw_type_error(env, NULL, "bad output arrays");
         return NULL;
     }
@@ -770,6 +868,364 @@ static napi_value fn_serialize_ical(napi_env env, napi_callback_info info)
     return out;
 }
 
+/* serializeCsv(idx Int32Array, m, start, end BigInt64Array, user, disc Int32Array, userIds Array<string>, discIds Array<string>,
+ *              headerLine string) -> Buffer: header + one CSV line per row, '\n' between lines — exactly the bytes of
+ * host/dispatchQueue.js [header].concat(rows.map(buildCsvRow)).join('\n') with the columns sessionRow, userId, discipline,
+ * createdAt, expiredAt.  csvEscape is the reference's rule (/root/reference/server/webhookDispatcher.js:332-338): a field is
+ * quoted iff it holds '"', ',', '\n' or '\r', inner quotes doubled.  Returns null for rows this fast path does not cover
+ * (a year outside 0000..9999): the caller then uses the JS path. */
+static int sb_csv_field(sbuf *b, const char *s, size_t n)
+{
+    int quote = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (s[i] == '"' || s[i] == ',' || s[i] == '\n' || s[i] == '\r') { quote = 1; break; }
+    if (!quote) return sb_put(b, s, n);
+    if (!SB_LIT(b, "\"")) return 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (s[i] == '"' && !SB_LIT(b, "\"")) return 0;
+        if (!sb_put(b, s + i, 1)) return 0;
+    }
+    return SB_LIT(b, "\"");
+}
+
+static napi_value fn_serialize_csv(napi_env env, napi_callback_info info)
+{
+    ARGS(9)
+    size_t cap = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+    int32_t *idx = typed(env, argv[0], napi_int32_array, &cap);
+    int64_t m = 0;
+    int64_t *start = typed(env, argv[2], napi_bigint64_array, &n1), *end = typed(env, argv[3], napi_bigint64_array, &n2);
+    int32_t *user = typed(env, argv[4], napi_int32_array, &n3), *disc = typed(env, argv[5], napi_int32_array, &n4);
+    uint32_t n_users = 0, n_disc = 0;
+    size_t hlen = 0;
+    if (!idx || !get_i64(env, argv[1], &m) || m < 0 || (size_t)m > cap || !start || !end || !user || !disc || n1 < (size_t)m ||
+        n2 < (size_t)m || n3 < (size_t)m || n4 < (size_t)m || napi_get_array_length(env, argv[6], &n_users) != napi_ok ||
+        napi_get_array_length(env, argv[7], &n_disc) != napi_ok || napi_get_value_string_utf8(env, argv[8], NULL, 0, &hlen) != napi_ok) {
+        napi_throw_type_error(env, NULL, "serializeCsv(Int32Array idx, m, BigInt64Array start, BigInt64Array end, Int32Array user, Int32Array disc, Array userIds, Array discIds, header)");
+        return NULL;
+    }
+    sbuf b = {NULL, 0, 0};
+    int ok = sb_need(&b, hlen + 1), covered = 1;
+    if (ok) {
+        napi_get_value_string_utf8(env, argv[8], b.p, hlen + 1, &hlen);
+        b.len = hlen;
+    }
+    char *tmp = NULL;
+    size_t tmp_cap = 0;
+    for (int64_t i = 0; i < m && ok && covered; ++i) {
+        char iso_s[25], iso_e[25];
+        int h, mi;
+        const int has_end = end[i] != INT64_MIN;
+        if (!iso_utc(start[i], iso_s, &h, &mi) || (has_end && !iso_utc(end[i], iso_e, &h, &mi))) { covered = 0; break; }
+        ok = SB_LIT(&b, "\n") && sb_i64(&b, idx[i]) && SB_LIT(&b, ",");
+        /* the two string columns: '' when the index is outside the table (userIds[u] === undefined / no discipline) */
+        for (int col = 0; col < 2 && ok; ++col) {
+            const int32_t k = col == 0 ? user[i] : disc[i];
+            const uint32_t lim = col == 0 ? n_users : n_disc;
+            if (k >= 0 && (uint32_t)k < lim) {
+                napi_value sv;
+                size_t len = 0;
+                napi_valuetype t;
+                if (napi_get_element(env, argv[6 + col], (uint32_t)k, &sv) != napi_ok || napi_typeof(env, sv, &t) != napi_ok) { ok = 0; break; }
+                if (t == napi_string) {
+                    if (napi_get_value_string_utf8(env, sv, NULL, 0, &len) != napi_ok) { ok = 0; break; }
+                    if (len + 1 > tmp_cap) {
+                        char *np = (char *)realloc(tmp, len + 1);
+                        if (!np) { ok = 0; break; }
+                        tmp = np;
+                        tmp_cap = len + 1;
+                    }
+                    if (napi_get_value_string_utf8(env, sv, tmp, len + 1, &len) != napi_ok) { ok = 0; break; }
+                    ok = sb_csv_field(&b, tmp, len);
+                } else if (t != napi_undefined && t != napi_null) {
+                    covered = 0; /* a non-string id: String(value) is the JS path's business */
+                }
+            }
+            if (ok) ok = SB_LIT(&b, ",");
+        }
+        if (ok && covered) ok = sb_put(&b, iso_s, 24) && SB_LIT(&b, ",") && (has_end ? sb_put(&b, iso_e, 24) : 1);
+    }
+    free(tmp);
+    napi_value out = NULL;
+    if (!ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "serializeCsv: out of memory or bad id table");
+        return NULL;
+    }
+    if (!covered) {
+        free(b.p);
+        napi_get_null(env, &out);
+        return out;
+    }
+    void *copy = NULL;
+    if (napi_create_buffer_copy(env, b.len, b.p, &copy, &out) != napi_ok) {
+        free(b.p);
+        napi_throw_error(env, NULL, "cannot create Buffer");
+        return NULL;
+    }
+    free(b.p);
+    return out;
+}
+
+/* ---- batched scan: the requests of one event-loop turn, one table pass ------------------------------------------------
+ * queries travel as three typed arrays of equal length (<= PIE_BATCH_MAX): now, cutoff (BigInt64Array), mask (BigUint64Array) */
+static int read_queries(napi_env env, napi_value nows, napi_value cutoffs, napi_value masks, pie_query *out, int *n_q)
+{
+    size_t a = 0, b = 0, c = 0;
+    int64_t *pn = typed(env, nows, napi_bigint64_array, &a), *pc = typed(env, cutoffs, napi_bigint64_array, &b);
+    uint64_t *pm = typed(env, masks, napi_biguint64_array, &c);
+    if (!pn || !pc || !pm || a != b || a != c || a < 1 || a > PIE_BATCH_MAX) return 0;
+    for (size_t k = 0; k < a; ++k) {
+        out[k].now = pn[k];
+        out[k].cutoff = pc[k];
+        out[k].mask = pm[k];
+    }
+    *n_q = (int)a;
+    return 1;
+}
+
+/* scanBatch(ctx, nows, cutoffs, masks) -> Array of M per query; results stay in HBM (batchUserFeed reads a slice) */
+static napi_value fn_scan_batch(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    pie_query q[PIE_BATCH_MAX];
+    int n_q = 0;
+    if (!read_queries(env, argv[1], argv[2], argv[3], q, &n_q)) {
+        napi_throw_type_error(env, NULL, "scanBatch(ctx, BigInt64Array nows, BigInt64Array cutoffs, BigUint64Array masks): 1..16 queries, equal lengths");
+        return NULL;
+    }
+    size_t m[PIE_BATCH_MAX];
+    int rc = p_pie_scan_batch(ctx, q, n_q, m);
+    if (rc) return throw_pie(env, ctx, rc);
+    napi_value out;
+    CHECK(env, napi_create_array_with_length(env, (size_t)n_q, &out));
+    for (int k = 0; k < n_q; ++k) napi_set_element(env, out, (uint32_t)k, js_int(env, (int64_t)m[k]));
+    return out;
+}
+
+/* batchUserFeed(ctx, qi, user, idx Int32Array) -> k */
+static napi_value fn_batch_user_feed(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t qi = 0;
+    int64_t user = 0;
+    size_t cap = 0, k = 0;
+    int32_t *idx = typed(env, argv[3], napi_int32_array, &cap);
+    if (napi_get_value_int32(env, argv[1], &qi) != napi_ok || !get_i64(env, argv[2], &user) || !idx || user < INT32_MIN || user > INT32_MAX) {
+        napi_throw_type_error(env, NULL, "batchUserFeed(ctx, qi, user, Int32Array)");
+        return NULL;
+    }
+    int rc = p_pie_batch_read_user_feed(ctx, qi, (int32_t)user, idx, cap, &k);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)k);
+}
+
+/* ---- communicator: the sharded table over several GPUs (pie_comm_*, RCCL behind the C ABI) -------------------------- */
+static napi_value throw_comm(napi_env env, pie_comm *cm, int rc)
+{
+    napi_value msg, err, code;
+    char buf[640];
+    snprintf(buf, sizeof buf, "pie_comm error %d: %s", rc, p_pie_comm_last_error ? p_pie_comm_last_error(cm) : "library not open");
+    napi_create_string_utf8(env, buf, NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_create_int32(env, rc, &code);
+    napi_set_named_property(env, err, "code", code);
+    napi_throw(env, err);
+    return NULL;
+}
+
+typedef struct {
+    pie_comm *comm;
+} comm_box;
+
+static void comm_finalize(napi_env env, void *data, void *hint)
+{
+    (void)env;
+    (void)hint;
+    comm_box *b = (comm_box *)data;
+    if (b && b->comm && p_pie_comm_destroy) p_pie_comm_destroy(b->comm);
+    free(b);
+}
+
+static pie_comm *get_comm(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((comm_box *)p)->comm) {
+        napi_throw_type_error(env, NULL, "expected a live pie communicator");
+        return NULL;
+    }
+    return ((comm_box *)p)->comm;
+}
+
+/* commCreate(Int32Array deviceIds) -> communicator: one shard per listed GPU, driven by this process */
+static napi_value fn_comm_create(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    if (!need_lib(env)) return NULL;
+    size_t n = 0;
+    int32_t *ids = typed(env, argv[0], napi_int32_array, &n);
+    if (!ids || n < 1) {
+        napi_throw_type_error(env, NULL, "commCreate(Int32Array deviceIds)");
+        return NULL;
+    }
+    pie_comm *cm = NULL;
+    int rc = p_pie_comm_create(ids, (int32_t)n, &cm);
+    if (rc) return throw_comm(env, NULL, rc);
+    comm_box *b = (comm_box *)calloc(1, sizeof *b);
+    napi_value ext;
+    if (!b || napi_create_external(env, b, comm_finalize, NULL, &ext) != napi_ok) {
+        p_pie_comm_destroy(cm);
+        free(b);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    b->comm = cm;
+    return ext;
+}
+
+static napi_value fn_comm_destroy(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a pie communicator");
+        return NULL;
+    }
+    comm_box *b = (comm_box *)p;
+    if (b->comm) p_pie_comm_destroy(b->comm); /* contexts handed out by commCtx die with it: do not use them afterwards */
+    b->comm = NULL;
+    return js_int(env, 0);
+}
+
+static napi_value fn_comm_world(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    return js_int(env, p_pie_comm_world(cm));
+}
+
+/* commCtx(comm, rank) -> context handle of that shard (owned by the communicator) */
+static napi_value fn_comm_ctx(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int32_t rank = 0;
+    CHECK(env, napi_get_value_int32(env, argv[1], &rank));
+    pie_ctx *ctx = p_pie_comm_ctx(cm, rank);
+    if (!ctx) return throw_state(env, "pie_comm error -6: that rank is not local to this communicator");
+    ctx_box *b = (ctx_box *)calloc(1, sizeof *b);
+    napi_value ext;
+    if (!b || napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
+        free(b);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    b->ctx = ctx;
+    b->owned = 0;
+    return ext;
+}
+
+/* commGenSyntheticSharded(comm, seed, nTotal, nUsers, nDisc, flags) */
+static napi_value fn_comm_gen(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int64_t seed, n_total;
+    int32_t n_users, n_disc, flags;
+    if (!get_i64(env, argv[1], &seed) || !get_i64(env, argv[2], &n_total)) {
+        napi_throw_type_error(env, NULL, "bad integer argument");
+        return NULL;
+    }
+    CHECK(env, napi_get_value_int32(env, argv[3], &n_users));
+    CHECK(env, napi_get_value_int32(env, argv[4], &n_disc));
+    CHECK(env, napi_get_value_int32(env, argv[5], &flags));
+    int rc = p_pie_comm_gen_synthetic_sharded(cm, (uint64_t)seed, n_total, n_users, n_disc, (uint32_t)flags);
+    if (rc) return throw_comm(env, cm, rc);
+    return js_int(env, n_total);
+}
+
+/* commScanBatchGather(comm, nows, cutoffs, masks) -> Array [rank][query] of M: every shard scans the batch, the messages
+ * are exchanged over RCCL; commReadGathered then reads one (source rank, query) message as a given rank holds it */
+static napi_value fn_comm_scan_gather(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    pie_query q[PIE_BATCH_MAX];
+    int n_q = 0;
+    if (!read_queries(env, argv[1], argv[2], argv[3], q, &n_q)) {
+        napi_throw_type_error(env, NULL, "commScanBatchGather(comm, BigInt64Array nows, BigInt64Array cutoffs, BigUint64Array masks)");
+        return NULL;
+    }
+    const int world = p_pie_comm_world(cm);
+    size_t *m = (size_t *)calloc((size_t)world * (size_t)n_q, sizeof *m);
+    if (!m) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    int rc = p_pie_comm_scan_batch_gather(cm, q, n_q, 0, m);
+    if (rc) {
+        free(m);
+        return throw_comm(env, cm, rc);
+    }
+    napi_value out;
+    napi_create_array_with_length(env, (size_t)world, &out);
+    for (int r = 0; r < world; ++r) {
+        napi_value row;
+        napi_create_array_with_length(env, (size_t)n_q, &row);
+        for (int k = 0; k < n_q; ++k) napi_set_element(env, row, (uint32_t)k, js_int(env, (int64_t)m[(size_t)r * n_q + k]));
+        napi_set_element(env, out, (uint32_t)r, row);
+    }
+    free(m);
+    return out;
+}
+
+/* commReadGathered(comm, atRank, srcRank, qi, offsets Int32Array[>= uPad + 1], idx Int32Array) -> M */
+static napi_value fn_comm_read(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int32_t at = 0, src = 0, qi = 0;
+    size_t no = 0, cap = 0, m = 0, u_pad = 0, rs = 0, qs = 0;
+    void *base = NULL;
+    CHECK(env, napi_get_value_int32(env, argv[1], &at));
+    CHECK(env, napi_get_value_int32(env, argv[2], &src));
+    CHECK(env, napi_get_value_int32(env, argv[3], &qi));
+    int32_t *off = typed(env, argv[4], napi_int32_array, &no), *idx = typed(env, argv[5], napi_int32_array, &cap);
+    int rc = p_pie_comm_gathered_device_ptr(cm, at, &base, &rs, &qs, &u_pad);
+    if (rc) return throw_comm(env, cm, rc);
+    if (!off || !idx || no < u_pad + 1) {
+        napi_throw_type_error(env, NULL, "commReadGathered(comm, at, src, qi, Int32Array[>= uPad + 1], Int32Array)");
+        return NULL;
+    }
+    rc = p_pie_comm_read_gathered(cm, at, src, qi, off, idx, cap, &m);
+    if (rc) return throw_comm(env, cm, rc);
+    return js_int(env, (int64_t)m);
+}
+
+/* commUPad(comm, atRank) -> users per message (the largest shard's user count) of the last exchange */
+static napi_value fn_comm_upad(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int32_t at = 0;
+    size_t u_pad = 0, rs = 0, qs = 0;
+    void *base = NULL;
+    CHECK(env, napi_get_value_int32(env, argv[1], &at));
+    int rc = p_pie_comm_gathered_device_ptr(cm, at, &base, &rs, &qs, &u_pad);
+    if (rc) return throw_comm(env, cm, rc);
+    return js_int(env, (int64_t)u_pad);
+}
+
 /* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
@@ -816,6 +1272,9 @@ static napi_value init(napi_env env, napi_value exports)
         {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+        {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed},
+        {"commCreate", fn_comm_create}, {"commDestroy", fn_comm_destroy}, {"commWorld", fn_comm_world}, {"commCtx", fn_comm_ctx},
+        {"commGenSyntheticSharded", fn_comm_gen}, {"commScanBatchGather", fn_comm_scan_gather}, {"commReadGathered", fn_comm_read}, {"commUPad", fn_comm_upad},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

@@ -2005,6 +2005,27 @@ int pie_batch_result_device_ptrs(pie_ctx* c, int qi, void** counts_dev, void** o
     return PIE_OK;
 }
 
+int pie_batch_read_user_feed(pie_ctx* c, int qi, int32_t user, int32_t* idx_out, size_t idx_cap, size_t* k_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (k_out) *k_out = 0;
+    void *dc = nullptr, *dof = nullptr, *di = nullptr;
+    int rc = pie_batch_result_device_ptrs(c, qi, &dc, &dof, &di);
+    if (rc) return rc;
+    if (user < 0 || user >= c->n_users) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    long long off[2] = {0, 0};
+    PIE_HIP(c, hipMemcpyAsync(off, static_cast<long long*>(dof) + user, sizeof off, hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t k = (size_t)(off[1] - off[0]);
+    if (k_out) *k_out = k;
+    if (k == 0) return PIE_OK;
+    if (!idx_out || k > idx_cap) return fail(c, PIE_E_CAPACITY, "idx_cap %zu < feed length %zu", idx_cap, k);
+    PIE_HIP(c, hipMemcpyAsync(idx_out, static_cast<int*>(di) + off[0], k * 4, hipMemcpyDeviceToHost, c->stream));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    return PIE_OK;
+}
+
 int pie_batch_read_results(pie_ctx* c, int qi, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)
 {
     if (!c) return PIE_E_INVAL;

@@ -144,7 +144,45 @@ function createFeedService(store, options){
     return feeds;
   }
 
-  return {scan, eventsForUser, eventsJsonForUser, icsForUser, allFeeds, scansRun: () => scansRun};
+  // ---- the requests of one event-loop turn, ONE table pass ---------------------------------------------------------
+  // requests: [{userId, query}] -> response bodies ({"events":[...]} bytes), in request order.  Requests are grouped by
+  // their (now, cutoff, discipline filter); up to store.BATCH_MAX distinct groups share one batched device scan
+  // (pie_scan_batch: the key column is streamed once, every candidate row is evaluated against all the queries), each
+  // request then reads its user's slice of its query's result.  Same bytes as eventsJsonForUser, request by request.
+  let batchesRun = 0;
+  function eventsJsonForRequests(requests){
+    const bodies = new Array(requests.length);
+    const groups = [];                 // {k, members: [request index]}
+    const byKey = new Map();
+    requests.forEach((r, i) => {
+      const k = key(r.query);
+      const id = k.now + '|' + k.cutoff + '|' + k.filter;
+      let g = byKey.get(id);
+      if(g === undefined){
+        g = {k, members: []};
+        byKey.set(id, g);
+        groups.push(g);
+      }
+      g.members.push(i);
+    });
+    const maxQ = store.BATCH_MAX || 16;
+    for(let at = 0; at < groups.length; at += maxQ){
+      const chunk = groups.slice(at, at + maxQ);
+      store.scanBatchDevice(chunk.map(g => ({now: g.k.now, cutoff: g.k.cutoff, disciplines: g.k.disciplines})));
+      batchesRun++;
+      last = null;                     // the device now holds a batch result, not a single scan's
+      chunk.forEach((g, qi) => {
+        for(const i of g.members){
+          const u = store.userIndexOf(requests[i].userId);
+          bodies[i] = u < 0 ? Buffer.from('{"events":[]}') : eventsJsonFromRows(store.batchUserFeed(qi, u));
+        }
+      });
+    }
+    return bodies;
+  }
+
+  return {scan, eventsForUser, eventsJsonForUser, eventsJsonForRequests, icsForUser, allFeeds, scansRun: () => scansRun,
+    batchesRun: () => batchesRun};
 }
 
 module.exports = {createFeedService};

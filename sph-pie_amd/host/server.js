@@ -56,6 +56,31 @@ function createServer(options){
     return user;
   }
 
+  // Request coalescing (options.coalesce): "calendarFeed per-request loop -> batched GPU scan".  Feed requests that arrive
+  // in one turn of the event loop are answered together: their (now, cutoff, filter) queries go to the device as ONE
+  // batched scan, and every response is written from its own slice.  A failure answers every request of the batch with
+  // the 500 body of /root/reference/server/index.js:526-536.
+  const coalesce = options.coalesce === true;
+  let pending = [];
+  function flushPending(){
+    const batch = pending;
+    pending = [];
+    try{
+      const bodies = feeds.eventsJsonForRequests(batch.map(p => ({userId: p.userId, query: p.query})));
+      batch.forEach((p, i) => {
+        p.res.writeHead(200, {'Content-Type': 'application/json; charset=utf-8', 'Content-Length': bodies[i].length});
+        p.res.end(bodies[i]);
+      });
+    }catch(err){
+      console.error(err);
+      for(const p of batch){
+        if(!p.res.headersSent){
+          sendJson(p.res, 500, {error: 'Internal server error', detail: err && err.message ? err.message : String(err)});
+        }
+      }
+    }
+  }
+
   function handleCalendar(req, res, asIcs){
     const user = authenticate(req);
     if(user && user.needsPasswordReset){
@@ -74,6 +99,14 @@ function createServer(options){
       const body = feeds.icsForUser(user.id, query);
       res.writeHead(200, {'Content-Type': 'text/calendar; charset=utf-8', 'Content-Length': body.length});
       return res.end(body);
+    }
+    if(coalesce && typeof feeds.eventsJsonForRequests === 'function'){
+      // batched: the request joins the batch of this event-loop turn; one device scan answers them all
+      pending.push({res, userId: user.id, query});
+      if(pending.length === 1){
+        setImmediate(flushPending);
+      }
+      return undefined;
     }
     if(typeof feeds.eventsJsonForUser === 'function'){
       // body bytes straight from the native serialiser (same bytes as JSON.stringify({events}))

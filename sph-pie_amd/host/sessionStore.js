@@ -10,6 +10,12 @@
 // scanFeeds().  What stays on the host: the token -> row map (O(1) lookups, sha256) and a mirror of each row's
 // {userId, createdAt, expiresAt}, kept exact by the row lists the device scans return, so getSession never
 // touches the device.  Mutations are batched and flushed to the device before any scan.
+//
+// Rows are reclaimed: the reference does sessions.delete(); here a deleted / purged session first becomes a tombstone
+// (its row index may still sit in a result the caller holds), and once the dead rows outweigh the live ones the table is
+// compacted — live rows re-uploaded in order, the token map re-pointed — so N follows the live sessions, not every login
+// ever made.  A session that getSession() finds expired keeps its real `end` on the device (it is dead for every scan
+// anyway) so that the expired-session dispatch queue still reports it.
 const crypto = require('crypto');
 const fs = require('fs');
 const path = require('path');
@@ -35,7 +41,18 @@ function createStore(options){
   let pendingEnd = new Map();                      // row -> BigInt new end (touch / delete of resident rows)
   let lastPurge = null;
   let out = null;                                  // scan output arrays, sized lazily
-  let generation = 0;                              // bumped by every change a scan could see (see feedService's scan sharing)
+  let generation = 0;                              // bumped by every change a scan could see AND by every native call that
+                                                   // drops the device's last scan result (see feedService's scan sharing)
+  let nGone = 0;                                   // rows that no scan, queue or lookup will ever need again
+  let listBuf = new Int32Array(1024);              // reused row-list buffer of the device scans (grown, never per call)
+  const compactMinRows = opts.compactMinRows === undefined ? 4096 : opts.compactMinRows;
+
+  function rowList(){
+    if(listBuf.length < rows.length){
+      listBuf = new Int32Array(Math.max(rows.length, 2 * listBuf.length));
+    }
+    return listBuf;
+  }
 
   function denseUser(userId){
     let u = userIndex.get(userId);
@@ -50,6 +67,9 @@ function createStore(options){
   // push host-side mutations to the device: appended rows first, then end updates, so a row that was created
   // and touched in the same batch ends with the touched value
   function flush(){
+    if(rows.length >= compactMinRows && nGone * 2 > rows.length){
+      compact();
+    }
     const k = rows.length - uploaded;
     if(k > 0 || uploaded === 0){
       const s = new BigInt64Array(k), e = new BigInt64Array(k);
@@ -57,7 +77,7 @@ function createStore(options){
       for(let i = 0; i < k; i++){
         const r = rows[uploaded + i];
         s[i] = BigInt(r.createdAt);
-        e[i] = r.tokenHash === null ? END_NONE : BigInt(r.expiresAt);
+        e[i] = r.gone ? END_NONE : BigInt(r.expiresAt);   // a deleted row is a tombstone; an expired one keeps its `end`
         u[i] = r.user;
         d[i] = r.disc;
         pendingEnd.delete(uploaded + i);
@@ -88,12 +108,44 @@ function createStore(options){
     }
   }
 
+  // the row has been reported by a purge / user delete, or was deleted explicitly: nothing will ask for it again
+  function retire(row){
+    const r = rows[row];
+    if(!r.gone){
+      r.gone = true;
+      nGone++;
+    }
+  }
+
   function tombstone(row){
     forget(row);
+    retire(row);
     if(row < uploaded){
       pendingEnd.set(row, END_NONE);
     }
   }
+
+  // Rebuild the table from the rows that are still needed (live sessions, and expired ones no purge has reported yet),
+  // in their old order; row indices change, so the device's last result is dropped with the generation bump.
+  function compact(){
+    const keep = [];
+    for(let i = 0; i < rows.length; i++){
+      if(!rows[i].gone){ keep.push(rows[i]); }
+    }
+    rows.length = 0;
+    rowOfToken.clear();
+    for(const r of keep){
+      if(r.tokenHash !== null){ rowOfToken.set(r.tokenHash, rows.length); }
+      rows.push(r);
+    }
+    uploaded = 0;                       // the next lines of flush() upload the whole (smaller) table
+    pendingEnd = new Map();
+    nGone = 0;
+    out = null;
+    generation++;
+    compactions++;
+  }
+  let compactions = 0;
 
   // createSession(userId[, disciplineId]) -> {token, expiresAt}.  The second argument is [DERIVED] (the reference
   // record has no discipline field): an id of disciplineConfig.DISCIPLINES, default = the default discipline.
@@ -122,8 +174,8 @@ function createStore(options){
     }
     const r = rows[row];
     if(r.expiresAt <= Date.now()){                  // dead iff expiresAt <= now (:30)
-      tombstone(row);
-      return null;
+      forget(row);                                  // sessions.delete(hash): the lookup is gone; the row keeps its real
+      return null;                                  // `end` on the device, so the expired-session queue still reports it
     }
     return {userId: r.userId, createdAt: r.createdAt, expiresAt: r.expiresAt, tokenHash};
   }
@@ -163,10 +215,12 @@ function createStore(options){
       return;
     }
     flush();
-    const list = new Int32Array(Math.max(rows.length, 1));
+    const list = rowList();
     const k = native.deleteUser(ctx, u, list);
+    generation++;                                   // the call drops the device's last scan result even when k == 0
     for(let i = 0; i < k; i++){
       forget(list[i]);
+      retire(list[i]);
     }
   }
 
@@ -175,11 +229,13 @@ function createStore(options){
   function purgeExpiredSessions(){
     const now = Date.now();
     flush();
-    const list = new Int32Array(Math.max(rows.length, 1));
+    const list = rowList();
     const prev = lastPurge === null ? END_NONE : BigInt(lastPurge);
     const k = native.expiredQueue(ctx, prev, now, list);
+    generation++;
     for(let i = 0; i < k; i++){
       forget(list[i]);
+      retire(list[i]);
     }
     lastPurge = now;
     return undefined;
@@ -211,7 +267,7 @@ function createStore(options){
     native.setDisciplines(ctx, disciplineConfig.disciplineMask(q.disciplines), disciplineConfig.DISCIPLINES.length);
     return native.scanDevice(ctx, now, cutoff);
   }
-  let feedBuf = null;
+  var feedBuf = null;
   function userFeed(u){
     if(feedBuf === null || feedBuf.length < rows.length){
       feedBuf = new Int32Array(Math.max(rows.length, 1));
@@ -223,9 +279,10 @@ function createStore(options){
   // ordered device queue of rows with prevNow < expiresAt <= now (no change to the host map: purgeExpiredSessions does that)
   function expiredRows(prevNow, now){
     flush();
-    const list = new Int32Array(Math.max(rows.length, 1));
+    const list = rowList();
     const prev = prevNow === null || prevNow === undefined ? END_NONE : prevNow;
     const k = native.expiredQueue(ctx, prev, now, list);
+    generation++;
     return list.slice(0, k);
   }
 
@@ -233,9 +290,36 @@ function createStore(options){
   // session is at least windowMs old, users in order of first appearance, rows in table order
   function archivedRows(now, windowMs){
     flush();
-    const list = new Int32Array(Math.max(rows.length, 1));
+    const list = rowList();
     const k = native.archiveQueue(ctx, now, windowMs === undefined ? SESSION_TTL_MS : windowMs, list);
+    generation++;
     return list.slice(0, k);
+  }
+
+  // ---- batched scan: the feed requests of one event-loop turn, ONE table pass (pie_scan_batch) ------------------------
+  // queries: up to native batch size of {now, cutoff, disciplines}; -> selected rows per query.  batchUserFeed(qi, u) then
+  // reads one user's rows of query qi (two small copies), like userFeed for a single scan.
+  const BATCH_MAX = 16;
+  function scanBatchDevice(queries){
+    if(queries.length < 1 || queries.length > BATCH_MAX){ throw new Error('a batch holds 1..' + BATCH_MAX + ' queries'); }
+    flush();
+    const nows = new BigInt64Array(queries.length), cutoffs = new BigInt64Array(queries.length);
+    const masks = new BigUint64Array(queries.length);
+    queries.forEach((q, k) => {
+      nows[k] = BigInt(q.now === undefined ? Date.now() : q.now);
+      cutoffs[k] = q.cutoff === undefined ? END_NONE : BigInt(q.cutoff);
+      masks[k] = BigInt.asUintN(64, BigInt(disciplineConfig.disciplineMask(q.disciplines)));
+    });
+    native.setDisciplines(ctx, (1n << BigInt(disciplineConfig.DISCIPLINES.length)) - 1n, disciplineConfig.DISCIPLINES.length);
+    generation++;                                   // a single-scan result on the device is gone
+    return native.scanBatch(ctx, nows, cutoffs, masks);
+  }
+  function batchUserFeed(qi, u){
+    if(feedBuf === null || feedBuf.length < rows.length){
+      feedBuf = new Int32Array(Math.max(rows.length, 1));
+    }
+    const k = native.batchUserFeed(ctx, qi, u, feedBuf);
+    return feedBuf.slice(0, k);
   }
 
   function fetchRows(idx){
@@ -261,16 +345,20 @@ function createStore(options){
     const doc = JSON.parse(fs.readFileSync(path.join(dir, 'tokens.json'), 'utf8'));
     if(doc.format !== 'pie-tokens' || doc.version !== 1){ throw new Error('not a pie-tokens file'); }
     const loaded = native.loadColumnsDir(ctx, dir);
-    if(loaded.rows !== doc.rows || doc.tokenHash.length !== doc.rows){ throw new Error('tokens.json does not match the column files'); }
+    if(loaded.rows !== doc.rows || doc.tokenHash.length !== doc.rows || !Array.isArray(doc.userIds) || doc.userIds.length < loaded.users && loaded.rows > 0){
+      throw new Error('tokens.json does not match the column files');
+    }
     const n = doc.rows;
     const s = new BigInt64Array(n), e = new BigInt64Array(n), u = new Int32Array(n), d = new Int32Array(n);
     if(n > 0){ native.readColumns(ctx, s, e, u, d); }
     doc.userIds.forEach(id => denseUser(id));
     for(let i = 0; i < n; i++){
-      const gone = e[i] === END_NONE || doc.tokenHash[i] === null;
-      rows.push({tokenHash: gone ? null : doc.tokenHash[i], userId: userIds[u[i]], user: u[i], disc: d[i],
-        createdAt: Number(s[i]), expiresAt: gone ? 0 : Number(e[i])});
-      if(!gone){ rowOfToken.set(doc.tokenHash[i], i); }
+      const dead = e[i] === END_NONE;
+      const lost = dead || doc.tokenHash[i] === null;
+      rows.push({tokenHash: lost ? null : doc.tokenHash[i], userId: userIds[u[i]], user: u[i], disc: d[i],
+        createdAt: Number(s[i]), expiresAt: dead ? 0 : Number(e[i])});
+      if(dead){ rows[i].gone = true; nGone++; }
+      if(!lost){ rowOfToken.set(doc.tokenHash[i], i); }
     }
     uploaded = n;
     lastPurge = doc.lastPurge;
@@ -284,7 +372,8 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, scanDevice, userFeed, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
+    scanFeeds, scanDevice, userFeed, scanBatchDevice, batchUserFeed, BATCH_MAX, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
+    compact, compactions: () => compactions, tableRows: () => rows.length,
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,

@@ -144,6 +144,39 @@ function consumeLikeTheReference(entries){
   eq(cf.toICalendar([{id: 'x', title: 't', startTs: NaN}], {dtstamp: 0}).indexOf('VEVENT'), -1);   // non-finite start: not emitted
 }
 
+// ---- table / CSV / message builders (webhookDispatcher.js:276-342; hand-derived vectors — parity unpinned: that module does
+// not load on Node 12; the three self-consistency checks are the ones /root/reference/scripts/simulate-webhook.js:71-95 makes)
+{
+  const dq = require('../dispatchQueue');
+  // csvEscape :332-338
+  eq(dq.csvEscape(null), ''); eq(dq.csvEscape(undefined), ''); eq(dq.csvEscape(0), '0'); eq(dq.csvEscape(false), 'false');
+  eq(dq.csvEscape('plain text'), 'plain text');
+  eq(dq.csvEscape('a,b'), '"a,b"');
+  eq(dq.csvEscape('say "hi"'), '"say ""hi"""');
+  eq(dq.csvEscape('line\nbreak'), '"line\nbreak"');
+  eq(dq.csvEscape('cr\rhere'), '"cr\rhere"');
+  eq(dq.csvEscape('"'), '""""');
+  eq(dq.csvEscape(' semi;colon '), ' semi;colon ');
+  const payload = {sessionRow: 0, userId: 'Smith, "Al"', discipline: 'drones', createdAt: '2025-01-02T03:04:05.006Z', expiredAt: ''};
+  const row = dq.buildTableRow(payload);
+  eq(row, {sessionRow: 0, userId: 'Smith, "Al"', discipline: 'drones', createdAt: '2025-01-02T03:04:05.006Z', expiredAt: ''});   // 0 stays 0 (delaySec rule :299)
+  eq(dq.buildTableRow({}), {sessionRow: '', userId: '', discipline: '', createdAt: '', expiredAt: ''});
+  eq(dq.buildTableRow(), {sessionRow: '', userId: '', discipline: '', createdAt: '', expiredAt: ''});
+  eq(dq.buildCsvRow(row), '0,"Smith, ""Al""",drones,2025-01-02T03:04:05.006Z,');
+  eq(dq.buildMessagePayload({sessionRow: 5, userId: null}), {sessionRow: 5, userId: '', discipline: '', createdAt: '', expiredAt: ''});
+  const entry = dq.buildEntryPayload('session.expired', payload, '2025-02-02T00:00:00.000Z');
+  // simulate-webhook.js:76-95: the table row follows the export column order of the row object, the message mirrors it,
+  // the CSV header is the column list
+  eq(JSON.stringify(entry.table.row), JSON.stringify(dq.EXPORT_COLUMNS.map(c => (row[c] === undefined || row[c] === null ? '' : row[c]))));
+  eq(JSON.stringify(entry.message), JSON.stringify(dq.buildMessagePayload(row)));
+  eq(JSON.stringify(entry.csv.header), JSON.stringify(dq.EXPORT_COLUMNS));
+  eq([entry.event, entry.schemaVersion, entry.dispatchedAt, entry.csv.row], ['session.expired', 2, '2025-02-02T00:00:00.000Z', dq.buildCsvRow(row)]);
+  const queue = dq.buildQueuePayload('session.archived', [payload, {sessionRow: 7, userId: 'u7', discipline: '', createdAt: 'x', expiredAt: 'y'}], 'T');
+  eq(queue.table.rows, [[0, 'Smith, "Al"', 'drones', '2025-01-02T03:04:05.006Z', ''], [7, 'u7', '', 'x', 'y']]);
+  eq(queue.csv.rows, ['0,"Smith, ""Al""",drones,2025-01-02T03:04:05.006Z,', '7,u7,,x,y']);
+  eq(queue.message.entries.length, 2); eq(queue.table.columns, dq.EXPORT_COLUMNS);
+}
+
 // ---- fetchCalendarFeed never rejects
 (async () => {
   eq(await cf.fetchCalendarFeed(''), []);

@@ -371,6 +371,136 @@ function get(port, cookie){
     eq([sum2.success, sum2.total], [true, expectRows.length]);
     store.close();
   }
+  // ---- 5. rows are reclaimed; a session that getSession() found expired still reaches the dispatch queue
+  {
+    const store = createStore({compactMinRows: 64});
+    const base = 1770000000000;
+    const toks = [];
+    for(let i = 0; i < 200; i++){ fakeNow = base + i * 1000; toks.push(store.createSession('u' + (i % 9)).token); }
+    store.flush();
+    eq(store.tableRows(), 200);
+    // sessions 0..9 expire and are looked up (the lookup drops them from the map, as the reference's getSession does)
+    fakeNow = base + 9 * 1000 + store.SESSION_TTL_MS;
+    for(let i = 0; i < 10; i++){ eq(store.getSession(toks[i]), null); }
+    eq(store.size(), 190);
+    eq(Array.from(store.expiredRows(null, fakeNow)), [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]);   // still in the queue: `end` kept
+    // explicit deletes and a user delete retire rows; once they outweigh the live rows the table is compacted
+    for(let i = 10; i < 120; i++){ store.deleteSession(toks[i]); }
+    eq(store.compactions(), 0);
+    store.purgeExpiredSessions();                                  // its flush compacts (110 of 200 rows are gone), then it
+    eq(store.compactions(), 1);                                    // reports + retires the ten expired rows
+    eq(store.tableRows(), 90);
+    const before = store.scanFeeds({now: fakeNow});
+    eq(before.m, 80);
+    store.createSession('fresh');
+    const after = store.scanFeeds({now: fakeNow});
+    eq(store.tableRows(), 91);
+    eq(after.m, 81);
+    eq(Array.from(store.expiredRows(null, fakeNow)), [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]);   // the queue itself forgets nothing
+    for(let i = 120; i < 200; i++){ const sess = store.getSession(toks[i]); eq(sess !== null && sess.userId === 'u' + (i % 9), true); }
+    for(let i = 0; i < 120; i += 17){ eq(store.getSession(toks[i]), null); }
+    // feeds after compaction: every live session of u3, ascending by createdAt
+    const feeds = createFeedService(store).allFeeds({now: fakeNow, cutoff: 0});
+    eq(feeds.get('u3').map(ev => ev.startTs), toks.map((t, i) => i).filter(i => i >= 120 && i % 9 === 3).map(i => base + i * 1000));
+    store.close();
+  }
+
+  // ---- 6. the requests of one turn, ONE table pass: batched bodies == per-request bodies; HTTP coalescing
+  {
+    const store = createStore();
+    const base = 1780000000000;
+    const toks = {};
+    for(let i = 0; i < 3000; i++){
+      fakeNow = base + i * 977;
+      const uid = 'user-' + (i % 37);
+      const t = store.createSession(uid, dc.DISCIPLINES[i % dc.DISCIPLINES.length].id).token;
+      if(toks[uid] === undefined){ toks[uid] = t; }
+    }
+    const feedsA = createFeedService(store), feedsB = createFeedService(store);
+    const t1 = base + 3000 * 977 + 5;
+    const requests = [];
+    for(let k = 0; k < 40; k++){
+      requests.push({userId: 'user-' + (k % 37), query: {now: t1 + (k % 19) * 1000, cutoff: base + (k % 3) * 100000, disciplines: k % 4 === 0 ? ['drones', 'audio'] : undefined}});
+    }
+    requests.push({userId: 'nobody', query: {now: t1, cutoff: 0}});
+    fakeNow = t1;
+    const bodies = feedsA.eventsJsonForRequests(requests);
+    eq(feedsA.batchesRun() >= 2, true);                            // 19 x 3 x 2 distinct keys at most 16 per batch
+    requests.forEach((r, i) => { eq(bodies[i].equals(feedsB.eventsJsonForUser(r.userId, r.query)), true, 'request ' + i); });
+    eq(bodies[40].toString(), '{"events":[]}');
+    // over HTTP: concurrent requests are answered from one batch
+    const users = new Map();
+    for(let u = 0; u < 37; u++){ users.set('user-' + u, {id: 'user-' + u, roles: ['drones.crew']}); }
+    const feedsC = createFeedService(store);
+    const server = createServer({store, findUserById: id => users.get(id) || null, feeds: feedsC, coalesce: true,
+      query: () => ({now: t1, cutoff: base})});
+    await new Promise(r => server.listen(0, '127.0.0.1', r));
+    const port = server.address().port;
+    const names = Array.from(users.keys()).slice(0, 12);
+    const answers = await Promise.all(names.map(nm => get(port, 'mt_session=' + toks[nm])));
+    const plain = createFeedService(store);
+    answers.forEach((a, i) => {
+      eq(a.status, 200);
+      eq(JSON.stringify(a.body), plain.eventsJsonForUser(names[i], {now: t1, cutoff: base}).toString());
+    });
+    eq(feedsC.batchesRun() >= 1 && feedsC.batchesRun() <= 12, true);
+    eq((await get(port, null)).status, 401);
+    await new Promise(r => server.close(r));
+    // CSV of a queue: native bytes == the JS builders
+    const dq = require('../dispatchQueue');
+    const rowsQ = store.expiredRows(null, base + 500 * 977 + store.SESSION_TTL_MS);
+    eq(rowsQ.length, 501);
+    const cols = store.fetchRows(rowsQ);
+    const lines = [dq.EXPORT_COLUMNS.join(',')];
+    for(let i = 0; i < rowsQ.length; i++){ lines.push(dq.buildCsvRow(dq.buildTableRow(dq.buildExpiredSessionPayload(rowsQ[i], cols, i, store.userIds())))); }
+    eq(dq.queueCsv(store, rowsQ).toString('utf8') === lines.join('\n'), true, 'native CSV bytes');
+    const odd = ['plain', 'comma, inside', 'quote " inside', 'new\nline', ''];
+    const got = store.native.serializeCsv(Int32Array.from([5, 6, 7, 8, 9]), 5, cols.start, cols.end, Int32Array.from([0, 1, 2, 3, 4]), cols.disc, odd,
+      dc.DISCIPLINES.map(d => d.id), dq.EXPORT_COLUMNS.join(','));
+    const wantOdd = [dq.EXPORT_COLUMNS.join(',')];
+    for(let i = 0; i < 5; i++){ wantOdd.push(dq.buildCsvRow(dq.buildTableRow(dq.buildExpiredSessionPayload(5 + i, {start: cols.start, end: cols.end, user: Int32Array.from([0, 1, 2, 3, 4]), disc: cols.disc}, i, odd)))); }
+    eq(got.toString('utf8'), wantOdd.join('\n'));
+    store.close();
+  }
+
+  // ---- 7. the communicator through the addon (one GPU on this box: a world of one shard): batch + exchange == single scans
+  {
+    const native = require('../pieNative').load();
+    const comm = native.commCreate(Int32Array.from([0]));
+    eq(native.commWorld(comm), 1);
+    const n = 300000, U = 2000, D = 7;
+    native.commGenSyntheticSharded(comm, 0x5EED5EED, n, U, D, 0);
+    const shard = native.commCtx(comm, 0);
+    native.setDisciplines(shard, 127n, D);
+    const T0 = 1700000000000;
+    const nows = BigInt64Array.from([BigInt(T0 - 6 * 3600000), BigInt(T0 - 7 * 3600000), BigInt(T0 - 30 * 86400000)]);
+    const cuts = BigInt64Array.from([BigInt(T0 - 61 * 86400000), 0n, BigInt(T0 - 40 * 86400000)]);
+    const masks = BigUint64Array.from([0x55n, 0x7Fn, 0x2An]);
+    const ms = native.commScanBatchGather(comm, nows, cuts, masks);
+    const uPad = native.commUPad(comm, 0);
+    eq(uPad, U);
+    const single = native.ctxCreate(0);
+    native.genSynthetic(single, 0x5EED5EED, n, 0, n, U, D, 0);
+    for(let q = 0; q < 3; q++){
+      native.setDisciplines(single, masks[q], D);
+      const counts = new Int32Array(U), offsets = new BigInt64Array(U + 1), idx = new Int32Array(n);
+      const m = native.scan(single, nows[q], cuts[q], counts, offsets, idx);
+      eq(ms[0][q], m);
+      const off = new Int32Array(uPad + 1), rows = new Int32Array(Math.max(m, 1));
+      eq(native.commReadGathered(comm, 0, 0, q, off, rows), m);
+      eq(Array.from(off), Array.from(offsets, Number));
+      eq(Buffer.from(rows.buffer, 0, m * 4).equals(Buffer.from(idx.buffer, 0, m * 4)), true);
+    }
+    // handles: a destroyed context throws instead of touching freed memory; short output arrays are refused
+    assert.throws(() => native.scan(single, nows[0], cuts[0], new Int32Array(U - 1), new BigInt64Array(U + 1), new Int32Array(n)), /Int32Array\[>= users\]/);
+    assert.throws(() => native.scan(single, nows[0], cuts[0], new Int32Array(U), new BigInt64Array(U), new Int32Array(n)), /users \+ 1/);
+    native.ctxDestroy(single);
+    assert.throws(() => native.scanDevice(single, nows[0], cuts[0]), e => e.code === -6);
+    checks += 3;
+    native.commDestroy(comm);
+    assert.throws(() => native.commWorld(comm), /communicator/);
+    checks++;
+  }
   Date.now = realNow;
   console.log('host gpu_test ok: ' + checks + ' checks');
 })().catch(err => { console.error(err); process.exit(1); });

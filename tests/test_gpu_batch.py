@@ -295,3 +295,42 @@ def test_exchange_over_rccl_one_rank(pie, oracle):
                     assert np.array_equal(res["rows"][0, q].cpu().numpy()[:m], w[2])
     finally:
         dist.destroy_process_group()
+
+
+def test_communicator_behind_the_c_abi(pie, oracle):
+    """pie_comm_*: the sharded table + RCCL exchange through the C ABI alone (what the Node addon binds), on this box's one
+    GPU: a single-process communicator of one shard and a process-per-GPU communicator of world 1 (unique id path).  The
+    gathered messages (grouped ncclSend / ncclRecv, own message by local copy) equal the oracle's answers per query."""
+    n, U, D = 500009, 3001, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    queries = mixed_queries(oracle, 5) + [(oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, ALL)]
+    wants = oracle_answers(oracle, cols, U, D, queries)
+
+    def check(comm, u_pad):
+        ctx = comm.ctx(0)
+        assert (ctx.n, ctx.n_users) == (n, U)
+        ctx.set_disciplines(ALL, D)
+        for _ in range(2):
+            ms = comm.scan_batch_gather(queries, u_pad)
+            assert ms == [[int(w[2].size) for w in wants]]
+            for q, w in enumerate(wants):
+                off, idx = comm.read_gathered(0, 0, q)
+                assert np.array_equal(off[: U + 1], w[1].astype(np.int32)) and np.all(off[U + 1:] == w[2].size)
+                assert np.array_equal(idx, w[2])
+        # the shard's context is an ordinary scan context
+        ctx.set_disciplines(queries[0][2], D)
+        got = ctx.scan(queries[0][0], queries[0][1])
+        assert np.array_equal(got[2], wants[0][2])
+
+    with pie.PieComm([0]) as comm:
+        assert comm.world == 1
+        comm.gen_synthetic_sharded(SEED, n, U, D, 0)
+        check(comm, 0)
+    uid = pie.PieComm.unique_id()
+    assert len(uid) == 128
+    with pie.PieComm.for_rank(uid, 0, 1, 0) as comm:
+        comm.gen_synthetic_sharded(SEED, n, U, D, 0)
+        comm.reserve(len(queries), U + 3, max(int(w[2].size) for w in wants) + 5)
+        check(comm, U + 3)
+    with pytest.raises(pie.PieError):
+        pie.PieComm([0, 0])
