@@ -172,6 +172,30 @@ def add_months(ts, months, tz_offset_ms=0):
     return None if nan.value else v
 
 
+def calendar_cutoff(now_ms, months_back=2, tz="UTC"):
+    """Restatement of the window scalar, /root/reference/server/calendarFeed.js:33-38: local midnight of `now` in zone
+    `tz`, minus months_back calendar months with JS Date rules — the month shift is applied to the LOCAL fields of the
+    midnight instant (on a day whose midnight does not exist, a DST change at 00:00, that instant reads 01:00 and the
+    hour is kept), day-of-month overflow rolls into the following month (Apr 30 - 2 -> "Feb 30" -> Mar 2).  A different
+    engine (Python zoneinfo) from the one that produced the pin, tests/golden/cutoff_zones.json (JS Date, oracle/
+    gen_cutoff_golden.js)."""
+    import datetime
+    import zoneinfo
+    z = zoneinfo.ZoneInfo(tz)
+    epoch = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc)
+    at = lambda ms: (epoch + datetime.timedelta(milliseconds=int(ms))).astimezone(z)
+    to_ms = lambda d: (d - epoch) // datetime.timedelta(milliseconds=1)
+    dt = at(now_ms)
+    midnight = datetime.datetime(dt.year, dt.month, dt.day, tzinfo=z)           # setHours(0, 0, 0, 0)
+    lt = at(to_ms(midnight))                                                    # what the Date now reads in local time
+    mi = (lt.month - 1) - int(months_back)                                      # setMonth(getMonth() - monthsBack)
+    y = lt.year + mi // 12
+    mi %= 12
+    day = datetime.date(y, mi + 1, 1) + datetime.timedelta(days=lt.day - 1)     # MakeDay: day overflow rolls over
+    local = datetime.datetime(day.year, day.month, day.day, lt.hour, lt.minute, lt.second, tzinfo=z)
+    return to_ms(local)
+
+
 def retention_queue(start, end, now, months=2, tz_offset_ms=0):
     start, end = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(end, np.int64)
     n = start.shape[0]

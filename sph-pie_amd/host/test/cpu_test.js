@@ -13,7 +13,10 @@ let checks = 0;
 const ok = (cond, msg) => { assert.ok(cond, msg); checks++; };
 const eq = (a, b, msg) => { assert.deepStrictEqual(a, b, msg); checks++; };
 
-// ---- H5 discipline table
+// ---- H5 discipline table, role keys and normalisation (SURVEY.md 8a rows a7 - a10: disciplineConfig.js:18-37, 39-146).
+// PARITY UNPINNED for a9 (parseRoleKey / roleMatches*) and a10 (getRoleKey / listRoleKeys / normalizeRole / getDisplayName):
+// /root/reference/server/disciplineConfig.js does not parse on this image's Node 12 (`?.` at :59) and the reference holds
+// no fixture for it, so these vectors are hand-derived from the cited lines, never reference output.
 const g = golden.disciplines;
 eq(dc.DISCIPLINES.map(d => d.id), g.ids);
 eq(dc.ROLE_LEVELS, g.roles);
@@ -39,7 +42,8 @@ eq(dc.disciplineMask('drones'), 16n);
 eq(dc.disciplineMask('*'), 127n);
 eq(dc.disciplineMask(['audio', 'nope', ' Broadcast ']), 65n);
 
-// ---- cutoff (calendarFeed.js:33-38) under TZ=UTC, incl. month-overflow cases
+// ---- cutoff (a11: calendarFeed.js:33-38) under TZ=UTC, incl. month-overflow cases (hand-derived); the JS-engine-made
+// vectors for seven real zones (tests/golden/cutoff_zones.json) are replayed per zone by tests/test_node_host.py
 for(const c of golden.cutoff_cases_tz_utc){
   eq(cf.getCalendarCutoffTimestamp(c.months_back, c.now_ms), c.expect_ms, 'cutoff ' + c.now_iso);
   eq(new Date(cf.getCalendarCutoffTimestamp(c.months_back, c.now_ms)).toISOString().replace('.000Z', 'Z'), c.expect_iso);
@@ -47,7 +51,8 @@ for(const c of golden.cutoff_cases_tz_utc){
 eq(cf.getCalendarCutoffTimestamp(undefined, golden.cutoff_cases_tz_utc[0].now_ms), golden.cutoff_cases_tz_utc[0].expect_ms);
 ok(cf.getCalendarCutoffTimestamp() <= Date.now());
 
-// ---- title metadata (calendarFeed.js:15-31)
+// ---- title metadata (a13: calendarFeed.js:15-31, module-private there).  PARITY UNPINNED: calendarFeed.js does not load here
+// (`?.` at :19, node-ical absent) and the reference has no fixture; vectors hand-derived from the cited lines.
 eq(cf.parseCalendarMetadata('Eagles #12 load-in'), {eventName: 'EAGLES', showNumber: 12, color: '#3b82f6'});
 eq(cf.parseCalendarMetadata('woz show 7 rehearsal 9'), {eventName: 'WOZ', showNumber: 7, color: '#22c55e'});
 eq(cf.parseCalendarMetadata('Zac Brown Band: Love and Fear # 3'), {eventName: 'ZAC', showNumber: 3, color: '#ef4444'});

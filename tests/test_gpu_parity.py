@@ -806,9 +806,41 @@ def test_full_size_properties_1e8(gpu_ctx, oracle):
     # idempotence: the same query again gives the same bytes
     c2, o2, i2 = gpu_ctx.scan(now, cutoff)
     assert np.array_equal(c2, counts) and np.array_equal(i2, idx)
-    # exact check against the oracle in slices of 10^7 rows: slice-local feeds must be the sub-sequences
-    base = 3 * 10 ** 7
-    sl = oracle.gen(SEED, n, base, 10 ** 7, U, D, 0)
-    wc, wo, wi = oracle.scan(*sl, U, now, cutoff, mask & ((1 << D) - 1))
-    in_slice = (idx >= base) & (idx < base + 10 ** 7)
-    assert np.array_equal(idx[in_slice] - base, wi)      # same relative order (user, start, row) inside the slice
+    # exact check against the oracle over the WHOLE table (the multi-thread form of the oracle, itself checked against the
+    # single-thread one in test_oracle_golden.py): counts, offsets and every row index, exact M
+    cols = oracle.gen_mt(SEED, n, 0, n, U, D, 0, threads=16)
+    wc, wo, wi = oracle.scan_mt(*cols, U, now, cutoff, mask & ((1 << D) - 1), 16)
+    assert wi.size == m
+    assert np.array_equal(counts, wc) and np.array_equal(offsets, wo) and np.array_equal(idx, wi)
+    # the batched scan at full size: 16 queries, one table pass, each equal to the oracle's answer for it
+    queries = [(now - 977 * q, cutoff - (q % 3) * DAY, (mask, 0xAAAAAAAAAAAAAAAA, ALL)[q % 3]) for q in range(16)]
+    gpu_ctx.set_disciplines(ALL, D)
+    got = gpu_ctx.scan_batch(queries)
+    for q, (qn, qc, qm) in enumerate(queries):
+        w = oracle.scan_mt(*cols, U, qn, qc, qm & ((1 << D) - 1), 16)
+        for a, b in zip(got[q], w):
+            assert np.array_equal(a, b), q
+    # config 5 at full size: the expired-session dispatch queue (change predicate prev < end <= now) exact against the oracle
+    # for a one-day and a one-month window, and the archive group-min chain by its defining properties + exact against numpy
+    e_col = cols[1]
+    for prev, nw in [(oracle.T0_MS - 30 * DAY, oracle.T0_MS - 29 * DAY), (oracle.T0_MS - 90 * DAY, oracle.T0_MS - 60 * DAY), (INT64_MIN, oracle.T0_MS - 119 * DAY)]:
+        q_gpu = gpu_ctx.expired_queue(prev, nw)
+        assert np.array_equal(q_gpu, oracle.expired_queue(e_col, prev, nw))
+    window = 3600 * 1000
+    now_a = oracle.T0_MS - 120 * DAY + 2 * window           # a user qualifies iff it has a session in the corpus' first hour: ~29 %
+    q_arch = gpu_ctx.archive_queue(now_a, window)
+    s_col, u_col = cols[0], cols[2]
+    earliest = np.full(U, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(earliest, u_col, s_col)
+    qual = (now_a - earliest) >= window
+    assert 0.2 < qual.mean() < 0.4
+    assert q_arch.size == int(np.count_nonzero(qual[u_col]))                 # every row of every qualifying group, nothing else
+    assert np.all(qual[u_col[q_arch]]) and np.unique(q_arch).size == q_arch.size
+    first = np.full(U, n, np.int64)
+    np.minimum.at(first, u_col, np.arange(n, dtype=np.int64))
+    grp = u_col[q_arch]
+    change = np.nonzero(np.diff(grp) != 0)[0] + 1
+    heads = np.r_[0, change]
+    assert np.unique(grp[heads]).size == heads.size                           # each group is one contiguous run
+    assert np.all(np.diff(first[grp[heads]]) > 0)                             # groups in order of first appearance
+    assert np.all((np.diff(q_arch) > 0) | (np.diff(grp) != 0))                # table order inside a group

@@ -30,6 +30,24 @@ def test_addon_builds_and_host_logic_cpu(pie):
 
 
 @needs_node
+def test_host_cutoff_matches_js_date_vectors_in_every_zone():
+    """a11: host/calendarFeed.js getCalendarCutoffTimestamp under each of the seven zones of tests/golden/cutoff_zones.json
+    (one node process per TZ: Node 12 reads TZ once) gives the vectors' values — the same vectors that pin the Python
+    restatement in test_oracle_golden.py."""
+    import json
+    doc = json.load(open(os.path.join(REPO, "tests", "golden", "cutoff_zones.json")))
+    script = ("const cf=require('./sph-pie_amd/host/calendarFeed.js');"
+              "const z=JSON.parse(require('fs').readFileSync('tests/golden/cutoff_zones.json','utf8')).zones[process.env.TZ];"
+              "let bad=0;for(const [now,back,want] of z){if(cf.getCalendarCutoffTimestamp(back,now)!==want){bad++;}}"
+              "console.log(z.length+' '+bad)")
+    for tz in doc["zones"]:
+        res = subprocess.run([node, "-e", script], cwd=REPO, env=dict(os.environ, TZ=tz), stdout=subprocess.PIPE, text=True,
+                             timeout=60, check=True)
+        n, bad = res.stdout.split()
+        assert int(n) == len(doc["zones"][tz]) and int(bad) == 0, (tz, res.stdout)
+
+
+@needs_node
 def test_reference_faithful_js_matches_c_oracle(oracle):
     """The JS restatement (bench baseline B1 + checker of the Node GPU test) agrees with the C oracle."""
     script = ("const r=require('./oracle/ref_faithful.js');const rows=r.genCorpus(0x5EED5EEDn,1000,10,3);"

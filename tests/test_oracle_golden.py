@@ -210,3 +210,40 @@ def test_g5_reference_trace_on_the_oracle(oracle):
     from trace_replay import OracleTable, load_trace, replay
     trace = load_trace(GOLDEN)
     assert replay(trace, OracleTable(oracle, len(trace["users"]))) == len(trace["ops"]) > 1300
+
+
+def test_calendar_cutoff_matches_js_date_vectors(oracle):
+    """a11, the window scalar (/root/reference/server/calendarFeed.js:33-38): the Python restatement (zoneinfo) against
+    4 634 vectors produced by the JS engine's own Date under seven real time zones (tests/golden/cutoff_zones.json,
+    oracle/gen_cutoff_golden.js): month-end overflow, leap years, DST change days of both hemispheres, a zone whose
+    midnight does not exist on the change day (the hour the Date then reads is kept by setMonth), a zone that skipped a
+    calendar day (Pacific/Apia, 2011-12-30).  The reference function itself cannot be imported here (node-ical, Node >= 14):
+    the pin is on the engine semantics its three Date calls rely on."""
+    doc = json.load(open(os.path.join(GOLDEN, "cutoff_zones.json")))
+    assert len(doc["zones"]) == 7
+    n = 0
+    for tz, cases in doc["zones"].items():
+        for now, back, want in cases:
+            assert oracle.calendar_cutoff(now, back, tz) == want, (tz, now, back)
+            n += 1
+    assert n >= 4000
+    # the hand-derived H4 cases agree with the engine-made ones
+    h = json.load(open(os.path.join(GOLDEN, "hand_derived_h1_h5.json")))
+    for c in h["cutoff_cases_tz_utc"]:
+        assert oracle.calendar_cutoff(c["now_ms"], c["months_back"], "UTC") == c["expect_ms"]
+
+
+def test_multithread_oracle_equals_single_thread(oracle):
+    """bench.py's cpu_baseline B2 leg: pie_oracle_scan_mt (rows split over threads, per-user prefix over the threads, buckets
+    ordered in parallel) gives pie_oracle_scan's bytes; pie_oracle_gen_mt the generator's."""
+    n, U, D = 300007, 977, 32
+    cols = oracle.gen(0x5EED5EED, n, 0, n, U, D, 1)
+    for a, b in zip(cols, oracle.gen_mt(0x5EED5EED, n, 0, n, U, D, 1, threads=5)):
+        assert np.array_equal(a, b)
+    T0 = oracle.T0_MS
+    for now, cutoff, mask in [(T0 - 6 * 3600 * 1000, T0 - 61 * 86400 * 1000, 0x55555555), (INT64_MIN, INT64_MIN, ALL), (2 ** 62, INT64_MIN, ALL)]:
+        want = oracle.scan(*cols, U, now, cutoff, mask & 0xFFFFFFFF)
+        for threads in (1, 3, 8):
+            got = oracle.scan_mt(*cols, U, now, cutoff, mask & 0xFFFFFFFF, threads)
+            for x, y in zip(got, want):
+                assert np.array_equal(x, y)
