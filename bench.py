@@ -184,9 +184,12 @@ def main():
     ap.add_argument("--profile-every", type=int, default=0,
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
                          "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
-    ap.add_argument("--mode", choices=["scan", "expired"], default="scan",
+    ap.add_argument("--mixed-rows", type=int, default=1000, help="--mode mixed: sessions created and sessions touched per step")
+    ap.add_argument("--mode", choices=["scan", "expired", "mixed"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
-                         "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic)")
+                         "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic); mixed: every step "
+                         "creates --mixed-rows sessions (append) and touches as many (set_end) before its scan: the upkeep of the "
+                         "derived key columns inside the timed region")
     ap.add_argument("--queries-per-launch", type=int, default=16,
                     help="every step is ONE batched scan of Q queries (Q feed requests, each with its own `now`, answered by one table "
                          "pass: pie_scan_batch_*); value counts Q x U feeds per step; 1 = one query per step (single_query reports that "
@@ -281,6 +284,28 @@ def main():
             for _ in range(k):
                 last = ctx.expired_queue(expired_window[0], expired_window[1], fetch=False)
             return last
+        if args.mode == "mixed":
+            # a live server between two feed scans: logins (createSession -> append) and touches (touchSession -> set_end),
+            # then one scan at the step's own clock; one scan at a time (table changes need an idle context)
+            kk = args.mixed_rows
+            for _ in range(k):
+                mixed_state["step"] += 1
+                t_step = now + mixed_state["step"] * 1000
+                t_a = time.perf_counter()
+                st_new = np.full(kk, t_step, np.int64) - mixed_state["rng"].integers(0, 1000, kk)
+                ctx.append_rows(st_new, st_new + 43200000, mixed_state["rng"].integers(0, u_local, kk).astype(np.int32),
+                                mixed_state["rng"].integers(0, D, kk).astype(np.int32), u_local)
+                t_b = time.perf_counter()
+                rows = mixed_state["rng"].integers(0, ctx.n, kk).astype(np.int32)
+                ctx.set_end(rows, np.full(kk, t_step + 43200000, np.int64))
+                t_c = time.perf_counter()
+                last = ctx.scan_device(t_step, cutoff)
+                t_d = time.perf_counter()
+                mixed_state["append_s"] += t_b - t_a
+                mixed_state["touch_s"] += t_c - t_b
+                mixed_state["scan_s"] += t_d - t_c
+                mixed_state["n"] += 1
+            return last
         if not gather:
             if Q > 1:
                 return ctx.scan_batch_pipelined(k, batch_queries)
@@ -298,6 +323,10 @@ def main():
         if last is None:  # a row list outgrew the message: capacity was raised, redo synchronously once
             last = feeds.scan_and_gather(now, cutoff)
         return last
+
+    mixed_state = {"step": 0, "append_s": 0.0, "touch_s": 0.0, "scan_s": 0.0, "n": 0, "rng": None}
+    if args.mode == "mixed":
+        mixed_state["rng"] = np.random.default_rng(SEED)
 
     def fence():
         ctx.synchronize()
@@ -322,15 +351,20 @@ def main():
     run_steps(max(args.warmup, 1))
     fence()
     ctx.stats_reset()
+    mixed_state.update({"append_s": 0.0, "touch_s": 0.0, "scan_s": 0.0, "n": 0})
     # HIP events around the scan kernels, on the stream they are launched on; every 16th step (at least three per region)
     # carries them (an event between two kernels drains the pipeline for a few microseconds)
     profile_every = args.profile_every if args.profile_every > 0 else max(1, min(16, args.steps // 3))
     ctx.set_profiling(1 if args.mode == "expired" else profile_every)
     region_ms, kernel_ms_regions, scan_ms_regions, n_prof = [], [], [], 0
     last = None
+    mixed_regions = []
     for _ in range(max(args.repeat, 1)):
+        mixed_state.update({"append_s": 0.0, "touch_s": 0.0, "scan_s": 0.0, "n": 0})
         dt, last = timed_region(run_steps, args.steps)
         region_ms.append(dt * 1e3 / args.steps)
+        if mixed_state["n"]:
+            mixed_regions.append({k: mixed_state[k] * 1e3 / mixed_state["n"] for k in ("append_s", "touch_s", "scan_s")})
         st = ctx.stats()
         if st["n_profiled"]:
             kernel_ms_regions.append(st["k1_ms_sum"] / st["n_profiled"])
@@ -413,12 +447,13 @@ def main():
             model = n_local * (24 if not variant & 2 else 20) + int(m) * (64 + 4 + (4 if variant & 2 else 0)) + u_local * 12
         basis = traffic if traffic else model
         achieved = (basis / (k1_ms * 1e-3) / 1e9) if basis and k1_ms > 0 else None
-        per_step_units = (tot_users * (Q if batch_ms is not None else 1) if args.mode == "scan" else tot_rows)
+        per_step_units = (tot_users * (Q if batch_ms is not None else 1) if args.mode in ("scan", "mixed") else tot_rows)
         line = {
             "metric": "feeds/sec + sessions scanned/sec, 10^8 synthetic sessions, 1/2/4/8 MI355X" if args.mode == "scan" else
+                      "mixed workload: per step %d sessions created + %d touched + one feed scan; feeds/sec" % (args.mixed_rows, args.mixed_rows) if args.mode == "mixed" else
                       "expired-queue pass (SURVEY 8f-1): sessions scanned/sec; value counts table rows, not feeds",
             "value": per_step_units / (ms_per_step * 1e-3),
-            "unit": "feeds/s" if args.mode == "scan" else "sessions/s",
+            "unit": "feeds/s" if args.mode in ("scan", "mixed") else "sessions/s",
             "sessions_per_sec": tot_rows * (Q if batch_ms is not None else 1) / (ms_per_step * 1e-3),
             "queries_per_launch": Q if batch_ms is not None else 1,
             "table_passes_per_sec": 1.0 / (ms_per_step * 1e-3),
@@ -471,6 +506,13 @@ def main():
                               "writer of `end`; index_build_ms = one full build on this table"},
         }
 
+    if rank == 0 and args.mode == "mixed" and mixed_regions:
+        med = lambda k: statistics.median(r[k] for r in mixed_regions)
+        line["mixed"] = {"append_ms": med("append_s"), "touch_ms": med("touch_s"), "scan_ms": med("scan_s"),
+                         "per_region": mixed_regions, "rows_per_step": args.mixed_rows, "table_rows_now": ctx.n,
+                         "note": "host wall time per step: append = pie_append_rows (H2D of the new rows + their keys / payload records), "
+                                 "touch = pie_set_end (H2D of the row list + the kernel that rewrites end and both keys), scan = one "
+                                 "synchronous scan; the key columns stay in step, so the scan keeps its keyed form"}
     gpu_result = None
     if world == 1 and args.mode == "scan" and not gather and not args.no_extra and Q > 1:
         # ---- one query per step (the unit SURVEY.md 8d defines: one scan = one query over all N rows), two scans in flight

@@ -2608,10 +2608,13 @@ __global__ __launch_bounds__(256) void k_sort_small(const Segment* __restrict__ 
     }
 }
 
-// K4c: one merge pass over every big bucket: sorted runs of `width` -> sorted runs of ways*width (4-way passes halve
-// the number of launches, and a pass is all launch + search latency).  Each thread owns one input element,
-// binary-searches its rank in the sibling runs, and stores it at its final slot
-// (keys are unique, so ranks are a permutation).  grid.y indexes big_list.
+// K4c: one merge pass over every big bucket: sorted runs of `width` -> sorted runs of ways*width, ways <= kMergeWays.
+// Each thread owns one input element and binary-searches its rank in the sibling runs of its group; its place in the
+// merged group = its place in its own run + the number of smaller keys in every other run (keys are unique, so ranks are
+// a permutation).  The searches of one element advance in LOCKSTEP — one probe per sibling run and step, all independent
+// loads — so a 16-way pass costs about one search's latency chain (log2(width) dependent L2 loads), not sixteen: a bucket
+// of up to 16 x 4096 rows (a Zipf head user) is merged by ONE launch instead of two 4-way ones.  grid.y indexes big_list.
+constexpr int kMergeWays = 16;
 __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_list, int n_big, const int* __restrict__ counts,
                                                     const long long* __restrict__ offsets, long long width, int ways,
                                                     const BktRec* __restrict__ src, BktRec* __restrict__ dst,
@@ -2623,23 +2626,36 @@ __global__ __launch_bounds__(256) void k_merge_pass(const int* __restrict__ big_
         for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
             const long long run = p / width;
             const long long group0 = (run / ways) * ways * width; // first slot of this group of `ways` runs
+            const int my_r = (int)(run - (run / ways) * ways);
             const BktRec me = src[o + p];
-            // keys are unique, so my place in the merged group = my place in my run + the number of smaller keys in every
-            // other run of the group (independent binary searches)
-            long long smaller = 0;
-            for (int r = 0; r < ways; ++r) {
+            int lo[kMergeWays], hi[kMergeWays];
+#pragma unroll
+            for (int r = 0; r < kMergeWays; ++r) {
                 const long long r0 = group0 + (long long)r * width;
-                if (r0 == run * width || r0 >= n) continue;
                 long long rn = n - r0;
-                if (rn > width) rn = width;
-                long long lo = 0, hi = rn;
-                while (lo < hi) {
-                    const long long mid = (lo + hi) >> 1;
-                    const BktRec x = src[o + r0 + mid];
-                    if (key_less(x.start, x.idx, me.start, me.idx)) lo = mid + 1; else hi = mid;
-                }
-                smaller += lo;
+                rn = rn > width ? width : rn;
+                lo[r] = 0;
+                hi[r] = (r < ways && r != my_r && rn > 0) ? (int)rn : 0; // an empty range: nothing to search
             }
+            bool more = true;
+            while (more) {
+                more = false;
+                BktRec x[kMergeWays];
+#pragma unroll
+                for (int r = 0; r < kMergeWays; ++r)
+                    if (lo[r] < hi[r]) x[r] = src[o + group0 + (long long)r * width + ((lo[r] + hi[r]) >> 1)];
+#pragma unroll
+                for (int r = 0; r < kMergeWays; ++r) {
+                    if (lo[r] < hi[r]) {
+                        const int mid = (lo[r] + hi[r]) >> 1;
+                        if (key_less(x[r].start, x[r].idx, me.start, me.idx)) lo[r] = mid + 1; else hi[r] = mid;
+                        more |= lo[r] < hi[r];
+                    }
+                }
+            }
+            long long smaller = 0;
+#pragma unroll
+            for (int r = 0; r < kMergeWays; ++r) smaller += lo[r];
             const long long q = o + group0 + (p - run * width) + smaller;
             if (dst_idx_only) dst_idx_only[q] = me.idx; // last pass: only the row order is wanted
             else dst[q] = me;

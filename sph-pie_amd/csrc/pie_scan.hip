@@ -1104,13 +1104,15 @@ int scan_finish(pie_ctx* c)
         // big buckets: tiles of kSegMax were sorted in place by K4; merge passes ping-pong between the bucket
         // arrays and scratch carved out of this slot's (now consumed) record staging; the last pass lands in out_idx.
         BktRec* tmp = reinterpret_cast<BktRec*>(sl.sel); // same 16-B records, n of them
-        // 4-way passes, a final 2-way pass when that is all it takes
+        // up to kMergeWays-way passes (one launch merges a bucket of up to 16 tiles); every pass takes as many ways as it
+        // needs to finish, at most kMergeWays
         int passes = 0;
-        for (long long w = kSegMax; w < (long long)sl.last.max_count; w *= 4) ++passes;
+        for (long long w = kSegMax; w < (long long)sl.last.max_count; w *= kMergeWays) ++passes;
         bool in_bkt = true; // which buffer holds the current runs
         long long w = kSegMax;
         for (int p = 0; p < passes; ++p) {
-            const int ways = (w * 2 >= (long long)sl.last.max_count) ? 2 : 4;
+            long long need = ((long long)sl.last.max_count + w - 1) / w; // runs of the largest bucket
+            const int ways = need < 2 ? 2 : (need > kMergeWays ? kMergeWays : (int)need);
             const BktRec* src = in_bkt ? sl.bkt : tmp;
             BktRec* dst = in_bkt ? tmp : sl.bkt;
             int* idx_only = (p == passes - 1) ? sl.out_idx : nullptr;
