@@ -167,7 +167,9 @@ def main():
     ap.add_argument("--rows", type=int, default=10 ** 8, help="sessions of the whole corpus (sharded over the ranks)")
     ap.add_argument("--users", type=int, default=10 ** 5, help="users of the whole corpus")
     ap.add_argument("--disc", type=int, default=32)
-    ap.add_argument("--order", choices=["random", "clustered"], default="random")
+    ap.add_argument("--order", choices=["random", "clustered", "time"], default="random",
+                    help="random (SURVEY.md 8d); clustered: rows of a user contiguous; time: rows in order of creation, as a session "
+                         "store appends them — every live row sits at the end of the table")
     ap.add_argument("--users-dist", choices=["uniform", "zipf"], default="uniform", help="zipf: Zipf(1.1) over the users")
     ap.add_argument("--variant", choices=["auth", "interval"], default="auth")
     ap.add_argument("--query", choices=["spec", "wide", "future"], default="spec",
@@ -230,7 +232,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0)
+    flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0) | \
+        (pie.PIE_GEN_TIME_ORDERED if args.order == "time" else 0)
     if args.query == "spec":
         now, cutoff, mask = T0_MS - 6 * 3600 * 1000, T0_MS - 61 * DAY, 0x5555555555555555
     elif args.query == "future":   # nothing is live: the table pass with no candidate rows (pure key streaming)

@@ -38,6 +38,8 @@ enum {
 /* synthetic-corpus flags; identical meaning in oracle/pie_oracle.h */
 #define PIE_GEN_INTERVAL  1u /* end = start + uniform[15 min, 12 h]; default end = start + SESSION_TTL_MS */
 #define PIE_GEN_CLUSTERED 2u /* rows of one user contiguous; default uniform random users */
+#define PIE_GEN_TIME_ORDERED 4u /* rows in order of creation (start ascending with the row index), as a session store appends
+                                   them: the live rows sit together at the end of the table; default random order */
 
 /* sentinel for "no end" (calendarFeed.js:74 endTs === null) and for tombstoned rows: never live */
 #define PIE_END_NONE INT64_MIN

@@ -16,6 +16,7 @@ SPAN_MS = 10368000000
 TTL_MS = 43200000
 GEN_INTERVAL = 1
 GEN_CLUSTERED = 2
+GEN_TIME_ORDERED = 4
 INT64_MIN = -(2 ** 63)
 
 _lib = None

@@ -41,7 +41,9 @@ void pie_oracle_gen(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int
         const uint64_t r0 = sm_out(seed, 4 * i + 0), r1 = sm_out(seed, 4 * i + 1);
         const uint64_t r2 = sm_out(seed, 4 * i + 2), r3 = sm_out(seed, 4 * i + 3);
         /* back-dated arithmetic timestamps, the pattern of scripts/simulate-archive.js:14-35 */
-        const int64_t s = PIE_ORACLE_T0_MS - (int64_t)mulhi64(r2, (uint64_t)PIE_ORACLE_SPAN_MS);
+        int64_t s = PIE_ORACLE_T0_MS - (int64_t)mulhi64(r2, (uint64_t)PIE_ORACLE_SPAN_MS);
+        if (flags & PIE_GEN_TIME_ORDERED) /* rows in order of creation: start ascending with the row index */
+            s = PIE_ORACLE_T0_MS - PIE_ORACLE_SPAN_MS + 1 + (int64_t)(((unsigned __int128)i * (uint64_t)PIE_ORACLE_SPAN_MS) / (uint64_t)n_total);
         int64_t dur = PIE_ORACLE_TTL_MS; /* expiresAt = createdAt + SESSION_TTL_MS, server/sessionStore.js:15-16 */
         if (flags & PIE_GEN_INTERVAL)
             dur = PIE_ORACLE_MIN_DUR_MS + (int64_t)mulhi64(r3, (uint64_t)(PIE_ORACLE_TTL_MS - PIE_ORACLE_MIN_DUR_MS + 1));

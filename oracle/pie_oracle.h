@@ -33,6 +33,8 @@ extern "C" {
 
 #define PIE_GEN_INTERVAL   1u   /* end = start + uniform[15 min, 12 h] instead of start + TTL */
 #define PIE_GEN_CLUSTERED  2u   /* user = floor(i*U/n_total): rows of one user are contiguous */
+#define PIE_GEN_TIME_ORDERED 4u /* start = T0 - SPAN + 1 + floor(i*SPAN/n_total): rows in order of creation, as a session
+                                   store appends them — the live rows sit together at the end of the table */
 
 void pie_oracle_gen(uint64_t seed, int64_t n_total, int64_t row0, int64_t n, int32_t n_users, int32_t n_disc,
                     uint32_t flags, int64_t *start, int64_t *end, int32_t *user, int32_t *disc);

@@ -6,7 +6,7 @@ BASELINE.json's north_star; nothing else of sph-pie is rebuilt here).
   binding.py ctypes binding of the same C ABI (used by tests, bench.py and the multi-GPU driver)
   shard.py   user-hash sharding + all-gather of per-user feeds (torch.distributed; nccl == RCCL on ROCm)
 """
-from .binding import (ABI_SYMBOLS, PIE_BATCH_MAX, PIE_END_NONE, PIE_GEN_CLUSTERED, PIE_GEN_INTERVAL, PieComm, PieError, PieScan,
+from .binding import (ABI_SYMBOLS, PIE_BATCH_MAX, PIE_END_NONE, PIE_GEN_CLUSTERED, PIE_GEN_INTERVAL, PIE_GEN_TIME_ORDERED, PieComm, PieError, PieScan,
                       load_library, shard_of)
 from .build import build_all, build_hip, build_napi, build_oracle
 
@@ -20,5 +20,5 @@ def zipf_cdf(n_users, exponent=1.1):
     thr[-1] = np.uint64(2 ** 64 - 1)
     return np.maximum.accumulate(thr)
 
-__all__ = ["ABI_SYMBOLS", "PIE_BATCH_MAX", "PIE_END_NONE", "PIE_GEN_CLUSTERED", "PIE_GEN_INTERVAL", "PieComm", "PieError", "PieScan",
+__all__ = ["ABI_SYMBOLS", "PIE_BATCH_MAX", "PIE_END_NONE", "PIE_GEN_CLUSTERED", "PIE_GEN_INTERVAL", "PIE_GEN_TIME_ORDERED", "PieComm", "PieError", "PieScan",
            "load_library", "shard_of", "zipf_cdf", "build_all", "build_hip", "build_napi", "build_oracle"]

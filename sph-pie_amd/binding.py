@@ -11,6 +11,7 @@ from .build import HIP_LIB
 
 PIE_GEN_INTERVAL = 1
 PIE_GEN_CLUSTERED = 2
+PIE_GEN_TIME_ORDERED = 4
 PIE_END_NONE = -(2 ** 63)
 INT64_MIN = -(2 ** 63)
 

@@ -62,6 +62,8 @@ struct Summary {
     unsigned int n_hot;         // users whose bucket exceeded the hot threshold (candidates for the next scan's hot set)
     unsigned int n_over;        // listed buckets with staged records (outgrew the direct slots / hot user / no slots): K3 needed
     unsigned long long cand;    // keyed table pass: candidate rows (key >= key(now)), i.e. payload records gathered
+    unsigned int chunk_max;     // keyed table pass: candidates in the densest chunk (one load per lane: 1024 / 512 rows)
+    unsigned int pad2;
 };
 
 // K2's inter-block state, zeroed together with the histogram it belongs to
@@ -83,33 +85,39 @@ struct HostSummary {
 // kernel that publishes the summary adds them up.
 struct alignas(128) StatSlot {
     unsigned long long live, amb, cand;
-    unsigned long long pad[13];
+    unsigned long long chunk_max; // max over the blocks of this slot
+    unsigned long long pad[12];
 };
 constexpr int kStatSlots = 64;
 constexpr int kSummaryBytes = 128; // Summary, padded: the slots start here
 static_assert(sizeof(Summary) <= kSummaryBytes, "Summary outgrew its padded slot");
 __device__ __forceinline__ StatSlot* stat_slots(Summary* s) { return reinterpret_cast<StatSlot*>(reinterpret_cast<char*>(s) + kSummaryBytes); }
-__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb, int bid = (int)blockIdx.x, int cand = 0)
+__device__ __forceinline__ void add_row_stats(Summary* s, int live, int amb, int bid = (int)blockIdx.x, int cand = 0, int chunk_max = 0)
 {
     StatSlot* slot = stat_slots(s) + (bid & (kStatSlots - 1));
     if (live) atomicAdd(&slot->live, (unsigned long long)live);
     if (amb) atomicAdd(&slot->amb, (unsigned long long)amb);
     if (cand) atomicAdd(&slot->cand, (unsigned long long)cand);
+    if (chunk_max) atomicMax(&slot->chunk_max, (unsigned long long)chunk_max);
 }
 // one wave: lane l reads slot l; every lane returns the totals
 __device__ __forceinline__ void sum_row_stats(Summary* s, int lane, unsigned long long& live, unsigned long long& amb,
-                                              unsigned long long* cand = nullptr)
+                                              unsigned long long* cand = nullptr, unsigned int* chunk_max = nullptr)
 {
     StatSlot* slot = stat_slots(s) + (lane & (kStatSlots - 1));
     live = __hip_atomic_load(&slot->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     amb = __hip_atomic_load(&slot->amb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long cd = __hip_atomic_load(&slot->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cm = __hip_atomic_load(&slot->chunk_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int o = 32; o > 0; o >>= 1) {
         live += __shfl_xor(live, o, 64);
         amb += __shfl_xor(amb, o, 64);
         cd += __shfl_xor(cd, o, 64);
+        const unsigned long long other = __shfl_xor(cm, o, 64);
+        cm = other > cm ? other : cm;
     }
     if (cand) *cand = cd;
+    if (chunk_max) *chunk_max = (unsigned int)cm;
 }
 
 constexpr int kWave = 64;
@@ -181,7 +189,10 @@ __global__ __launch_bounds__(256) void k_gen(unsigned long long seed, long long 
         const unsigned long long i = (unsigned long long)(row0 + k);
         const unsigned long long r0 = mix64(seed + (4 * i + 1) * G), r1 = mix64(seed + (4 * i + 2) * G);
         const unsigned long long r2 = mix64(seed + (4 * i + 3) * G), r3 = mix64(seed + (4 * i + 4) * G);
-        const long long s = T0 - (long long)__umul64hi(r2, (unsigned long long)SPAN);
+        long long s = T0 - (long long)__umul64hi(r2, (unsigned long long)SPAN);
+        // flags bit 2: rows in order of creation, as a session store appends them (start ascending with the row index,
+        // evenly spread over the span): the live rows then sit together at the end of the table
+        if (flags & 4u) s = T0 - SPAN + 1 + (long long)(((unsigned __int128)i * (unsigned long long)SPAN) / (unsigned long long)n_total);
         long long dur = TTL;
         if (flags & 1u) dur = MIN_DUR + (long long)__umul64hi(r3, (unsigned long long)(TTL - MIN_DUR + 1));
         start[k] = s;
@@ -728,7 +739,7 @@ __device__ __forceinline__ void scan_keyed_body(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
-    DirectSlots direct, const HotSet& hot, int* __restrict__ blk_hot_base, int bid)
+    DirectSlots direct, const HotSet& hot, int* __restrict__ blk_hot_base, int bid, int n_scan_blocks, int run_shift_arg)
 {
     __shared__ SelRec stage[kK1Waves][kStage];
     __shared__ int stage_rank[kK1Waves][kStage];
@@ -737,19 +748,21 @@ __device__ __forceinline__ void scan_keyed_body(
     __shared__ int blk_live;
     __shared__ int blk_amb;
     __shared__ int blk_cand;
+    __shared__ int blk_chunk_max;
     __shared__ int blk_hot_cnt[kHotMax];
     constexpr int kPerLane = 16 / (int)sizeof(KT); // rows per lane per 16-byte load
+    constexpr int kLogUnroll = UNROLL >= 8 ? 3 : UNROLL >= 4 ? 2 : UNROLL >= 2 ? 1 : 0;
+    const int run_shift = run_shift_arg < kLogUnroll ? (run_shift_arg < 0 ? 0 : run_shift_arg) : kLogUnroll;
+    int pushed = 0, chunk_max = 0; // wave-uniform: candidates queued so far; most candidates seen in one chunk
     constexpr int kRowsPerLoad = kPerLane * kWave;
-    constexpr int kTile = kRowsPerLoad * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; blk_cand = 0; }
+    if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_amb = 0; blk_cand = 0; blk_chunk_max = 0; }
     if (AGG && threadIdx.x < kHotMax) blk_hot_cnt[threadIdx.x] = 0;
     __syncthreads();
 
+    // the block's private output region for staged records: rows_per_block slots (it never reads more rows than that)
     const long long c0 = (long long)bid * rows_per_block;
-    long long c1 = c0 + rows_per_block;
-    if (c1 > n) c1 = n;
     SelRec* out = sel + c0;
     int* out_rank = sel_rank + c0;
     WaveStage st;
@@ -861,6 +874,7 @@ __device__ __forceinline__ void scan_keyed_body(
         if (b == 0) return false;
         if (cand) lring[(lhead + lfill + prefix_in_ballot(b)) & (kLiveRing - 1)] = entry;
         lfill += __popcll(b);
+        pushed += __popcll(b);
         __builtin_amdgcn_wave_barrier();
         if (lfill >= kWave) drain(kWave);
         __builtin_amdgcn_wave_barrier();
@@ -872,53 +886,68 @@ __device__ __forceinline__ void scan_keyed_body(
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
     const unsigned nkr = sizeof(KT) == 2 ? (now_key | (now_key << 16)) : now_key * 0x01010101u;
-    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
-        if (t + kTile <= c1) {
-            u4_t kv[UNROLL];
+    // Rows are dealt to the waves of the whole launch in CHUNKS of one 16-byte load per lane (1024 / 512 rows), round robin:
+    // wave g of W takes chunks g, g + W, g + 2W, ...  In a session table the live rows are the recent ones, i.e. they sit
+    // together at the end of the table (and a login burst appends there): with one contiguous row range per block the few
+    // blocks at the end would evaluate nearly every candidate while the rest of the chip idles (measured: the table pass
+    // 4x slower once 10^5 freshly appended / touched rows are live).  Interleaved, a dense stretch of the table is spread
+    // over as many waves as it has chunks.  Every load is still one contiguous, aligned KiB per wave.
+    int chunk_mark = 0;
+    const long long n_chunks = n / kRowsPerLoad;              // full chunks; the ragged rest goes to one wave, row by row
+    const long long W = (long long)n_scan_blocks * kK1Waves;
+    const long long gw = (long long)bid * kK1Waves + wave;
+    for (long long cb = gw << run_shift; cb < n_chunks; cb += W * UNROLL) {
+        u4_t kv[UNROLL];
 #pragma unroll
-            for (int j = 0; j < UNROLL; ++j)
-                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(key + t + j * kRowsPerLoad + kPerLane * lane));
+        for (int j = 0; j < UNROLL; ++j) {
+            const long long ch = cb + (((long long)(j >> run_shift) * W) << run_shift) + (j & ((1 << run_shift) - 1));
+            kv[j] = (u4_t){0u, 0u, 0u, 0u};                    // key 0 = below every query's key: no candidates
+            if (ch < n_chunks) kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(key + ch * kRowsPerLoad + kPerLane * lane));
+        }
 #pragma unroll
-            for (int j = 0; j < UNROLL; ++j) {
-                const int r0 = (int)(t + j * kRowsPerLoad + kPerLane * lane);
-                const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
-                const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
-                if constexpr (sizeof(KT) == 2) {
-                    // rows 0..3 keep their flags at bits 15/31/47/63, rows 4..7 move to bits 7/23/39/55
-                    unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
-                                           (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
-                    for (;;) {
-                        const bool has = m != 0;
-                        const int pbit = __ffsll((long long)m) - 1;         // meaningless when !has
-                        const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);   // row within the lane's eight
-                        const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
-                        const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
-                        const int entry = (r0 + q) | (kq == now_key ? (int)0x80000000 : 0);
-                        if (!push(has, entry)) break;
-                        m &= m - 1;
-                    }
-                } else {
-                    // byte b of word w is row 4w + b; its flag moves to bit 8b + w
-                    unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
-                    for (;;) {
-                        const bool has = m != 0;
-                        const int pbit = __ffs((int)m) - 1;
-                        const int w = pbit & 7, b = pbit >> 3;
-                        const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
-                        const unsigned kq = (word >> (8 * b)) & 0xFFu;
-                        const int entry = (r0 + 4 * w + b) | (kq == now_key ? (int)0x80000000 : 0);
-                        if (!push(has, entry)) break;
-                        m &= m - 1;
-                    }
+        for (int j = 0; j < UNROLL; ++j) {
+            const long long ch = cb + (((long long)(j >> run_shift) * W) << run_shift) + (j & ((1 << run_shift) - 1));
+            if (ch >= n_chunks) continue;                      // wave-uniform
+            chunk_max = max(chunk_max, pushed - chunk_mark);   // candidates of the chunk before this one
+            chunk_mark = pushed;
+            const int r0 = (int)(ch * kRowsPerLoad + kPerLane * lane);
+            const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
+            const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
+            if constexpr (sizeof(KT) == 2) {
+                // rows 0..3 keep their flags at bits 15/31/47/63, rows 4..7 move to bits 7/23/39/55
+                unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
+                                       (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
+                for (;;) {
+                    const bool has = m != 0;
+                    const int pbit = __ffsll((long long)m) - 1;         // meaningless when !has
+                    const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);   // row within the lane's eight
+                    const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
+                    const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
+                    const int entry = (r0 + q) | (kq == now_key ? (int)0x80000000 : 0);
+                    if (!push(has, entry)) break;
+                    m &= m - 1;
+                }
+            } else {
+                // byte b of word w is row 4w + b; its flag moves to bit 8b + w
+                unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
+                for (;;) {
+                    const bool has = m != 0;
+                    const int pbit = __ffs((int)m) - 1;
+                    const int w = pbit & 7, b = pbit >> 3;
+                    const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
+                    const unsigned kq = (word >> (8 * b)) & 0xFFu;
+                    const int entry = (r0 + 4 * w + b) | (kq == now_key ? (int)0x80000000 : 0);
+                    if (!push(has, entry)) break;
+                    m &= m - 1;
                 }
             }
-        } else {
-            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
-            for (long long r0 = t; r0 < t1; r0 += kWave) {
-                const long long r = r0 + lane;
-                const unsigned kq = r < t1 ? key[r] : 0u;
-                push(r < t1 && kq >= now_key, (int)r | (kq == now_key ? (int)0x80000000 : 0));
-            }
+        }
+    }
+    if (gw == (n_chunks >> run_shift) % W) { // the wave whose turn the next chunk would be: the table's last, partial chunk
+        for (long long r0 = n_chunks * kRowsPerLoad; r0 < n; r0 += kWave) {
+            const long long r = r0 + lane;
+            const unsigned kq = r < n ? key[r] : 0u;
+            push(r < n && kq >= now_key, (int)r | (kq == now_key ? (int)0x80000000 : 0));
         }
     }
     if (lfill > 0) drain(lfill);
@@ -931,10 +960,12 @@ __device__ __forceinline__ void scan_keyed_body(
     if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
     if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
     if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
+    chunk_max = max(chunk_max, pushed - chunk_mark);
+    if (lane == 0 && chunk_max) atomicMax(&blk_chunk_max, chunk_max);
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_count[bid] = blk_cursor;
-        add_row_stats(summary, blk_live, blk_amb, bid, blk_cand);
+        add_row_stats(summary, blk_live, blk_amb, bid, blk_cand, blk_chunk_max);
     }
     if constexpr (AGG) { // one histogram atomic per (block, hot user); K3 needs the base it returned
         if ((int)threadIdx.x < hot.n) {
@@ -949,10 +980,10 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed(
     const PayRec* __restrict__ pay, const long long* __restrict__ end, const KT* __restrict__ key, long long n,
     long long rows_per_block, long long now, unsigned now_key, long long cutoff, unsigned long long mask, int n_users, int* __restrict__ counts,
     SelRec* __restrict__ sel, int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary,
-    DirectSlots direct, HotSet hot, int* __restrict__ blk_hot_base)
+    DirectSlots direct, HotSet hot, int* __restrict__ blk_hot_base, int run_shift)
 {
     scan_keyed_body<UNROLL, AGG, NT, KT, PIPE>(pay, end, key, n, rows_per_block, now, now_key, cutoff, mask, n_users, counts, sel, sel_rank,
-                                               blk_count, summary, direct, hot, blk_hot_base, (int)blockIdx.x);
+                                               blk_count, summary, direct, hot, blk_hot_base, (int)blockIdx.x, (int)gridDim.x, run_shift);
 }
 
 // ------------------------------------------------------------------------------------------------ partitioned fast path
@@ -1257,6 +1288,8 @@ __global__ __launch_bounds__(256) void k_publish_summary(Summary* __restrict__ s
         out.live = live;
         out.amb = amb;
         out.cand = 0;
+        out.chunk_max = 0;
+        out.pad2 = 0;
         out.max_count = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         out.n_seg = out.n_big = out.n_small = 0;
         out.q = 0;
@@ -1654,10 +1687,13 @@ __device__ __forceinline__ void offsets_body(const int* __restrict__ counts, int
     __syncthreads();
     if (is_last && threadIdx.x < 64) {
         unsigned long long live = 0, amb = 0, cand = 0;
-        sum_row_stats(summary, (int)threadIdx.x, live, amb, &cand); // K1 finished before this kernel started
+        unsigned int chunk_max = 0;
+        sum_row_stats(summary, (int)threadIdx.x, live, amb, &cand, &chunk_max); // K1 finished before this kernel started
         if (threadIdx.x == 0) {
             Summary out;
             out.cand = cand;
+            out.chunk_max = chunk_max;
+            out.pad2 = 0;
             out.m = __hip_atomic_load(&summary->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.n_seg = __hip_atomic_load(&summary->n_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.n_big = __hip_atomic_load(&summary->n_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1716,6 +1752,7 @@ struct KeyedArgs {
     DirectSlots direct;
     HotSet hot;
     int* blk_hot_base;
+    int run_shift;   // log2 of the consecutive chunks a wave takes before the round robin moves on (0: fully interleaved)
 };
 struct OffsetsArgs {
     const int* counts;
@@ -1756,7 +1793,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
     } else {
         scan_keyed_body<UNROLL, AGG, NT, KT, false>(a.pay, a.end, a.key, a.n, a.rows_per_block, a.now, a.now_key, a.cutoff, a.mask,
                                                       a.n_users, a.counts, a.sel, a.sel_rank, a.blk_count, a.summary, a.direct, a.hot,
-                                                      a.blk_hot_base, (int)blockIdx.x - t.n_tail);
+                                                      a.blk_hot_base, (int)blockIdx.x - t.n_tail, (int)gridDim.x - t.n_tail, a.run_shift);
     }
 }
 
@@ -1798,25 +1835,26 @@ struct BatchScanArgs {
     int* counts;               // union histogram (transposed user order, hist_index)
     Summary* summary;          // query 0's summary: bad rows and the row statistics of the pass
     BktRec* direct;            // union bucket slots, (1 << dshift) per user; BktRec::pad = the queries that selected the row
+    int run_shift;             // see KeyedArgs
     BatchQueryScalars q[kBatchMax];
 };
 
 template <int UNROLL, bool NT, class KT>
-__device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int bid)
+__device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int bid, int n_scan_blocks)
 {
     __shared__ int ring_row[kK1Waves][kLiveRing];
     __shared__ int ring_key[kK1Waves][kLiveRing];
     __shared__ int blk_cand;
+    __shared__ int blk_chunk_max;
+    constexpr int kLogUnroll = UNROLL >= 8 ? 3 : UNROLL >= 4 ? 2 : UNROLL >= 2 ? 1 : 0;
+    const int run_shift = a.run_shift < kLogUnroll ? (a.run_shift < 0 ? 0 : a.run_shift) : kLogUnroll;
+    int pushed = 0, chunk_max = 0, chunk_mark = 0;
     constexpr int kPerLane = 16 / (int)sizeof(KT);
     constexpr int kRowsPerLoad = kPerLane * kWave;
-    constexpr int kTile = kRowsPerLoad * UNROLL;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) blk_cand = 0;
+    if (threadIdx.x == 0) { blk_cand = 0; blk_chunk_max = 0; }
     __syncthreads();
-    const long long c0 = (long long)bid * a.rows_per_block;
-    long long c1 = c0 + a.rows_per_block;
-    if (c1 > a.n) c1 = a.n;
     int* rrow = ring_row[wave];
     int* rkey = ring_key[wave];
     int lhead = 0, lfill = 0, ncand = 0; // wave-uniform
@@ -1875,6 +1913,7 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
             rkey[slot] = (int)key;
         }
         lfill += __popcll(b);
+        pushed += __popcll(b);
         __builtin_amdgcn_wave_barrier();
         if (lfill >= kWave) drain(kWave);
         __builtin_amdgcn_wave_barrier();
@@ -1886,55 +1925,66 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
     const unsigned mk = a.min_key;
     const unsigned nkr = sizeof(KT) == 2 ? (mk | (mk << 16)) : mk * 0x01010101u;
-    for (long long t = c0 + (long long)wave * kTile; t < c1; t += (long long)kTile * kK1Waves) {
-        if (t + kTile <= c1) {
-            u4_t kv[UNROLL];
+    // rows dealt to the launch's waves in chunks of one load per lane, round robin (see scan_keyed_body)
+    const long long n_chunks = a.n / kRowsPerLoad;
+    const long long W = (long long)n_scan_blocks * kK1Waves;
+    const long long gw = (long long)bid * kK1Waves + wave;
+    for (long long cb = gw << run_shift; cb < n_chunks; cb += W * UNROLL) {
+        u4_t kv[UNROLL];
 #pragma unroll
-            for (int j = 0; j < UNROLL; ++j)
-                kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(a.key + t + j * kRowsPerLoad + kPerLane * lane));
+        for (int j = 0; j < UNROLL; ++j) {
+            const long long ch = cb + (((long long)(j >> run_shift) * W) << run_shift) + (j & ((1 << run_shift) - 1));
+            kv[j] = (u4_t){0u, 0u, 0u, 0u};
+            if (ch < n_chunks) kv[j] = stream_load<NT>(reinterpret_cast<const u4_t*>(a.key + ch * kRowsPerLoad + kPerLane * lane));
+        }
 #pragma unroll
-            for (int j = 0; j < UNROLL; ++j) {
-                const int r0 = (int)(t + j * kRowsPerLoad + kPerLane * lane);
-                const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
-                const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
-                if constexpr (sizeof(KT) == 2) {
-                    unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
-                                           (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
-                    for (;;) {
-                        const bool has = m != 0;
-                        const int pbit = __ffsll((long long)m) - 1;
-                        const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);
-                        const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
-                        const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
-                        if (!push(has, r0 + q, kq)) break;
-                        m &= m - 1;
-                    }
-                } else {
-                    unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
-                    for (;;) {
-                        const bool has = m != 0;
-                        const int pbit = __ffs((int)m) - 1;
-                        const int w = pbit & 7, b = pbit >> 3;
-                        const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
-                        const unsigned kq = (word >> (8 * b)) & 0xFFu;
-                        if (!push(has, r0 + 4 * w + b, kq)) break;
-                        m &= m - 1;
-                    }
+        for (int j = 0; j < UNROLL; ++j) {
+            const long long ch = cb + (((long long)(j >> run_shift) * W) << run_shift) + (j & ((1 << run_shift) - 1));
+            if (ch >= n_chunks) continue;
+            chunk_max = max(chunk_max, pushed - chunk_mark);
+            chunk_mark = pushed;
+            const int r0 = (int)(ch * kRowsPerLoad + kPerLane * lane);
+            const unsigned g0 = ((kv[j].x | kTop) - nkr) & kTop, g1 = ((kv[j].y | kTop) - nkr) & kTop;
+            const unsigned g2 = ((kv[j].z | kTop) - nkr) & kTop, g3 = ((kv[j].w | kTop) - nkr) & kTop;
+            if constexpr (sizeof(KT) == 2) {
+                unsigned long long m = ((unsigned long long)g0 | ((unsigned long long)g1 << 32)) |
+                                       (((unsigned long long)g2 | ((unsigned long long)g3 << 32)) >> 8);
+                for (;;) {
+                    const bool has = m != 0;
+                    const int pbit = __ffsll((long long)m) - 1;
+                    const int q = (pbit >> 4) + ((pbit & 8) ? 0 : 4);
+                    const unsigned w = q < 4 ? (q < 2 ? kv[j].x : kv[j].y) : (q < 6 ? kv[j].z : kv[j].w);
+                    const unsigned kq = (w >> ((q & 1) * 16)) & 0xFFFFu;
+                    if (!push(has, r0 + q, kq)) break;
+                    m &= m - 1;
+                }
+            } else {
+                unsigned m = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
+                for (;;) {
+                    const bool has = m != 0;
+                    const int pbit = __ffs((int)m) - 1;
+                    const int w = pbit & 7, b = pbit >> 3;
+                    const unsigned word = w < 2 ? (w == 0 ? kv[j].x : kv[j].y) : (w == 2 ? kv[j].z : kv[j].w);
+                    const unsigned kq = (word >> (8 * b)) & 0xFFu;
+                    if (!push(has, r0 + 4 * w + b, kq)) break;
+                    m &= m - 1;
                 }
             }
-        } else {
-            const long long t1 = (t + kTile < c1) ? t + kTile : c1;
-            for (long long r0 = t; r0 < t1; r0 += kWave) {
-                const long long r = r0 + lane;
-                const unsigned kq = r < t1 ? a.key[r] : 0u;
-                push(r < t1 && kq >= mk, (int)r, kq);
-            }
+        }
+    }
+    if (gw == (n_chunks >> run_shift) % W) {
+        for (long long r0 = n_chunks * kRowsPerLoad; r0 < a.n; r0 += kWave) {
+            const long long r = r0 + lane;
+            const unsigned kq = r < a.n ? a.key[r] : 0u;
+            push(r < a.n && kq >= mk, (int)r, kq);
         }
     }
     if (lfill > 0) drain(lfill);
     if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
+    chunk_max = max(chunk_max, pushed - chunk_mark);
+    if (lane == 0 && chunk_max) atomicMax(&blk_chunk_max, chunk_max);
     __syncthreads();
-    if (threadIdx.x == 0) add_row_stats(a.summary, 0, 0, bid, blk_cand);
+    if (threadIdx.x == 0) add_row_stats(a.summary, 0, 0, bid, blk_cand, blk_chunk_max);
 }
 
 // offsets + order kernel of a batch: blocks of 256 users; see the section header
@@ -2243,7 +2293,8 @@ __device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int g
     __syncthreads();
     if (is_last && threadIdx.x < 64) {
         unsigned long long live = 0, amb = 0, cand = 0;
-        sum_row_stats(sum0, (int)threadIdx.x, live, amb, &cand);
+        unsigned int chunk_max = 0;
+        sum_row_stats(sum0, (int)threadIdx.x, live, amb, &cand, &chunk_max);
         if ((int)threadIdx.x < nq) {
             const int q = (int)threadIdx.x;
             Summary* sq = reinterpret_cast<Summary*>(t.span + (long long)(q_lo + q) * t.span_stride + t.summary_off);
@@ -2259,6 +2310,8 @@ __device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int g
             out.n_hot = 0;
             out.n_over = __hip_atomic_load(&sumg->n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out.cand = cand;
+            out.chunk_max = chunk_max;
+            out.pad2 = 0;
             t.host[q_lo + q].s = out;
             __hip_atomic_store(&t.host[q_lo + q].seq, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2271,7 +2324,7 @@ __global__ __launch_bounds__(kK1Threads) void k_offsets_batch(BatchTailArgs t) {
 template <int UNROLL, bool NT, class KT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
 {
-    scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x);
+    scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // table pass of batch i+1 with the offsets kernel of batch i in its first blocks (see k_scan_keyed_with_tail)
@@ -2280,7 +2333,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_batch_with_tail(BatchScanAr
 {
     const int n_tail = t.tiles * (t.n_q > 8 ? 2 : 1);
     if ((int)blockIdx.x < n_tail) offsets_union_body<QT>(t, (int)blockIdx.x);
-    else scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x - n_tail);
+    else scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x - n_tail, (int)gridDim.x - n_tail);
 }
 
 // ------------------------------------------------------------------------------------------------ K3 scatter
@@ -2700,6 +2753,42 @@ __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, co
         if (key) key[rows[t]] = (lkey_t)key_of(new_end[t], key_base, key_shift);
         if (fkey) fkey[rows[t]] = (fkey_t)key_of(new_end[t], fkey_base, fkey_shift, kFineKeyMax);
     }
+}
+
+// createSession, k rows at a time (pie_append_rows' in-place path): the packed staging block [start k | end k | user k |
+// disc k] becomes rows [row0, row0 + k) of the four columns and of the derived columns (both keys under the table's current
+// parameters, the payload record), and user ids outside [0, n_users) are counted — one kernel instead of four copies, a
+// validation pass and two key passes.
+__global__ __launch_bounds__(256) void k_append_rows(const long long* __restrict__ st_start, const long long* __restrict__ st_end,
+                                                     const int* __restrict__ st_user, const int* __restrict__ st_disc, long long k,
+                                                     long long row0, int n_users, long long* __restrict__ start,
+                                                     long long* __restrict__ end, int* __restrict__ user, int* __restrict__ disc,
+                                                     lkey_t* __restrict__ key, long long key_base, int key_shift,
+                                                     fkey_t* __restrict__ fkey, long long fkey_base, int fkey_shift,
+                                                     PayRec* __restrict__ pay, unsigned int* __restrict__ bad)
+{
+    unsigned int local = 0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < k; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = row0 + t;
+        const long long sv = st_start[t], ev = st_end[t];
+        const int uv = st_user[t], dv = st_disc[t];
+        local += ((unsigned)uv >= (unsigned)n_users) ? 1u : 0u;
+        start[r] = sv;
+        end[r] = ev;
+        user[r] = uv;
+        disc[r] = dv;
+        if (key) key[r] = (lkey_t)key_of(ev, key_base, key_shift);
+        if (fkey) fkey[r] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
+        if (pay) {
+            PayRec pr;
+            pr.start = sv;
+            pr.user = uv;
+            pr.disc = dv;
+            pay[r] = pr;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
 }
 
 __global__ __launch_bounds__(256) void k_fetch_rows(const int* __restrict__ idx, long long m, long long n,

@@ -164,6 +164,9 @@ struct pie_ctx {
     bool no_fused_order = false; // PIE_FUSED_ORDER=0: K2 and the tiny-bucket order as two kernels (A/B runs)
     int k1_keyed = 0xC85;       // keyed liveness-first form (bit 0x400; 0x800: the 1-byte fine key where the query allows), unroll 8
     long long* d_range = nullptr;
+    char* h_stage = nullptr;       // pinned host + device staging of the small mutations (append, touch): grown, never per call
+    char* d_stage = nullptr;
+    size_t stage_bytes = 0;
     int* d_shard_rows = nullptr;   // pie_shard_table: local row -> global row
     int* d_shard_users = nullptr;  // ... local user -> global user
     long long shard_rows_n = 0;
@@ -204,6 +207,11 @@ struct pie_ctx {
     bool batch_alloc = false;
     int bdshift = 4;            // log2 of the union bucket capacity of the batched pass (16 .. 64 slots per user)
     int bdshift_want = 4;       // capacity the last finished batch asked for (applied at the next begin with nothing in flight)
+    int run_shift = 0;          // chunk interleave of the keyed / batched table pass: 0 = fully interleaved (dense stretches of
+                                // live rows, the safe default), 3 = eight consecutive chunks per wave (live rows spread evenly: a few
+                                // per cent faster); follows the densest-chunk statistic of the last pass, see choose_run_shift
+    bool batch_poor = false;    // union buckets overflowed at their largest capacity (skewed users): batches run as single scans
+    bool run_shift_pinned = false; // PIE_RUN_SHIFT=0..3 pins it (A/B runs)
     bool last_was_batch = false; // pie_stats_get describes the last finished batch rather than the last single scan
     unsigned long long bseq_counter = 0;
     char* span[3] = {nullptr, nullptr, nullptr}; // rotating histogram spans (see counts_span)
@@ -360,6 +368,18 @@ size_t span_parts_bytes() { return (size_t)kPartMax * 4; }
 size_t span_stats_bytes() { return (size_t)kSummaryBytes + (size_t)kStatSlots * sizeof(StatSlot); } // Summary (padded) + the K1 row-statistics slots
 size_t counts_span(const pie_ctx* c) { return span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128 + span_stats_bytes(); }
 
+// everything that depends on the number of users of the resident table (within the allocated capacity)
+void set_user_count(pie_ctx* c, int n_users)
+{
+    c->n_users = n_users;
+    c->n_tiles = (n_users + kScanTile - 1) / kScanTile;
+    c->part_shift = -1;
+    for (int sh = 0; (1 << sh) <= kPartRange; ++sh) {
+        if ((((long long)n_users - 1) >> sh) + 1 <= kPartMax) { c->part_shift = sh; break; }
+    }
+    c->n_parts = c->part_shift >= 0 ? (int)((((long long)n_users - 1) >> c->part_shift) + 1) : 0;
+}
+
 // Make room for n rows / n_users users.  keep_rows > 0: the first keep_rows rows of the resident columns survive
 // a re-allocation (append path; capacity grows geometrically so appends are amortised O(1) per row).
 int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 0)
@@ -437,6 +457,8 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         // a new table: nothing is known about it.  An append keeps what the last scans observed (live fraction, skew,
         // clustering): a few new rows do not change the picture, and one scan corrects it if they do
         c->live_frac = -1;
+        c->batch_poor = false;
+        if (!c->run_shift_pinned) c->run_shift = 0;
         c->hot_bucket = false;
         c->clustered = false;
         c->hot.n = 0;
@@ -445,17 +467,30 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         c->last_m = -1;
     }
     c->fast_enabled = c->fast_env;
-    c->part_shift = -1;
-    for (int sh = 0; (1 << sh) <= kPartRange; ++sh) {
-        if ((((long long)n_users - 1) >> sh) + 1 <= kPartMax) { c->part_shift = sh; break; }
-    }
-    c->n_parts = c->part_shift >= 0 ? (int)((((long long)n_users - 1) >> c->part_shift) + 1) : 0;
+    set_user_count(c, n_users);
     c->res = nullptr;
     for (Slot& s : c->slot) s.have_result = false;
     // all three spans start clean; from here on every K2 zeroes the span of the scan after it
     for (char* sp : c->span) PIE_HIP(c, hipMemsetAsync(sp, 0, counts_span(c), c->stream));
     c->span_next = 0;
     plan_k1(c);
+    return PIE_OK;
+}
+
+// pinned host + device staging blocks of at least `bytes` (one pair per context; the context is used by one thread)
+int ensure_stage(pie_ctx* c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return PIE_OK;
+    size_t want = c->stage_bytes ? c->stage_bytes : (size_t)64 << 10;
+    while (want < bytes) want *= 2;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    dfree(c->d_stage);
+    c->h_stage = nullptr;
+    c->stage_bytes = 0;
+    PIE_HIP(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    PIE_HIP(c, hipMalloc(&c->d_stage, want));
+    c->stage_bytes = want;
     return PIE_OK;
 }
 
@@ -617,12 +652,12 @@ void launch_k1(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cut
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, fkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_fkey, c->n, sl.rows_per_block, now, host_fine_key_of(c, now), cutoff, mask, \
                                    c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), \
-                                   sl.hot, sl.blk_hot_base);                                                        \
+                                   sl.hot, sl.blk_hot_base, c->run_shift);                                          \
             else                                                                                                    \
                 hipLaunchKernelGGL((k_scan_keyed<UN, AG, NT, lkey_t, PP>), dim3(sl.k1_blocks), dim3(kK1Threads), 0, s, c->d_pay, \
                                    c->d_end, c->d_key, c->n, sl.rows_per_block, now, host_key_of(c, now), cutoff, mask,       \
                                    c->n_users, sl.counts, sl.sel, sl.sel_rank, sl.blk_count, sl.sum, direct_of(c, sl), \
-                                   sl.hot, sl.blk_hot_base);                                                        \
+                                   sl.hot, sl.blk_hot_base, c->run_shift);                                          \
         } while (0)
 #define PIE_K1K(UN, AG, NT)                                                                                          \
         do {                                                                                                        \
@@ -759,7 +794,7 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
         a.pay = c->d_pay; a.end = c->d_end; a.key = KEYPTR; a.n = c->n; a.rows_per_block = sl.rows_per_block; a.now = now; \
         a.now_key = NOWKEY; a.cutoff = cutoff; a.mask = mask; a.n_users = c->n_users; a.counts = sl.counts; a.sel = sl.sel;  \
         a.sel_rank = sl.sel_rank; a.blk_count = sl.blk_count; a.summary = sl.sum; a.direct = direct_of(c, sl); a.hot = sl.hot; \
-        a.blk_hot_base = sl.blk_hot_base;                                                                               \
+        a.blk_hot_base = sl.blk_hot_base; a.run_shift = c->run_shift;                                                   \
         if (sl.variant & 0x40) hipLaunchKernelGGL((k_scan_keyed_with_tail<8, true, KT, true>), dim3(grid), dim3(kK1Threads), 0, s, a, t);  \
         else hipLaunchKernelGGL((k_scan_keyed_with_tail<8, true, KT, false>), dim3(grid), dim3(kK1Threads), 0, s, a, t);   \
     } while (0)
@@ -937,6 +972,21 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     return PIE_OK;
 }
 
+// Chunk interleave of the next keyed / batched pass, from what the last one saw: `chunk_max` = candidates in its densest
+// chunk (1024 or 512 rows), `cand` = all candidates.  Live rows spread evenly (the synthetic corpus of SURVEY.md 8d: a
+// chunk holds a handful) -> eight consecutive chunks per wave; a chunk that is an eighth full while the average chunk
+// is nearly empty (a session table in creation order: every live row at its end; a login burst) -> fully interleaved.
+void choose_run_shift(pie_ctx* c, unsigned long long cand, unsigned chunk_max, bool fine_key)
+{
+    if (c->run_shift_pinned) return;
+    const double rows_per_chunk = fine_key ? (double)kFineKeyRowsPerLoad : (double)kKeyRowsPerLoad;
+    const double chunks = (double)c->n / rows_per_chunk;
+    if (chunks < 1.0) return;
+    const double mean = (double)cand / chunks;
+    const bool dense_stretch = (double)chunk_max >= rows_per_chunk / 8.0 && (double)chunk_max > 8.0 * (mean + 1.0);
+    c->run_shift = dense_stretch ? 0 : 3;
+}
+
 // Tail of the oldest scan in flight: launch its K2 if no later scan took it along, wait for its summary, then — only for
 // buckets that outgrew their direct slots — scatter + per-bucket order (plus the merge passes of big buckets, sized from
 // the summary).  Also where the adaptive choices for the next scans are made (scan form, key fit, hot set, slot capacity).
@@ -997,12 +1047,14 @@ int scan_finish(pie_ctx* c)
             Summary dev;
             memcpy(&dev, raw.data(), sizeof dev);
             dev.live = dev.amb = dev.cand = 0;
+            dev.chunk_max = 0;
             for (int k = 0; k < kStatSlots; ++k) {
                 StatSlot st;
                 memcpy(&st, raw.data() + kSummaryBytes + (size_t)k * sizeof(StatSlot), sizeof st);
                 dev.live += st.live;
                 dev.amb += st.amb;
                 dev.cand += st.cand;
+                dev.chunk_max = st.chunk_max > dev.chunk_max ? (unsigned)st.chunk_max : dev.chunk_max;
             }
             sl.h_sum->s = dev;
         }
@@ -1040,6 +1092,7 @@ int scan_finish(pie_ctx* c)
             return PIE_OK;
         }
     }
+    if ((sl.variant & 0x400) && !c->d_qual) choose_run_shift(c, sl.last.cand, sl.last.chunk_max, (sl.variant & 0x800) != 0);
     if ((sl.variant & 0x400) && sl.last.amb > 4096 && sl.last.amb > (unsigned long long)c->n / 64) {
         // the key column separated this query badly (e.g. `now` beyond the range it was built for)
         if (c->key_dirty) c->key_rebuild = true;
@@ -1285,7 +1338,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     b.msg_counts = msg_counts; b.msg_counts_stride = msg_counts_stride;
     for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; }
     b.ev_index = -1;
-    b.unsupported = !batch_supported(c) || c->key_poor;
+    b.unsupported = !batch_supported(c) || c->key_poor || c->batch_poor;
     if (b.unsupported) { // finish() runs every query on the general path
         for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
         b.in_flight = true;
@@ -1372,7 +1425,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         a.n_users = c->n_users; a.n_q = n_q; a.dshift = c->bdshift;                                                     \
         a.counts = reinterpret_cast<int*>(b.span);                                                                      \
         a.summary = reinterpret_cast<Summary*>(b.span + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128); \
-        a.direct = b.direct;                                                                                            \
+        a.direct = b.direct; a.run_shift = c->run_shift;                                                                \
         unsigned mk = IMPOSSIBLE;                                                                                       \
         for (int q = 0; q < n_q; ++q) {                                                                                 \
             a.q[q].now = qs[q].now; a.q[q].cutoff = qs[q].cutoff; a.q[q].pad = 0;                                       \
@@ -1406,25 +1459,20 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     return PIE_OK;
 }
 
-// one query of a batch on the general path; its results are copied into the batch's arrays
-int batch_fallback(pie_ctx* c, BatchSlot& b, int q)
+// Queries of a batch on the general path, two scans in flight (the offsets kernel of one rides in the next one's table
+// pass); every result is copied into the batch's arrays in stream order, one wait at the end.
+int batch_fallback_copy(pie_ctx* c, BatchSlot& b, int q)
 {
-    const unsigned long long keep_mask = c->disc_mask;
-    c->disc_mask = b.q[q].mask;
-    int rc = run_scan(c, b.q[q].now, b.q[q].cutoff);
-    c->disc_mask = keep_mask;
-    if (rc) return rc;
     Slot& sl = *c->res;
     hipStream_t s = c->stream;
     const long long us = batch_users_stride(c);
-    rc = ensure_batch(c, false);
-    if (rc) return rc;
     PIE_HIP(c, hipMemcpyAsync(b.counts_ord + (long long)q * us, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, s));
     PIE_HIP(c, hipMemcpyAsync(b.offsets + (long long)q * us, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, s));
     const long long m = (long long)sl.last.m;
     int* dst = b.out_idx ? b.out_idx + (long long)q * batch_out_stride(c) : nullptr;
     if (!dst || m > batch_out_stride(c)) {
         if (b.over_cap[q] < m || !b.over_idx[q]) {
+            PIE_HIP(c, hipStreamSynchronize(s)); // an earlier copy may still be reading the old buffer's neighbours: keep it simple
             dfree(b.over_idx[q]);
             b.over_cap[q] = 0;
             PIE_HIP(c, hipMalloc(&b.over_idx[q], (size_t)(m > 0 ? m : 1) * 4));
@@ -1435,14 +1483,38 @@ int batch_fallback(pie_ctx* c, BatchSlot& b, int q)
     if (m) PIE_HIP(c, hipMemcpyAsync(dst, sl.out_idx, (size_t)m * 4, hipMemcpyDeviceToDevice, s));
     b.idx_of[q] = dst;
     if (b.msg) {
-        rc = pie_pack_results_device(c, b.msg + (long long)q * b.msg_stride, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
+        int rc = pie_pack_results_device(c, b.msg + (long long)q * b.msg_stride, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
         if (rc) return rc;
     }
     if (b.msg_counts)
         PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDefault, s));
-    PIE_HIP(c, hipStreamSynchronize(s));
     b.last[q] = sl.last;
-    sl.have_result = false; // an implementation detail of the batch, not a feed result of its own
+    return PIE_OK;
+}
+
+int batch_fallback_many(pie_ctx* c, BatchSlot& b, const int* list, int n_list)
+{
+    if (n_list == 0) return PIE_OK;
+    int rc = ensure_batch(c, false);
+    if (rc) return rc;
+    const unsigned long long keep_mask = c->disc_mask;
+    auto begin = [&](int q) {
+        c->disc_mask = b.q[q].mask;
+        return scan_begin(c, b.q[q].now, b.q[q].cutoff);
+    };
+    rc = begin(list[0]);
+    for (int i = 0; i < n_list && rc == PIE_OK; ++i) {
+        if (i + 1 < n_list) rc = begin(list[i + 1]);
+        if (rc == PIE_OK) rc = scan_finish(c);
+        if (rc == PIE_OK) rc = batch_fallback_copy(c, b, list[i]);
+    }
+    c->disc_mask = keep_mask;
+    if (rc != PIE_OK) { // leave no scan in flight behind an error
+        while (c->n_flight) (void)scan_finish(c);
+        return rc;
+    }
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    for (Slot& sl : c->slot) sl.have_result = false; // implementation details of the batch, not feed results of their own
     c->res = nullptr;
     return PIE_OK;
 }
@@ -1494,16 +1566,24 @@ int batch_finish(pie_ctx* c, int* ready_out)
         if (b.n_q > 8 && (b.last[8].n_over > 0 || b.last[0].n_over > 0)) { // either query group found the overflow: it holds for the whole batch
             for (int q = 0; q < b.n_q; ++q) b.fallback[q] = true;
         }
-        if ((b.last[0].n_over > 0 || (b.n_q > 8 && b.last[8].n_over > 0)) && c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
+        if (b.last[0].n_over > 0 || (b.n_q > 8 && b.last[8].n_over > 0)) {
+            if (c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
+            else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
+        }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
+        choose_run_shift(c, b.last[0].cand, b.last[0].chunk_max, b.fine_key);
     }
     b.in_flight = false;
     c->b_flight--;
-    for (int q = 0; q < b.n_q; ++q) {
-        if (!b.fallback[q]) continue;
-        all_ready = false;
-        int rc = batch_fallback(c, b, q);
-        if (rc) return rc;
+    {
+        int list[kBatchMax], n_list = 0;
+        for (int q = 0; q < b.n_q; ++q)
+            if (b.fallback[q]) list[n_list++] = q;
+        if (n_list) {
+            all_ready = false;
+            int rc = batch_fallback_many(c, b, list, n_list);
+            if (rc) return rc;
+        }
     }
     b.have_result = true;
     c->bres = &b;
@@ -1577,6 +1657,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
+    if (const char* v = getenv("PIE_RUN_SHIFT")) { const int r = atoi(v); if (r >= 0 && r <= 3) { c->run_shift = r; c->run_shift_pinned = true; } }
     if (const char* v = getenv("PIE_WAIT_DEADLINE_MS")) { const double d = atof(v); if (d > 0) c->wait_deadline_ms = d; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);
@@ -1595,6 +1676,8 @@ int pie_ctx_destroy(pie_ctx* c)
     free_table(c);
     dfree(c->d_shard_rows);
     dfree(c->d_shard_users);
+    dfree(c->d_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& e : c->ring) {
         (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2);
     }
@@ -1657,6 +1740,42 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
     if (n_users < c->n_users) return fail(c, PIE_E_INVAL, "n_users may only grow (%d < %d)", n_users, c->n_users);
     PIE_HIP(c, hipSetDevice(c->device));
     const long long old_n = c->n;
+    if (k > 0 && old_n > 0 && old_n + (long long)k <= c->cap_rows && n_users <= c->cap_users && c->key_ok && k <= ((size_t)1 << 24)) {
+        // In-place path (room for the rows and the users, key columns in step): ONE staged upload, ONE kernel that writes the
+        // four columns, both keys and the payload record of every new row and validates the user ids, ONE wait.  A login
+        // burst costs tens of microseconds, not the half-dozen blocking calls of the general path below.
+        if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
+        if (old_n + (long long)k >= (1LL << 31) - 1) return fail(c, PIE_E_INVAL, "row count outside [0, 2^31 - 1)");
+        int rc0 = ensure_stage(c, k * 24 + 64);
+        if (rc0) return rc0;
+        char* h = c->h_stage;
+        memcpy(h, start, k * 8);
+        memcpy(h + k * 8, end, k * 8);
+        memcpy(h + k * 16, user, k * 4);
+        memcpy(h + k * 20, disc, k * 4);
+        hipStream_t s = c->stream;
+        PIE_HIP(c, hipMemcpyAsync(c->d_stage, h, k * 24, hipMemcpyHostToDevice, s));
+        PIE_HIP(c, hipMemsetAsync(&c->d_summary->bad_rows, 0, sizeof(unsigned int), s));
+        const unsigned grid = (unsigned)((k + 255) / 256) < (unsigned)c->n_cus * 8 ? (unsigned)((k + 255) / 256) : (unsigned)c->n_cus * 8;
+        hipLaunchKernelGGL(k_append_rows, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(c->d_stage),
+                           reinterpret_cast<const long long*>(c->d_stage + k * 8), reinterpret_cast<const int*>(c->d_stage + k * 16),
+                           reinterpret_cast<const int*>(c->d_stage + k * 20), (long long)k, old_n, n_users, c->d_start, c->d_end, c->d_user,
+                           c->d_disc, c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift, c->d_pay,
+                           &c->d_summary->bad_rows);
+        PIE_HIP(c, hipGetLastError());
+        PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+        if (c->h_summary->bad_rows) // the rows were written beyond n: the table itself is unchanged
+            return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", c->h_summary->bad_rows, n_users);
+        c->n = old_n + (long long)k;
+        if (n_users > c->n_users) set_user_count(c, n_users);
+        c->key_dirty = true;
+        c->res = nullptr;
+        for (Slot& sl : c->slot) sl.have_result = false;
+        c->bres = nullptr;
+        plan_k1(c);
+        return PIE_OK;
+    }
     int rc = ensure_capacity(c, old_n + (long long)k, n_users, old_n > 0 ? old_n : 1);
     if (rc) return rc;
     if (k > 0) {
@@ -1830,20 +1949,18 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     for (size_t i = 0; i < k; ++i)
         if (rows[i] < 0 || rows[i] >= c->n) return fail(c, PIE_E_INVAL, "row %d outside the table", rows[i]);
     PIE_HIP(c, hipSetDevice(c->device));
-    int* d_rows = nullptr;
-    long long* d_new = nullptr;
-    PIE_HIP(c, hipMalloc(&d_rows, k * 4));
-    hipError_t e = hipMalloc(&d_new, k * 8);
-    if (e != hipSuccess) { (void)hipFree(d_rows); return fail(c, PIE_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    (void)hipMemcpyAsync(d_rows, rows, k * 4, hipMemcpyHostToDevice, c->stream);
-    (void)hipMemcpyAsync(d_new, new_end, k * 8, hipMemcpyHostToDevice, c->stream);
-    hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end, d_rows, d_new,
-                       (long long)k, c->n, c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift);
+    // staged like the append path: one upload of [new_end k | rows k], one kernel (end + both keys), one wait
+    int rc = ensure_stage(c, k * 12 + 64);
+    if (rc) return rc;
+    memcpy(c->h_stage, new_end, k * 8);
+    memcpy(c->h_stage + k * 8, rows, k * 4);
+    PIE_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, k * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end,
+                       reinterpret_cast<const int*>(c->d_stage + k * 8), reinterpret_cast<const long long*>(c->d_stage), (long long)k, c->n,
+                       c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift);
+    PIE_HIP(c, hipGetLastError());
     c->key_dirty = true;
-    e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_rows);
-    (void)hipFree(d_new);
-    if (e != hipSuccess) return fail(c, PIE_E_HIP, "pie_set_end: %s", hipGetErrorString(e));
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
     return PIE_OK;
 }
 

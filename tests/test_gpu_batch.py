@@ -36,6 +36,7 @@ def mixed_queries(oracle, k):
 
 @pytest.mark.parametrize("n,U,D,flags", [
     (1, 1, 1, 0), (65, 3, 2, 0), (4097, 9, 7, 1), (100003, 97, 32, 0), (1 << 20, 10 ** 4, 32, 0), (3000017, 20011, 64, 1),
+    (1 << 20, 10 ** 4, 32, 4), (3000017, 20011, 64, 5),   # rows in order of creation: every live row at the table's end
 ])
 @pytest.mark.parametrize("nq", [1, 3, 16])
 def test_batch_equals_separate_scans(gpu_ctx, oracle, n, U, D, flags, nq):

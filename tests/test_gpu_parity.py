@@ -100,6 +100,7 @@ def test_hand_derived_vectors(gpu_ctx):
     (1, 1, 1, 0), (63, 2, 2, 0), (64, 2, 2, 1), (65, 3, 2, 0), (511, 5, 7, 1), (512, 5, 7, 0), (513, 5, 7, 3),
     (2047, 11, 32, 0), (2048, 11, 32, 1), (2049, 11, 32, 2), (100003, 97, 32, 0), (300000, 1, 32, 1),
     (1 << 20, 10 ** 4, 32, 0), (1 << 20, 10 ** 4, 32, 3), (3000017, 2049, 64, 1),
+    (70001, 333, 32, 4), (1 << 20, 10 ** 4, 32, 4), (2500013, 5000, 32, 5),   # rows in order of creation: live rows at the table's end
 ])
 def test_parity_small(gpu_ctx, oracle, n, U, D, flags):
     cols = oracle.gen(SEED, n, 0, n, U, D, flags)

@@ -5,14 +5,21 @@ mkdir -p gpurun_out
 : > $out
 run() {
   echo "== $*" >> $out
-  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null \
-    | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms_per_step', round(d['ms_per_step'],5), r['kernel'], r['kernel_variant'], 'k1_ms', round(r['kernel_ms'],5), 'M', d['config']['selected_rows_rank0'])" >> $out
+  python3 bench.py --steps 100 --warmup 10 --repeat 3 --no-cpu-baseline --no-extra "$@" 2>/dev/null \
+    | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms_per_step', round(d['ms_per_step'],5), 'Q', d.get('queries_per_launch'), 'feeds/s %.3e' % d['value'], r['kernel'], r['kernel_variant'], 'k1_ms', round(r['kernel_ms'],5), 'M', d['config']['selected_rows_rank0'], d.get('mixed') and {k: round(v, 4) for k, v in d['mixed'].items() if k.endswith('_ms')} or '')" >> $out
 }
 run
-run --order clustered
-run --variant interval
+run --queries-per-launch 1
+run --order time
+run --order time --queries-per-launch 1
+run --order clustered --queries-per-launch 1
+run --variant interval --queries-per-launch 1
+run --users-dist zipf --queries-per-launch 1
 run --users-dist zipf
 run --rows 10000000 --users 10000
-run --rows 1000 --users 10 --disc 4
-run --query wide --steps 50
-run --mode expired --steps 100
+run --rows 10000000 --users 10000 --queries-per-launch 1
+run --rows 1000 --users 10 --disc 4 --queries-per-launch 1
+run --query wide --steps 30 --queries-per-launch 1
+run --mode expired --steps 60
+run --mode mixed --steps 50
+cat $out
