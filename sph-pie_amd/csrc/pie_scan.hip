@@ -2482,6 +2482,9 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
         per_slot += (uint64_t)kPartMax * kPartCap * sizeof(SelRec);
     }
     out->workspace_bytes = rows ? 2 * per_slot + 3 * (uint64_t)counts_span(c) : 0;
+    if (c->batch_alloc) // batched scans: per slot 16 sets of counts / offsets / row lists + the union bucket slots, 3 span sets
+        out->workspace_bytes += 2 * ((uint64_t)kBatchMax * (uint64_t)batch_users_stride(c) * 12 + (uint64_t)kBatchMax * (uint64_t)batch_out_stride(c) * 4 +
+                                     ((uint64_t)users << c->bdshift) * sizeof(BktRec)) + 3 * (uint64_t)kBatchMax * (uint64_t)counts_span(c);
     out->index_build_ms = c->index_build_ms;
     return PIE_OK;
 }
