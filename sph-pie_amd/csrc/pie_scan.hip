@@ -139,6 +139,7 @@ struct pie_ctx {
     long long n = 0;
     int n_users = 0;
     long long cap_rows = 0;
+    long long sel_cap = 0;      // records the staging arrays (sel, sel_rank) of each slot hold: see ensure_sel
     int cap_users = 0;
     long long *d_start = nullptr, *d_end = nullptr;
     int *d_user = nullptr, *d_disc = nullptr;
@@ -285,6 +286,7 @@ void free_slots(pie_ctx* c)
     }
     for (char*& sp : c->span) dfree(sp);
     c->span_next = 0;
+    c->sel_cap = 0;
     c->res = nullptr;
     c->n_flight = 0;
     c->next_slot = 0;
@@ -361,6 +363,34 @@ void plan_k1(pie_ctx* c)
     plan_one(c, 3, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_FINE");
 }
 
+// The staging arrays give block b of a table pass the private region [b * rows_per_block, (b + 1) * rows_per_block): a
+// block never stages more records than it reads, and since the keyed pass deals rows in interleaved chunks EVERY block,
+// the last one too, reads up to rows_per_block rows — so the arrays must hold blocks x rows_per_block records of the
+// largest plan (up to one block's worth beyond n), not n.  (Found by the differential fuzz: a dense query on the keyed
+// form overran the arrays by most of a block and trampled the neighbouring allocation.)
+int ensure_sel(pie_ctx* c)
+{
+    long long need = c->cap_rows + 256;
+    for (int k = 0; k < 4; ++k) {
+        const long long span = (long long)c->plan_blocks[k] * c->plan_rows[k] + 256;
+        if (span > need) need = span;
+    }
+    if (need <= c->sel_cap && c->slot[0].sel) return PIE_OK;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    for (Slot& s : c->slot) {
+        dfree(s.sel);
+        dfree(s.sel_rank);
+    }
+    c->sel_cap = 0;
+    need += need / 16 + 65536; // room for the plans of a table that grows inside its capacity
+    for (Slot& s : c->slot) {
+        PIE_HIP(c, hipMalloc(&s.sel, (size_t)need * sizeof(SelRec)));
+        PIE_HIP(c, hipMalloc(&s.sel_rank, (size_t)need * 4));
+    }
+    c->sel_cap = need;
+    return PIE_OK;
+}
+
 // layout of a slot's span (all parts 128-byte aligned, total a multiple of 16 bytes so K2 can zero it as int4)
 size_t span_counts_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users + 32) * 4 + 127) / 128) * 128; } // +32: the transposed histogram rounds U up to a multiple of 32
 size_t span_tiles_bytes(const pie_ctx* c) { return ((((size_t)c->cap_users / 256 + 2) * 8 + 127) / 128) * 128; } // sized for the smallest tile shape
@@ -432,8 +462,6 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
             PIE_HIP(c, hipMalloc(&s.offsets, ((size_t)users + 1) * 8));
             PIE_HIP(c, hipMalloc(&s.counts_ord, ((size_t)users + 1) * 4));
             // +256: K3 fetches a region's first 256 records before it knows the count
-            PIE_HIP(c, hipMalloc(&s.sel, (rows + 256) * sizeof(SelRec)));
-            PIE_HIP(c, hipMalloc(&s.sel_rank, (rows + 256) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_count, (max_blocks * kK1Waves + 8) * 4));
             PIE_HIP(c, hipMalloc(&s.blk_hot_base, (size_t)(max_blocks + 8) * kHotMax * 4));
             PIE_HIP(c, hipMalloc(&s.hot_list, (size_t)kHotMax * 4));
@@ -474,7 +502,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     for (char* sp : c->span) PIE_HIP(c, hipMemsetAsync(sp, 0, counts_span(c), c->stream));
     c->span_next = 0;
     plan_k1(c);
-    return PIE_OK;
+    return ensure_sel(c);
 }
 
 // pinned host + device staging blocks of at least `bytes` (one pair per context; the context is used by one thread)
@@ -1774,7 +1802,7 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
         for (Slot& sl : c->slot) sl.have_result = false;
         c->bres = nullptr;
         plan_k1(c);
-        return PIE_OK;
+        return ensure_sel(c);
     }
     int rc = ensure_capacity(c, old_n + (long long)k, n_users, old_n > 0 ? old_n : 1);
     if (rc) return rc;
@@ -2476,7 +2504,7 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
     // mirrors ensure_capacity(): per slot sel + sel_rank + bkt + out_idx (row-sized), the direct slots, the per-user arrays
     uint64_t per_slot = 0;
     if (rows) {
-        per_slot += (uint64_t)(rows + 256) * (sizeof(SelRec) + 4) + (uint64_t)rows * (sizeof(BktRec) + 4);
+        per_slot += (uint64_t)c->sel_cap * (sizeof(SelRec) + 4) + (uint64_t)rows * (sizeof(BktRec) + 4);
         per_slot += (uint64_t)users * (8 + 4 + 4 + sizeof(Segment) * 2 + 4) + (uint64_t)(rows / kSegMax) * sizeof(Segment);
         if (c->slot[0].direct) per_slot += ((uint64_t)users << c->dshift) * sizeof(BktRec);
         per_slot += (uint64_t)kPartMax * kPartCap * sizeof(SelRec);

@@ -335,3 +335,36 @@ def test_communicator_behind_the_c_abi(pie, oracle):
         check(comm, U + 3)
     with pytest.raises(pie.PieError):
         pie.PieComm([0, 0])
+
+
+def test_few_users_dense_queries_on_the_keyed_form(pie, oracle, monkeypatch):
+    """Found by tools/fuzz_gpu.py (case seed 20261039): three users, one discipline, the keyed form pinned, batches whose
+    queries are dense.  With rows dealt to the waves in interleaved chunks EVERY block (the last one too) can stage up
+    to rows_per_block records, so the staging arrays are sized blocks x rows_per_block of the largest plan, not rows —
+    an overrun there corrupted the neighbouring allocation and a later batch never published its summary."""
+    monkeypatch.setenv("PIE_K1_VARIANT", "0x425")
+    monkeypatch.setenv("PIE_WAIT_DEADLINE_MS", "5000")
+    rng = np.random.default_rng(20261039)
+    n, U, D, flags = 300000, 3, 1, 3
+    cols = oracle.gen(12345, n, 0, n, U, D, flags)
+    s = cols[0]
+    t0 = oracle.T0_MS
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(1, D)
+
+        def rq():
+            now = int(t0 - rng.integers(0, 20 * HOUR)) if rng.random() < 0.6 else int(t0 - rng.integers(0, 130 * DAY))
+            cutoff = int(rng.choice([INT64_MIN, t0 - 61 * DAY, int(s[int(rng.integers(n))])]))
+            mask = int(rng.integers(0, 2 ** 63)) if rng.random() < 0.7 else ALL
+            return now, cutoff, mask
+        for trial in range(8):
+            batches = [[rq() for _ in range(int(rng.integers(1, 17)))] for _ in range(int(rng.integers(1, 4)))]
+            ctx.scan_batch_begin(batches[0])
+            for k, batch in enumerate(batches):
+                if k + 1 < len(batches):
+                    ctx.scan_batch_begin(batches[k + 1])
+                ctx.scan_batch_finish()
+                want = oracle_answers(oracle, cols, U, D, batch)
+                for qi in range(len(batch)):
+                    assert_same(ctx.batch_read_results(qi), want[qi], f"trial {trial} batch {k} q{qi}")

@@ -42,7 +42,7 @@ while time.time() < t_end:
     n = int(rng.choice([1, 7, 300, 5000, 70001, 300000, 1 << 20]))
     U = int(rng.choice([1, 3, 50, 1000, 40000, 600000]))
     D = int(rng.choice([1, 7, 32, 64]))
-    flags = int(rng.integers(4))
+    flags = int(rng.integers(8))   # interval / user-clustered / creation-ordered, in any combination
     what = "seed %d form %s n %d U %d D %d flags %d" % (case_seed, form, n, U, D, flags)
     try:
         s, e, u, d = [c.copy() for c in oracle.gen(int(rng.integers(1, 2 ** 60)), n, 0, n, U, D, flags)]
@@ -118,6 +118,28 @@ while time.time() < t_end:
                         raise AssertionError(what + " message now %d cutoff %d u_pad %d cap %d: got_m %d m %d, first bad offsets %s, pad %s, rows %s, variant %s"
                                              % (now, cutoff, u_pad, cap, got_m, m, bad.tolist(), a[U + 1: u_pad + 2].tolist(), a[u_pad + 2:].tolist()[:8], hex(ctx.stats()["k1_variant"])))
                     scans += 1
+                if rng.random() < 0.5:   # batched scans: random queries with their own now / cutoff / mask, 1 or 2 batches in flight
+                    def rand_query():
+                        qq = rng.random()
+                        nw = int(T0 - rng.integers(0, 20 * 3600 * 1000)) if qq < 0.6 else int(T0 - rng.integers(0, 130 * DAY)) if qq < 0.85 else \
+                            int(rng.choice([INT64_MIN, 2 ** 62, int(e[int(rng.integers(n))]), int(e[int(rng.integers(n))]) - 1]))
+                        ct = int(rng.choice([INT64_MIN, T0 - 61 * DAY, int(s[int(rng.integers(n))])]))
+                        mk = int(rng.integers(0, 2 ** 63)) | (int(rng.integers(0, 2)) << 63) if rng.random() < 0.7 else 2 ** 64 - 1
+                        return nw, ct, mk
+                    lim = 2 ** 64 - 1 if D >= 64 else (1 << D) - 1
+                    batches = [[rand_query() for _ in range(int(rng.integers(1, 17)))] for _ in range(int(rng.integers(1, 4)))]
+                    ctx.scan_batch_begin(batches[0])
+                    for k in range(len(batches)):
+                        if k + 1 < len(batches):
+                            ctx.scan_batch_begin(batches[k + 1])
+                        ms = ctx.scan_batch_finish()
+                        for qi, (nw, ct, mk) in enumerate(batches[k]):
+                            w = oracle.scan(s, e, u, d, U, nw, ct, mk & lim)
+                            if ms[qi] != w[2].size:
+                                raise AssertionError(what + " batch %d query %d: M differs" % (k, qi))
+                            same(ctx.batch_read_results(qi), w, what + " batch %d query %d now %d cutoff %d mask %x" % (k, qi, nw, ct, mk))
+                            scans += 1
+                    ctx.set_disciplines(mask, D)
                 if rng.random() < 0.3:
                     prev = int(now - rng.integers(0, 3 * DAY)) if now > INT64_MIN + 4 * DAY else INT64_MIN
                     if not np.array_equal(ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now)):
