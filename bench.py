@@ -51,6 +51,10 @@ def kernel_name(variant, rides, mode):
     """Name of the table-pass kernel a scan form runs (as rocprofv3 prints it, without 'void pie::')."""
     if mode == "expired":
         return "k_expired_stage<8>" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed<2>"
+    if variant & 0x2000:   # the ordered run (pie_ordered.h)
+        if variant & 0x400:
+            return "k_ord_scan_keyed<%s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
+        return "k_ord_scan_dense"
     if variant & 0x400:
         kt = "unsigned char" if variant & 0x800 else "unsigned short"
         agg = "true" if variant & 0x40 else "false"
@@ -427,6 +431,7 @@ def main():
     line = None
     if rank == 0:
         variant = st["k1_variant"]
+        info = ctx.table_info()   # again: an ordered run, if the scans called for one, was built during the warm-up
         rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
         kname = kernel_name(variant, rides, args.mode)
         if batch_ms is not None:
@@ -505,6 +510,8 @@ def main():
             },
             "index": {"index_build_ms": info["index_build_ms"], "derived_bytes": info["derived_bytes"],
                       "table_bytes": info["table_bytes"], "workspace_bytes": info["workspace_bytes"],
+                      "ordered_run": {"rows": info["ordered_rows"], "bytes": info["ordered_bytes"], "build_ms": info["ordered_build_ms"],
+                                      "builds": info["ordered_builds"]},
                       "note": "the keyed pass reads derived columns built at load (outside the timed region) and kept in step by every "
                               "writer of `end`; index_build_ms = one full build on this table"},
         }

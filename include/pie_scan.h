@@ -61,7 +61,8 @@ typedef struct pie_stats {
     uint32_t k1_blocks;    /* grid of the scan kernel */
     uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first,
                               0x400 keyed: streams the 2-byte liveness key instead of the `end` column, 0x800 the 1-byte key,
-                              0x1000 batched: the last finished call was a batch, `selected` sums its queries) */
+                              0x1000 batched: the last finished call was a batch, `selected` sums its queries,
+                              0x2000 ordered run: 0x2003 dense form, 0x2400 / 0x2C00 keyed form on the 2- / 1-byte key) */
     uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
     uint64_t live;         /* rows with end > now seen by the last scan */
     uint64_t candidates;   /* keyed form: rows whose key was >= the query's, i.e. payload records the table pass gathered */
@@ -241,8 +242,21 @@ typedef struct pie_table_info {
     uint64_t derived_bytes;   /* derived columns (2-byte key, 1-byte key, 16-byte payload record) */
     uint64_t workspace_bytes; /* per-scan workspace of the two slots + histogram spans */
     double index_build_ms;    /* host wall time of the last full build of the derived columns (kernels + syncs) */
+    uint64_t ordered_rows;    /* positions of the ordered run (0: there is none, or it was invalidated) */
+    uint64_t ordered_bytes;   /* device memory of the ordered run (31 B per row of capacity + small per-unit arrays) */
+    double ordered_build_ms;  /* host wall time of its last build (one all-selecting scan + a gather) */
+    uint64_t ordered_builds;  /* times it was built for this context */
 } pie_table_info;
 int pie_table_info_get(pie_ctx *ctx, pie_table_info *out);
+/* The ordered run (sph-pie_amd/csrc/pie_ordered.h): the table's rows a second time, in (user, start, row) order — the order
+ * of every answer — so that a query is a filter over positions: no histogram atomics, no per-bucket sort, no dependence on
+ * how rows are spread over users.  There is no counterpart in the reference (its Map is scanned per request,
+ * server/sessionStore.js:55-73); results are identical to the general path's.  mode 0: never (frees it); 1 (default):
+ * built and used when the general path is weak — a query selecting more than 1/24 of the rows, or skewed users — the second
+ * time in a row such a query arrives; 2: always (built at the next scan).  Touches and deletes keep it in step; loads,
+ * appends and sharding invalidate it (queries run on the general path until it is rebuilt).  PIE_ORDERED=0|1|2 sets the
+ * mode a context starts with. */
+int pie_set_ordered_run(pie_ctx *ctx, int mode);
 /* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
  * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */
 int pie_set_profiling(pie_ctx *ctx, int enabled);

@@ -28,7 +28,8 @@ class PieTableInfo(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("has_keys", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
         ("table_bytes", C.c_uint64), ("derived_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64),
-        ("index_build_ms", C.c_double),
+        ("index_build_ms", C.c_double), ("ordered_rows", C.c_uint64), ("ordered_bytes", C.c_uint64),
+        ("ordered_build_ms", C.c_double), ("ordered_builds", C.c_uint64),
     ]
 
 
@@ -80,6 +81,7 @@ _SIGS = [
     ("pie_host_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(_P)]),
     ("pie_host_free", C.c_int, [_P, _P]),
     ("pie_set_scan_form", C.c_int, [_P, C.c_int]),
+    ("pie_set_ordered_run", C.c_int, [_P, C.c_int]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
     ("pie_scan_batch_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
@@ -338,6 +340,10 @@ class PieScan:
     def set_scan_form(self, form):
         """Pin the table-pass form (pie_stats.k1_variant codes); form < 0: adaptive."""
         self._check(self._lib.pie_set_scan_form(self._ctx, int(form)))
+
+    def set_ordered_run(self, mode):
+        """0: never (frees the run), 1: adaptive (default), 2: always (pie_set_ordered_run)."""
+        self._check(self._lib.pie_set_ordered_run(self._ctx, int(mode)))
 
     def table_info(self):
         ti = PieTableInfo()

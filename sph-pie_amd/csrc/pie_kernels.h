@@ -654,6 +654,28 @@ __device__ __forceinline__ unsigned key_of(long long e, long long base, int shif
     return k >= (unsigned long long)(kmax - 1u) ? kmax : (unsigned)k + 1u;
 }
 
+// The ordered run (pie_ordered.h) keeps its own copies of `end` and of both keys, in (user, start, row) order.  Every writer of
+// `end` that does not invalidate the run mirrors its store through the row -> position map; a row the run does not hold
+// (tombstoned when the run was built) that comes back to life is counted in *stale (mapped host memory): the host call
+// that made the store reads it when its kernel has finished and drops the run.
+struct OrdMirror {
+    const int* pos;        // nullptr: no ordered run
+    long long* end;
+    lkey_t* key;
+    fkey_t* fkey;
+    unsigned int* stale;
+};
+__device__ __forceinline__ void ord_mirror_end(const OrdMirror& o, long long row, long long e, unsigned k, unsigned fk)
+{
+    if (!o.pos) return;
+    const int p = o.pos[row];
+    if (p >= 0) {
+        o.end[p] = e;
+        o.key[p] = (lkey_t)k;
+        o.fkey[p] = (fkey_t)fk;
+    } else if (e != INT64_MIN) __hip_atomic_fetch_add(o.stale, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // mapped host memory
+}
+
 // histogram of the 15-bit keys of rows [0, n), 8 keys per bin, privatised in LDS
 __global__ __launch_bounds__(1024) void k_key_hist(const lkey_t* __restrict__ key, long long n, unsigned int* __restrict__ hist)
 {
@@ -2745,13 +2767,15 @@ __global__ __launch_bounds__(256) void k_pack_results(const long long* __restric
 __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, const int* __restrict__ rows,
                                                  const long long* __restrict__ new_end, long long k, long long n,
                                                  lkey_t* __restrict__ key, long long key_base, int key_shift,
-                                                 fkey_t* __restrict__ fkey, long long fkey_base, int fkey_shift)
+                                                 fkey_t* __restrict__ fkey, long long fkey_base, int fkey_shift, OrdMirror ord)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < k && (unsigned)rows[t] < (unsigned long long)n) {
         end[rows[t]] = new_end[t];
-        if (key) key[rows[t]] = (lkey_t)key_of(new_end[t], key_base, key_shift);
-        if (fkey) fkey[rows[t]] = (fkey_t)key_of(new_end[t], fkey_base, fkey_shift, kFineKeyMax);
+        const unsigned kk = key_of(new_end[t], key_base, key_shift), fk = key_of(new_end[t], fkey_base, fkey_shift, kFineKeyMax);
+        if (key) key[rows[t]] = (lkey_t)kk;
+        if (fkey) fkey[rows[t]] = (fkey_t)fk;
+        ord_mirror_end(ord, rows[t], new_end[t], kk, fk);
     }
 }
 
@@ -2912,7 +2936,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end, const int* __restrict__ user, long long n,
                                                     long long rows_per_block, long long a, long long b,
                                                     const long long* __restrict__ blk_off, int* __restrict__ queue, long long cap,
-                                                    lkey_t* __restrict__ key, fkey_t* __restrict__ fkey)
+                                                    lkey_t* __restrict__ key, fkey_t* __restrict__ fkey, OrdMirror ord)
 {
     __shared__ int wcount[4];
     __shared__ long long carry_s;
@@ -2936,6 +2960,7 @@ __global__ __launch_bounds__(256) void k_list_write(long long* __restrict__ end,
                 end[r] = INT64_MIN;
                 if (key) key[r] = 0;
                 if (fkey) fkey[r] = 0;
+                ord_mirror_end(ord, r, INT64_MIN, 0u, 0u);
             }
         }
         __syncthreads();

@@ -1,0 +1,529 @@
+// The ordered run: the table's rows a second time, in the order every answer wants them.
+//
+// A feed scan returns, per user, the selected rows ordered by (start, row).  The general path finds that grouping and
+// order anew for every query: one returning histogram atomic per selected row (25 G/s chip-wide, whatever the scope:
+// DESIGN.md "What the atomics cost") and a per-bucket sort — fine for the sparse spec query, 1.8 ms when a quarter of a
+// 10^8-row table is selected, and at the mercy of the user distribution (a Zipf head user is one bucket of 41 k rows).
+// None of that work depends on the query: (user, start, row) is a property of the TABLE.  The ordered run stores the
+// rows once in that order — the result of the all-selecting scan, i.e. built by the general path itself — as
+//     o_pay[i] = {start, row, disc}   o_end[i]   o_key[i] / o_fkey[i] (the liveness keys of o_end)   pos[row] = i
+// plus uoff[u], the first position of user u.  A query is then a FILTER over positions 0 .. n_ord: the selected positions,
+// in position order, ARE the answer (idx = their row ids, offsets[u] = selected positions before uoff[u]).  No atomics,
+// no sort, no dependence on how the rows are spread over the users; every kernel below is a straight pass:
+//
+//   k_ord_scan_dense    every position: 2-byte key + 16-byte record (18 B/row, `end` only for ambiguous keys); per 4096-position
+//                       tile the selected row ids go to the staging array in order, with the tile's count and its 64 slice
+//                       ballots / prefixes (what a rank lookup needs)
+//   k_ord_scan_keyed    the sparse form: streams only the key column (1 or 2 B/row), candidates of a chunk queue up IN POSITION
+//                       ORDER in a per-wave LDS ring and are evaluated 64 at a time (one 16-byte gather each); the selected
+//                       positions of a chunk go to the staging array in order, with the chunk's count.  Chunks are dealt to
+//                       the waves round robin (a dense stretch — the head user's live rows — spreads over as many waves as it
+//                       has chunks)
+//   k_ord_prefix        exclusive prefix of the unit (tile / chunk) counts, two levels in one launch
+//   k_ord_emit          the copy staging -> idx (balanced per element / per tile) and, in other blocks of the same launch,
+//                       offsets[u] = rank of uoff[u] among the selected positions, counts, largest bucket
+//   k_ord_publish       one wave: summary to the host
+//
+// No kernel waits for another block: there is no look-back, no ticket, no spin anywhere in this file ("the block that
+// finishes last does X" is a counter, not a wait).
+//
+// Writers of `end` (touch, delete, purge) mirror their store into o_end / the keys through pos[] (OrdMirror in
+// pie_kernels.h); anything that changes the set of rows (load, append, shard) invalidates the run and the host falls
+// back to the general path until it is rebuilt.
+#pragma once
+
+namespace pie {
+
+struct alignas(16) OrdRec {
+    long long start;
+    int row;
+    int disc;
+};
+
+constexpr int kOrdTile = 4096;       // positions per unit of the dense form
+constexpr int kOrdTileShift = 12;
+constexpr int kOrdSlices = kOrdTile / kWave;
+
+struct OrdCtl {
+    unsigned int done_prefix; // blocks of the prefix kernel that have finished
+    unsigned int pad[3];
+};
+
+// out_idx of the all-selecting scan -> the run's columns
+__global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx, long long m, const PayRec* __restrict__ pay,
+                                                    const long long* __restrict__ end, const lkey_t* __restrict__ key,
+                                                    const fkey_t* __restrict__ fkey, OrdRec* __restrict__ o_pay,
+                                                    long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
+                                                    fkey_t* __restrict__ o_fkey, int* __restrict__ pos)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const int r = idx[i];
+        const PayRec p = pay[r];
+        OrdRec o;
+        o.start = p.start;
+        o.row = r;
+        o.disc = p.disc;
+        o_pay[i] = o;
+        o_end[i] = end[r];
+        o_key[i] = key[r];
+        o_fkey[i] = fkey[r];
+        pos[r] = (int)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dense form
+
+__global__ __launch_bounds__(256) void k_ord_scan_dense(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
+                                                        const lkey_t* __restrict__ key, long long n_ord, long long now,
+                                                        unsigned now_key, long long cutoff, unsigned long long mask,
+                                                        unsigned int* __restrict__ stage, int* __restrict__ unit_count,
+                                                        unsigned long long* __restrict__ tile_ballot,
+                                                        unsigned int* __restrict__ tile_prefix, Summary* __restrict__ summary)
+{
+    __shared__ int lrow[kOrdTile];
+    __shared__ unsigned long long sball[kOrdSlices];
+    __shared__ int wcnt[4];
+    __shared__ int blk_live, blk_amb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { blk_live = 0; blk_amb = 0; }
+    int nlive = 0, namb = 0;
+    int* mine = lrow + wave * 1024;
+    const long long n_tiles = (n_ord + kOrdTile - 1) >> kOrdTileShift;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long w0 = (t << kOrdTileShift) + (long long)wave * 1024;
+        int running = 0;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            OrdRec r[8];
+            unsigned k[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long p = w0 + (h * 8 + j) * 64 + lane;
+                k[j] = 0;
+                r[j].start = 0;
+                r[j].row = 0;
+                r[j].disc = -1;
+                if (p < n_ord) {
+                    k[j] = __builtin_nontemporal_load(key + p);
+                    const ll2_t raw = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(pay + p));
+                    r[j].start = raw.x;
+                    r[j].row = (int)(raw.y & 0xFFFFFFFFll);
+                    r[j].disc = (int)(raw.y >> 32);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long p = w0 + (h * 8 + j) * 64 + lane;
+                const bool valid = p < n_ord;
+                const bool amb = valid && k[j] == now_key;
+                bool live = valid && k[j] > now_key;
+                if (amb) live = end[p] > now;
+                const int dv = r[j].disc;
+                const bool sel = live && r[j].start >= cutoff && (unsigned)dv < 64u && (((mask >> (dv & 63)) & 1ull) != 0);
+                const unsigned long long b = __ballot(sel);
+                if (sel) mine[running + prefix_in_ballot(b)] = r[j].row;
+                running += __popcll(b);
+                if (lane == 0) sball[wave * 16 + h * 8 + j] = b;
+                nlive += __popcll(__ballot(live));
+                namb += __popcll(__ballot(amb));
+            }
+        }
+        if (lane == 0) wcnt[wave] = running;
+        __syncthreads();
+        int base_w = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cw = wcnt[w];
+            if (w < wave) base_w += cw;
+            total += cw;
+        }
+        unsigned int* dst = stage + (t << kOrdTileShift) + base_w;
+        for (int j = lane; j < running; j += 64) dst[j] = (unsigned)mine[j];
+        if (wave == 0) {
+            const unsigned long long b = sball[lane];
+            const int cnt = __popcll(b);
+            const int incl = wave_incl_scan_i32(cnt, lane);
+            tile_ballot[t * kOrdSlices + lane] = b;
+            tile_prefix[t * kOrdSlices + lane] = (unsigned)(incl - cnt);
+            if (lane == 0) unit_count[t] = total;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
+    __syncthreads();
+    if (threadIdx.x == 0) add_row_stats(summary, blk_live, blk_amb);
+}
+
+// ------------------------------------------------------------------------------------------------ keyed (sparse) form
+
+// KT = fkey_t: 1024 positions per chunk (16 per lane); KT = lkey_t: 512 (8 per lane).  The key arrays are padded with zero
+// keys to a whole number of chunks; a padding position can only become a candidate when key(now) == 0, and is dropped
+// when its batch is formed (pos >= n_ord).
+template <class KT>
+__global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
+                                                        const KT* __restrict__ key, long long n_ord, long long n_chunks,
+                                                        long long now, unsigned now_key, long long cutoff, unsigned long long mask,
+                                                        unsigned int* __restrict__ stage, int* __restrict__ unit_count,
+                                                        Summary* __restrict__ summary)
+{
+    constexpr int kPerLane = 16 / (int)sizeof(KT);
+    constexpr int kChunk = kPerLane * kWave;
+    constexpr int kChunkShift = sizeof(KT) == 1 ? 10 : 9;
+    constexpr int kRing = 2 * kChunk;
+    constexpr int kUnroll = 4;
+    __shared__ int ring_s[4][kRing];
+    __shared__ int blk_live, blk_amb, blk_cand, blk_chunk_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { blk_live = 0; blk_amb = 0; blk_cand = 0; blk_chunk_max = 0; }
+    __syncthreads();
+    int* ring = ring_s[wave];
+    int head = 0, fill = 0;                    // wave-uniform
+    int nlive = 0, namb = 0, ncand = 0, chunk_max = 0;
+    int cur_chunk = -1, cur_cnt = 0;           // the chunk of the last selected position so far and its count (not yet written)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+
+    bool a_have = false, a_valid = false, a_amb = false;
+    int a_pos = 0x7FFFFFFF;
+    OrdRec a_pay;
+    a_pay.start = 0; a_pay.row = 0; a_pay.disc = -1;
+    long long a_end = 0;
+
+    auto step_b = [&]() { // the gathers of the batch formed one step ago are back: evaluate, emit in position order
+        if (!a_have) return;
+        a_have = false;
+        bool live = false, sel = false;
+        if (a_valid) {
+            live = a_amb ? (a_end > now) : true;
+            const int dv = a_pay.disc;
+            sel = live && a_pay.start >= cutoff && (unsigned)dv < 64u && (((mask >> (dv & 63)) & 1ull) != 0);
+        }
+        nlive += __popcll(__ballot(live));
+        namb += __popcll(__ballot(a_valid && a_amb));
+        ncand += __popcll(__ballot(a_valid));
+        const unsigned long long sb = __ballot(sel);
+        if (sb == 0) return;
+        // positions ascend with the lane, so the lanes of one chunk are consecutive: a segment starts where the chunk id changes
+        const int ch = a_pos >> kChunkShift;
+        const int ch_below = __shfl_up(ch, 1, kWave);
+        const unsigned long long hb = __ballot(lane == 0 || ch != ch_below);
+        const int first = 63 - __clzll((long long)(hb & le));                       // first lane of my segment
+        int rank = __popcll(sb & lt & ~((1ull << first) - 1ull));
+        if (ch == cur_chunk) rank += cur_cnt;
+        const unsigned long long ha = hb & ~le;                                     // segment heads above me
+        const int seg_end = ha ? __ffsll((long long)ha) - 1 : 64;
+        const unsigned long long upto = seg_end == 64 ? ~0ull : ((1ull << seg_end) - 1ull);
+        const bool last_of_seg = sel && (sb & ~le & upto) == 0;
+        const int last = 63 - __clzll((long long)sb);                               // last selected lane of the batch
+        const int new_chunk = __shfl(ch, last, kWave);
+        const int new_cnt = __shfl(rank, last, kWave) + 1;
+        if (sel) {
+            stage[((long long)ch << kChunkShift) + rank] = (unsigned)a_pos;
+            // a chunk's count is written exactly once: here when no later batch can hold more of it, else it is carried
+            if (last_of_seg && ch != new_chunk) unit_count[ch] = rank + 1;
+        }
+        // the carried chunk got nothing in this batch and the batch moved past it: its count is final
+        if (cur_chunk >= 0 && cur_chunk != new_chunk && __ballot(sel && ch == cur_chunk) == 0 && lane == 0) unit_count[cur_chunk] = cur_cnt;
+        cur_chunk = new_chunk;
+        cur_cnt = new_cnt;
+    };
+    auto step_a = [&](int cnt) { // form a batch of cnt <= 64 candidates and issue its gathers
+        a_valid = false;
+        a_amb = false;
+        a_pos = 0x7FFFFFFF;
+        if (lane < cnt) {
+            const int ent = ring[(head + lane) & (kRing - 1)];
+            a_pos = ent & 0x7FFFFFFF;
+            if (a_pos < n_ord) {
+                a_valid = true;
+                a_amb = ent < 0;
+                a_pay = pay[a_pos];
+                if (a_amb) a_end = end[a_pos];
+            }
+        }
+        a_have = true;
+        head = (head + cnt) & (kRing - 1);
+        fill -= cnt;
+    };
+
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
+    const unsigned nk_ge = sizeof(KT) == 2 ? (now_key | (now_key << 16)) : now_key * 0x01010101u;
+    const unsigned nk1 = now_key + 1u; // <= 0x80 / 0x8000: still no borrow out of a byte / half
+    const unsigned nk_gt = sizeof(KT) == 2 ? (nk1 | (nk1 << 16)) : nk1 * 0x01010101u;
+    auto row_bits = [&](unsigned g0, unsigned g1, unsigned g2, unsigned g3) -> unsigned { // flags (top bit per key) -> one bit per row, row order
+        if constexpr (sizeof(KT) == 1) {
+            auto nib = [](unsigned g) { return ((((g >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+            return nib(g0) | (nib(g1) << 4) | (nib(g2) << 8) | (nib(g3) << 12);
+        } else {
+            auto two = [](unsigned g) { return ((g >> 15) & 1u) | ((g >> 30) & 2u); };
+            return two(g0) | (two(g1) << 2) | (two(g2) << 4) | (two(g3) << 6);
+        }
+    };
+
+    const long long W = (long long)gridDim.x * 4;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    for (long long cb = gw; cb < n_chunks; cb += W * kUnroll) {
+        u4_t kv[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const long long ch = cb + (long long)j * W;
+            kv[j] = (u4_t){0u, 0u, 0u, 0u};
+            if (ch < n_chunks) kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const long long ch = cb + (long long)j * W;
+            if (ch >= n_chunks) continue; // wave-uniform
+            const unsigned ge = row_bits(((kv[j].x | kTop) - nk_ge) & kTop, ((kv[j].y | kTop) - nk_ge) & kTop,
+                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop);
+            const unsigned gt = row_bits(((kv[j].x | kTop) - nk_gt) & kTop, ((kv[j].y | kTop) - nk_gt) & kTop,
+                                         ((kv[j].z | kTop) - nk_gt) & kTop, ((kv[j].w | kTop) - nk_gt) & kTop);
+            const int cnt = __popc(ge);
+            const int incl = wave_incl_scan_i32(cnt, lane);
+            const int total = __shfl(incl, 63, kWave);
+            if (total == 0) continue;
+            chunk_max = max(chunk_max, total);
+            int w = head + fill + incl - cnt;
+            const int p0 = (int)(ch << kChunkShift) + kPerLane * lane;
+            unsigned m = ge;
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                ring[w & (kRing - 1)] = (p0 + b) | (((gt >> b) & 1u) ? 0 : (int)0x80000000);
+                ++w;
+                m &= m - 1;
+            }
+            fill += total;
+            __builtin_amdgcn_wave_barrier();
+            while (fill >= kWave) {
+                step_b();
+                step_a(kWave);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (fill > 0) {
+        step_b();
+        step_a(fill);
+    }
+    step_b();
+    if (cur_chunk >= 0 && lane == 0) unit_count[cur_chunk] = cur_cnt;
+    if (lane == 0 && nlive) atomicAdd(&blk_live, nlive);
+    if (lane == 0 && namb) atomicAdd(&blk_amb, namb);
+    if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
+    if (lane == 0 && chunk_max) atomicMax(&blk_chunk_max, chunk_max);
+    __syncthreads();
+    if (threadIdx.x == 0) add_row_stats(summary, blk_live, blk_amb, (int)blockIdx.x, blk_cand, blk_chunk_max);
+}
+
+// ------------------------------------------------------------------------------------------------ prefix
+
+// Exclusive prefix of the unit counts, in two levels, one launch: block g scans the counts of group g (1024 units: four per
+// thread) into unit_local[] and reports the group's sum; the block that finishes LAST (a counter, not a wait) scans the group
+// sums into group_base[] and closes the list with M.  base(unit) = group_base[unit >> 10] + unit_local[unit].
+constexpr int kOrdGroupShift = 10;
+constexpr int kOrdGroup = 1 << kOrdGroupShift;
+
+__global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit_count, long long n_units, int* __restrict__ unit_local,
+                                                    long long* __restrict__ group_sum, long long* __restrict__ group_base,
+                                                    OrdCtl* __restrict__ ctl, Summary* __restrict__ summary)
+{
+    __shared__ int wsum[4];
+    __shared__ long long wsum64[4];
+    __shared__ bool is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
+    for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const long long u = (g << kOrdGroupShift) + 4 * (long long)threadIdx.x; // unit_count is padded to whole groups of zeros
+        const int4 c = *reinterpret_cast<const int4*>(unit_count + u);
+        const int mine = c.x + c.y + c.z + c.w;
+        const int incl = wave_incl_scan_i32(mine, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int sw = wsum[w];
+            if (w < wave) wbase += sw;
+            total += sw;
+        }
+        int4 o;
+        o.x = wbase + incl - mine;
+        o.y = o.x + c.x;
+        o.z = o.y + c.y;
+        o.w = o.z + c.z;
+        *reinterpret_cast<int4*>(unit_local + u) = o;
+        if (threadIdx.x == 0) group_sum[g] = total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(&ctl->done_prefix, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    long long carry = 0;
+    for (long long g0 = 0; g0 < n_groups; g0 += 256) {
+        const long long g = g0 + threadIdx.x;
+        const long long v = g < n_groups ? __hip_atomic_load(&group_sum[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const long long incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum64[wave] = incl;
+        __syncthreads();
+        long long wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const long long sw = wsum64[w];
+            if (w < wave) wbase += sw;
+            total += sw;
+        }
+        if (g < n_groups) group_base[g] = carry + wbase + incl - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        group_base[n_groups] = carry;
+        summary->m = (unsigned long long)carry;
+        ctl->done_prefix = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ emit: row list, offsets, counts, summary
+
+// One launch, two kinds of block.  Blocks [0, copy_blocks) write the row list:
+//   dense   block per tile: the tile's staged row ids are contiguous, so is their place in idx
+//   keyed   thread per output element k: its unit is found by a two-level search (group bases, then the group's
+//           unit_local[]) — balanced whatever the units hold (a head user's 80 chunks of 500 are 41 k elements like any
+//           others); the staged entry is a position, the row id comes from the run's record
+// Blocks [copy_blocks, ...) look after the users: thread t of user-block b has user b * 255 + t (the last thread's user is
+// the next block's first: its rank closes the block's last count); offsets[u] = selected positions before uoff[u],
+// u = n_users closes the list with M.
+template <bool KEYED>
+__global__ __launch_bounds__(256) void k_ord_emit(const long long* __restrict__ uoff, int n_users, long long n_ord, int unit_shift,
+                                                  const int* __restrict__ unit_count, const int* __restrict__ unit_local,
+                                                  const long long* __restrict__ group_base, long long n_units,
+                                                  const unsigned int* __restrict__ stage, const OrdRec* __restrict__ pay,
+                                                  const unsigned long long* __restrict__ tile_ballot,
+                                                  const unsigned int* __restrict__ tile_prefix, int* __restrict__ out_idx,
+                                                  long long* __restrict__ offsets, int* __restrict__ counts_ord, int copy_blocks,
+                                                  Summary* __restrict__ summary, int* __restrict__ zero_counts, long long zero_n)
+{
+    __shared__ long long soff[256];
+    __shared__ long long gb[1024];
+    __shared__ int wmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
+    // the other unit-count buffer starts the next ordered scan clean
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
+    if ((int)blockIdx.x < copy_blocks) {
+        if constexpr (KEYED) {
+            const long long m = group_base[n_groups];
+            const bool in_lds = n_groups < 1024;
+            if (in_lds)
+                for (int i = threadIdx.x; i <= (int)n_groups; i += 256) gb[i] = group_base[i];
+            __syncthreads();
+            for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < m; k += (long long)copy_blocks * 256) {
+                long long lo = 0, hi = n_groups - 1; // the largest g with group_base[g] <= k: never an empty group
+                while (lo < hi) {
+                    const long long mid = (lo + hi + 1) >> 1;
+                    if ((in_lds ? gb[mid] : group_base[mid]) <= k) lo = mid;
+                    else hi = mid - 1;
+                }
+                const int x = (int)(k - (in_lds ? gb[lo] : group_base[lo]));
+                const int* loc = unit_local + (lo << kOrdGroupShift);
+                int a = 0, b = kOrdGroup - 1;        // the largest j with loc[j] <= x: never an empty unit
+                while (a < b) {
+                    const int mid = (a + b + 1) >> 1;
+                    if (loc[mid] <= x) a = mid;
+                    else b = mid - 1;
+                }
+                const long long unit = (lo << kOrdGroupShift) + a;
+                const unsigned p = stage[(unit << unit_shift) + (x - loc[a])];
+                out_idx[k] = pay[p].row;
+            }
+        } else {
+            for (long long t = blockIdx.x; t < n_units; t += copy_blocks) {
+                const int cnt = unit_count[t];
+                const long long base = group_base[t >> kOrdGroupShift] + unit_local[t];
+                const unsigned int* src = stage + (t << kOrdTileShift);
+                for (int j = threadIdx.x; j < cnt; j += 256) out_idx[base + j] = (int)src[j];
+            }
+        }
+    } else {
+        const long long u = (long long)((int)blockIdx.x - copy_blocks) * 255 + threadIdx.x;
+        long long my = 0;
+        if (u <= n_users) {
+            const long long q = uoff[u];
+            if (q >= n_ord) my = group_base[n_groups];
+            else {
+                const long long unit = q >> unit_shift;
+                my = group_base[unit >> kOrdGroupShift] + unit_local[unit];
+                if constexpr (KEYED) {
+                    const unsigned int* s = stage + (unit << unit_shift);
+                    int lo = 0, hi = unit_count[unit];
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s[mid] < (unsigned)q) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    my += lo;
+                } else {
+                    const int in = (int)(q & (kOrdTile - 1));
+                    const long long sl = unit * kOrdSlices + (in >> 6);
+                    my += tile_prefix[sl] + __popcll(tile_ballot[sl] & ((1ull << (in & 63)) - 1ull));
+                }
+            }
+            offsets[u] = my;
+        }
+        soff[threadIdx.x] = my;
+        __syncthreads();
+        int cnt = 0;
+        if (threadIdx.x < 255 && u < n_users) {
+            cnt = (int)(soff[threadIdx.x + 1] - my);
+            counts_ord[u] = cnt;
+        }
+        int mx = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, kWave));
+        if (lane == 0) wmax[wave] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int bm = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+            if (bm > 0) atomicMax(&summary->max_count, (unsigned)bm);
+        }
+    }
+}
+
+// One wave behind the emit kernel: the row statistics of the table pass, M and the largest bucket -> mapped host memory, seq
+// last.  (A "last block publishes" tail inside k_ord_emit would cost every one of its thousands of blocks a device-scope
+// fence — an L2 write-back each, right after the row list was written — and an atomic on one address: measured 0.25 ms on
+// the dense query.  A kernel boundary orders the same thing for a few microseconds.)
+__global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summary, HostSummary* __restrict__ host, unsigned long long seq)
+{
+    const int lane = threadIdx.x;
+    unsigned long long live = 0, amb = 0, cand = 0;
+    unsigned int chunk_max = 0;
+    sum_row_stats(summary, lane, live, amb, &cand, &chunk_max);
+    { // this slot's statistics start the next ordered scan clean
+        StatSlot* slot = stat_slots(summary) + lane;
+        slot->live = 0;
+        slot->amb = 0;
+        slot->cand = 0;
+        slot->chunk_max = 0;
+    }
+    if (lane == 0) {
+        Summary out{};
+        out.m = summary->m;
+        out.max_count = summary->max_count;
+        out.live = live;
+        out.amb = amb;
+        out.cand = cand;
+        out.chunk_max = chunk_max;
+        summary->max_count = 0; // m stays: the pack kernel reads it from here, and the next prefix overwrites it
+        host->s = out;
+        __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+} // namespace pie

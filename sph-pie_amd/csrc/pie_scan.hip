@@ -20,6 +20,7 @@
 // (live fraction, ambiguous keys, hot buckets) — see scan_begin.
 #include "../../include/pie_scan.h"
 #include "pie_kernels.h"
+#include "pie_ordered.h"
 
 #include <hip/hip_runtime.h>
 
@@ -83,6 +84,7 @@ struct Slot {
     int* part_cursor = nullptr;   // in the span: cursors of the partitioned fast path
     SelRec* part_rec = nullptr;   // kPartMax x kPartCap records
     bool fast = false;            // this scan ran on the partitioned fast path
+    bool ordered = false;         // this scan ran on the ordered run (pie_ordered.h): nothing left to launch at finish
     long long q_now = 0, q_cutoff = 0; // the query, kept for a rerun on the general path
     int* big_list = nullptr;
     // per-scan host state
@@ -123,6 +125,37 @@ struct BatchSlot {
     long long msg_counts_stride = 0;
     int k1_blocks = 0;
     int ev_index = -1;
+};
+
+// the ordered run of the resident table (pie_ordered.h)
+struct OrderedRun {
+    int mode = 1;            // PIE_ORDERED: 0 = never, 1 = when the general path is weak (dense / skewed queries), 2 = always
+    bool valid = false;
+    long long n = 0;         // positions (= rows the all-selecting scan returned)
+    long long rows = 0;      // table rows the run was built from
+    long long cap = 0;       // positions the arrays hold
+    int cap_users = 0;
+    OrdRec* pay = nullptr;
+    long long* end = nullptr;
+    lkey_t* key = nullptr;
+    fkey_t* fkey = nullptr;
+    int* pos = nullptr;
+    long long* uoff = nullptr;
+    int* unit_count[2] = {nullptr, nullptr}; // alternate: the finish kernel of one ordered scan zeroes the other buffer
+    int uc_next = 0;
+    long long units_cap = 0;
+    int* unit_local = nullptr;               // exclusive prefix of the unit counts inside their group of 1024
+    long long* group_sum = nullptr;
+    long long* group_base = nullptr;
+    unsigned long long* tile_ballot = nullptr;
+    unsigned int* tile_prefix = nullptr;
+    unsigned int* h_stale = nullptr;         // mapped pinned: rows outside the run that a writer of `end` brought back to life
+    unsigned int* stale = nullptr;           // ... as the device sees it
+    bool no_room = false;                    // the arrays did not fit: not tried again for this table
+    char* sum[2] = {nullptr, nullptr};       // per scan slot: Summary + row-statistics slots + OrdCtl
+    unsigned wanted = 0;     // consecutive scans that wanted the run while it was not there
+    unsigned long long builds = 0;
+    double build_ms = 0;
 };
 
 } // namespace
@@ -198,6 +231,8 @@ struct pie_ctx {
     bool fast_enabled = false; // the partitioned path is opt-in (PIE_FAST_PATH=1): measured at parity with the general
     bool fast_env = false;     // path (0.179 vs 0.177 ms/step), so the simpler path stays the default; an overflow turns it off for the table
 
+    OrderedRun ord;
+    bool ord_building = false;  // the scan being begun is the ordered run's build
     Slot slot[2];
     BatchSlot bslot[2];         // batched scans (pie_scan_batch_begin): two batches may be in flight, like two scans
     char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating span SETS: kBatchMax spans each, query q at q * counts_span()
@@ -308,8 +343,40 @@ void free_batch(pie_ctx* c)
     c->batch_alloc = false;
 }
 
+void ord_free(pie_ctx* c)
+{
+    OrderedRun& o = c->ord;
+    dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff);
+    dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
+    dfree(o.sum[0]); dfree(o.sum[1]);
+    o.valid = false;
+    o.no_room = false;
+    o.cap = 0; o.cap_users = 0; o.units_cap = 0; o.n = 0; o.rows = 0; o.wanted = 0;
+}
+
+// the set of rows changed (load, append, shard, key refit): the run no longer describes the table
+void ord_invalidate(pie_ctx* c)
+{
+    c->ord.valid = false;
+    c->ord.wanted = 0;
+}
+
+OrdMirror ord_mirror_of(const pie_ctx* c)
+{
+    OrdMirror m{};
+    if (c->ord.valid) {
+        m.pos = c->ord.pos;
+        m.end = c->ord.end;
+        m.key = c->ord.key;
+        m.fkey = c->ord.fkey;
+        m.stale = c->ord.stale;
+    }
+    return m;
+}
+
 void free_table(pie_ctx* c)
 {
+    ord_free(c);
     free_batch(c);
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
     c->key_ok = false;
@@ -419,6 +486,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     int rc = sync_all(c);
     if (rc) return rc;
+    ord_invalidate(c);
     long long rows = n > 0 ? n : 1;
     if (rows > c->cap_rows || n_users > c->cap_users) {
         int users = n_users;
@@ -548,6 +616,7 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     hipStream_t s = c->stream;
     const int grid = c->n_cus * 8;
     const bool full_build = row0 == 0 || !c->key_ok || rebuild;
+    if (full_build) ord_invalidate(c); // the run carries copies of the keys
     timespec tb0{};
     if (full_build) { // index_build_ms of pie_table_info: everything from here to the last key kernel's completion
         PIE_HIP(c, hipStreamSynchronize(s));
@@ -766,6 +835,7 @@ int hot_threshold(const pie_ctx* c)
 
 void launch_k2(pie_ctx* c, Slot& sl, hipStream_t s, int4* zero_span, long long zero_vec16)
 {
+    if (!zero_span) zero_vec16 = 0; // a scan outside the span rotation (the ordered run's build) zeroes nothing
     const int hot_thr = hot_threshold(c);
     const int ob = c->order_block;
     const int order_tiles = (c->n_users + ob - 1) / ob;
@@ -832,8 +902,213 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
 }
 
 // Head of a scan: K1 and K2 on the stream (plus the tiny-bucket order kernel when buckets have direct slots).  No host wait.
+// ------------------------------------------------------------------------------------------------ the ordered run (pie_ordered.h)
+
+int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg, int msg_u_pad, long long msg_cap, int* msg_counts);
+int scan_finish(pie_ctx* c, Slot* which = nullptr);
+
+size_t ord_sum_bytes() { return span_stats_bytes() + 128; } // Summary + row-statistics slots, then OrdCtl
+
+// arrays for the table's current capacity; no room is not an error (the general path serves every query)
+int ord_alloc(pie_ctx* c)
+{
+    OrderedRun& o = c->ord;
+    if (o.pay && o.cap >= c->cap_rows && o.cap_users >= c->cap_users) return PIE_OK;
+    ord_free(c);
+    const size_t padded = (((size_t)c->cap_rows + 1023) / 1024) * 1024 + 1024; // whole chunks of zero keys behind the last row
+    const size_t units = ((padded / 512 + 8 + 1023) / 1024) * 1024;              // the smallest unit is a 512-position chunk; whole groups
+    const size_t tiles = padded / kOrdTile + 2;
+    const bool ok = hipMalloc(&o.pay, padded * sizeof(OrdRec)) == hipSuccess && hipMalloc(&o.end, padded * 8) == hipSuccess &&
+                    hipMalloc(&o.key, padded * sizeof(lkey_t)) == hipSuccess && hipMalloc(&o.fkey, padded * sizeof(fkey_t)) == hipSuccess &&
+                    hipMalloc(&o.pos, (size_t)c->cap_rows * 4 + 64) == hipSuccess &&
+                    hipMalloc(&o.uoff, ((size_t)c->cap_users + 1) * 8) == hipSuccess &&
+                    hipMalloc(&o.unit_count[0], units * 4) == hipSuccess && hipMalloc(&o.unit_count[1], units * 4) == hipSuccess &&
+                    hipMalloc(&o.unit_local, units * 4) == hipSuccess && hipMalloc(&o.group_sum, (units / 1024 + 2) * 8) == hipSuccess &&
+                    hipMalloc(&o.group_base, (units / 1024 + 2) * 8) == hipSuccess &&
+                    hipMalloc(&o.tile_ballot, tiles * kOrdSlices * 8) == hipSuccess &&
+                    hipMalloc(&o.tile_prefix, tiles * kOrdSlices * 4) == hipSuccess &&
+                    hipMalloc(&o.sum[0], ord_sum_bytes()) == hipSuccess && hipMalloc(&o.sum[1], ord_sum_bytes()) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        ord_free(c);
+        o.no_room = true;
+        return PIE_OK;
+    }
+    o.cap = c->cap_rows;
+    o.cap_users = c->cap_users;
+    o.units_cap = (long long)units;
+    return PIE_OK;
+}
+
+// Build the run: ONE all-selecting scan on the general path (every row that any query can ever select: end above
+// INT64_MIN, discipline inside the table) gives the rows in (user, start, row) order and the per-user segment starts;
+// a gather makes the run's columns from them.  Nothing the scan learns about the table is kept: it is not a query.
+int build_ordered(pie_ctx* c)
+{
+    OrderedRun& o = c->ord;
+    if (c->n_flight > 1) return fail(c, PIE_E_STATE, "ordered run: two scans are in flight");
+    hipStream_t s = c->stream;
+    PIE_HIP(c, hipStreamSynchronize(s));
+    timespec t0{};
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int rc = ord_alloc(c);
+    if (rc || !o.pay) return rc;
+    struct Keep {
+        unsigned long long mask; int n_disc, variant, dshift_want, next_slot, mode, run_shift, bdshift_want;
+        bool pinned, fast, hot_bucket, clustered, key_poor, fkey_poor, profiling, last_was_batch, batch_poor;
+        double live_frac; long long last_m; HotSet hot; unsigned hot_seen, hot_age; Slot* res;
+    } k{c->disc_mask, c->n_disc, c->k1_variant, c->dshift_want, c->next_slot, o.mode, c->run_shift, c->bdshift_want,
+        c->k1_pinned, c->fast_enabled, c->hot_bucket, c->clustered, c->key_poor, c->fkey_poor, c->profiling, c->last_was_batch, c->batch_poor,
+        c->live_frac, c->last_m, c->hot, c->hot_seen, c->hot_age, c->res};
+    c->disc_mask = ~0ull;
+    c->n_disc = 64;
+    c->k1_pinned = true;
+    c->k1_variant = 0x43; // streaming, histogram atomics aggregated per wave: bounded whatever the row order (a user-clustered
+                          // table would otherwise send 64 lanes to one counter, 10^8 times)
+    c->fast_enabled = false;
+    c->profiling = false;
+    o.mode = 0;           // the scan below must not come back here
+    // The build's scan stands OUTSIDE the span rotation.  A caller's scan may be in flight: its tail (launched at its finish,
+    // i.e. after everything queued here) still reads its span, which a regular scan's K2 would zero for the scan after the
+    // next.  So this scan zeroes nothing, its own span is wiped when it is done, and the rotation continues where it was.
+    const int keep_span_next = c->span_next;
+    c->ord_building = true;
+    // one scan of the caller's may be in flight (a pipelined caller always has one): the build takes the free slot, and
+    // finishes THAT slot; the caller's scan stays the oldest in flight
+    Slot* built = &c->slot[c->next_slot];
+    rc = scan_begin(c, INT64_MIN, INT64_MIN, nullptr, 0, 0, nullptr);
+    if (rc == PIE_OK) rc = scan_finish(c, built);
+    c->ord_building = false;
+    (void)hipMemsetAsync(c->span[keep_span_next], 0, counts_span(c), s);
+    c->span_next = keep_span_next;
+    c->disc_mask = k.mask; c->n_disc = k.n_disc; c->k1_pinned = k.pinned; c->k1_variant = k.variant; c->fast_enabled = k.fast;
+    c->profiling = k.profiling; o.mode = k.mode; c->dshift_want = k.dshift_want; c->hot_bucket = k.hot_bucket; c->clustered = k.clustered;
+    c->key_poor = k.key_poor; c->fkey_poor = k.fkey_poor; c->live_frac = k.live_frac; c->last_m = k.last_m; c->hot = k.hot;
+    c->hot_seen = k.hot_seen; c->hot_age = k.hot_age; c->last_was_batch = k.last_was_batch; c->run_shift = k.run_shift;
+    c->bdshift_want = k.bdshift_want; c->batch_poor = k.batch_poor;
+    if (rc) return rc;
+    const long long m = (long long)built->last.m;
+    const size_t padded = (((size_t)o.cap + 1023) / 1024) * 1024 + 1024;
+    PIE_HIP(c, hipMemsetAsync(o.pos, 0xFF, (size_t)o.cap * 4, s));
+    PIE_HIP(c, hipMemsetAsync(o.key, 0, padded * sizeof(lkey_t), s));
+    PIE_HIP(c, hipMemsetAsync(o.fkey, 0, padded * sizeof(fkey_t), s));
+    PIE_HIP(c, hipMemsetAsync(o.unit_count[0], 0, (size_t)o.units_cap * 4, s));
+    PIE_HIP(c, hipMemsetAsync(o.unit_count[1], 0, (size_t)o.units_cap * 4, s));
+    PIE_HIP(c, hipMemsetAsync(o.sum[0], 0, ord_sum_bytes(), s));
+    PIE_HIP(c, hipMemsetAsync(o.sum[1], 0, ord_sum_bytes(), s));
+    if (m > 0) {
+        hipLaunchKernelGGL(k_ord_gather, dim3(c->n_cus * 16), dim3(256), 0, s, built->out_idx, m, c->d_pay, c->d_end, c->d_key, c->d_fkey,
+                           o.pay, o.end, o.key, o.fkey, o.pos);
+        PIE_HIP(c, hipGetLastError());
+    }
+    PIE_HIP(c, hipMemcpyAsync(o.uoff, built->offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    *o.h_stale = 0;
+    // the build's scan is not a result: the caller's last one (in the other slot) stays readable, and the next scan takes
+    // the slot it would have taken
+    built->have_result = false;
+    c->res = (k.res && k.res != built) ? k.res : nullptr;
+    c->next_slot = k.next_slot;
+    o.n = m;
+    o.rows = c->n;
+    o.uc_next = 0;
+    o.valid = true;
+    o.wanted = 0;
+    o.builds++;
+    timespec t1{};
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    o.build_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    return PIE_OK;
+}
+
+// should this query run on the ordered run?  (mode 1: where the general path is weak)
+bool ordered_wanted(const pie_ctx* c)
+{
+    if (c->ord.mode == 2) return true;
+    if (c->ord.mode == 0) return false;
+    return c->hot_bucket || c->batch_poor || (c->last_m >= 0 && c->last_m * 24 > c->n);
+}
+
+// keyed (sparse) or dense form: an upper bound on the candidate rows — the key histogram while it describes the
+// table, else the live fraction of the last scan
+bool ordered_keyed_form(const pie_ctx* c, long long now)
+{
+    if (c->key_poor) return false;
+    double frac = c->live_frac >= 0 ? c->live_frac : 1.0;
+    if (!c->key_dirty && c->key_hist_rows == c->n && c->n > 0) {
+        unsigned long long at_or_above = 0;
+        for (int b = (int)(host_key_of(c, now) >> 3); b < kKeyHistBins; ++b) at_or_above += c->key_hist[(size_t)b];
+        frac = (double)at_or_above / (double)c->n;
+    }
+    return frac < 0.08;
+}
+
+// scan kernel, prefix, emit, publish: four launches, nothing to do at pie_scan_finish but read the summary
+void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long long cutoff, unsigned long long mask)
+{
+    OrderedRun& o = c->ord;
+    const int si = (int)(&sl - c->slot);
+    Summary* sum = reinterpret_cast<Summary*>(o.sum[si]);
+    sl.sum = sum; // what a later pack of this slot's result reads M from
+    OrdCtl* ctl = reinterpret_cast<OrdCtl*>(o.sum[si] + span_stats_bytes());
+    int* uc = o.unit_count[o.uc_next];
+    int* uc_other = o.unit_count[o.uc_next ^ 1];
+    o.uc_next ^= 1;
+    unsigned int* stage = reinterpret_cast<unsigned int*>(sl.sel);
+    const bool keyed = ordered_keyed_form(c, now);
+    const bool fine = keyed && (c->k1_keyed & 0x800) && !c->fkey_poor && now >= c->fkey_base;
+    long long n_units;
+    int unit_shift;
+    if (!keyed) {
+        unit_shift = kOrdTileShift;
+        n_units = (o.n + kOrdTile - 1) >> kOrdTileShift;
+        long long grid = n_units < (long long)c->n_cus * 8 ? n_units : (long long)c->n_cus * 8;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k_ord_scan_dense, dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, now, host_key_of(c, now),
+                           cutoff, mask, stage, uc, o.tile_ballot, o.tile_prefix, sum);
+        sl.variant = 0x2003;
+    } else if (fine) {
+        unit_shift = 10;
+        n_units = (o.n + 1023) >> 10;
+        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * 5 ? (n_units + 3) / 4 : (long long)c->n_cus * 5;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
+                           host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
+        sl.variant = 0x2C00;
+    } else {
+        unit_shift = 9;
+        n_units = (o.n + 511) >> 9;
+        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * 8 ? (n_units + 3) / 4 : (long long)c->n_cus * 8;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_scan_keyed<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_units, now,
+                           host_key_of(c, now), cutoff, mask, stage, uc, sum);
+        sl.variant = 0x2400;
+    }
+    sl.k1_blocks = 0;
+    if (sl.ev_index >= 0) (void)hipEventRecord(c->ring[sl.ev_index].e1, s);
+    long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
+    if (n_groups < 1) n_groups = 1;
+    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, uc, n_units, o.unit_local, o.group_sum, o.group_base, ctl, sum);
+    const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
+    if (keyed) {
+        const int copy_blocks = c->n_cus * 8;
+        hipLaunchKernelGGL(k_ord_emit<true>, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, unit_shift,
+                           uc, o.unit_local, o.group_base, n_units, stage, o.pay, o.tile_ballot, o.tile_prefix, sl.out_idx, sl.offsets,
+                           sl.counts_ord, copy_blocks, sum, uc_other, o.units_cap);
+    } else {
+        long long copy_blocks = n_units < (long long)c->n_cus * 16 ? n_units : (long long)c->n_cus * 16;
+        if (copy_blocks < 1) copy_blocks = 1;
+        hipLaunchKernelGGL(k_ord_emit<false>, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, unit_shift,
+                           uc, o.unit_local, o.group_base, n_units, stage, o.pay, o.tile_ballot, o.tile_prefix, sl.out_idx, sl.offsets,
+                           sl.counts_ord, (int)copy_blocks, sum, uc_other, o.units_cap);
+    }
+    hipLaunchKernelGGL(k_ord_publish, dim3(1), dim3(64), 0, s, sum, sl.h_sum_dev, sl.seq);
+}
+
 int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, int msg_u_pad = 0, long long msg_cap = 0,
-               int* msg_counts = nullptr)
+               int* msg_counts = nullptr);
+int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg, int msg_u_pad, long long msg_cap, int* msg_counts)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (c->n_flight >= 2) return fail(c, PIE_E_STATE, "two scans are already in flight: call pie_scan_finish first");
@@ -859,6 +1134,16 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
             c->dshift_want = c->dshift; // no room: stay with what there is
         }
     }
+    // The ordered run serves the queries the general path is weak at (dense, skewed users).  It is built the second time
+    // in a row such a query arrives with nothing in flight and the table unchanged (a first dense query may be the only one).
+    bool ord_route = false;
+    if (!c->d_qual && !c->k1_pinned && c->key_ok && !c->ord.no_room && ordered_wanted(c)) {
+        if (!c->ord.valid && c->n_flight <= 1 && (c->ord.mode == 2 || ++c->ord.wanted >= 2)) {
+            int rc = build_ordered(c);
+            if (rc) return rc;
+        }
+        ord_route = c->ord.valid && c->ord.rows == c->n;
+    } else c->ord.wanted = 0;
     Slot& sl = c->slot[c->next_slot];
     hipStream_t s = c->stream;
     sl.ev_index = -1;
@@ -919,6 +1204,33 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     sl.msg_cap = msg_cap;
     sl.msg_counts = msg_counts;
     sl.msg_by_k2 = false;
+    sl.ordered = false;
+
+    if (ord_route) {
+        {
+            Slot& prev = c->slot[c->next_slot ^ 1];
+            if (c->n_flight == 1 && prev.in_flight && prev.k2_pending) { // nothing carries it along: it goes first
+                launch_k2(c, prev, s, prev.zero_span, (long long)(counts_span(c) / 16));
+                prev.k2_pending = false;
+            }
+            sl.ordered = true;
+            sl.fast = false;
+            sl.k2_pending = false;
+            sl.hot.n = 0;
+            c->scans_begun++;
+            sl.q_now = now;
+            sl.q_cutoff = cutoff;
+            sl.seq = ++c->seq_counter;
+            if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e0, s));
+            launch_ordered(c, sl, s, now, cutoff, mask);
+            PIE_HIP(c, hipGetLastError());
+            if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, s));
+            sl.in_flight = true;
+            c->n_flight++;
+            c->next_slot ^= 1;
+            return PIE_OK;
+        }
+    }
 
     // this scan's histogram span (zeroed by the previous scan's K2, or by the load) and the one K2 will zero
     {
@@ -933,6 +1245,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, 
     // K2 (or the fast path's tail) zeroes the span of the scan AFTER the next one: every span is clean again before its
     // next user starts, and K2 of this scan may run beside the next scan's table pass, which uses span_next
     int4* zero_span = reinterpret_cast<int4*>(c->span[(c->span_next + 1) % 3]);
+    if (c->ord_building) zero_span = nullptr; // see build_ordered: this scan stands outside the rotation
     sl.zero_span = zero_span;
     c->scans_begun++;
     sl.q_now = now;
@@ -1018,9 +1331,11 @@ void choose_run_shift(pie_ctx* c, unsigned long long cand, unsigned chunk_max, b
 // Tail of the oldest scan in flight: launch its K2 if no later scan took it along, wait for its summary, then — only for
 // buckets that outgrew their direct slots — scatter + per-bucket order (plus the merge passes of big buckets, sized from
 // the summary).  Also where the adaptive choices for the next scans are made (scan form, key fit, hot set, slot capacity).
-int scan_finish(pie_ctx* c)
+// `which`: finish THIS slot's scan although an older one is still in flight (the ordered run's build, which must not
+// consume the caller's scan); everything a finish launches works on its own slot's arrays, in stream order
+int scan_finish(pie_ctx* c, Slot* which)
 {
-    Slot* slp = oldest_in_flight(c);
+    Slot* slp = which ? which : oldest_in_flight(c);
     if (!slp) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
     Slot& sl = *slp;
     hipStream_t a = c->stream;
@@ -1043,7 +1358,7 @@ int scan_finish(pie_ctx* c)
             __builtin_ia32_pause();
             if ((++spins & 0x3FFFF) == 0) { // every ~1 ms: is the stream still healthy, is the deadline up?
                 hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess && *seq != sl.seq) {
+                if (q == hipSuccess && *seq != sl.seq && !sl.ordered) {
                     // the stream drained but the mapped write is not visible: read the device copy instead
                     from_device = true;
                     break;
@@ -1090,6 +1405,21 @@ int scan_finish(pie_ctx* c)
     sl.in_flight = false;
     c->n_flight--;
     sl.last = sl.h_sum->s;
+    if (sl.ordered) {
+        // idx, offsets and counts are complete; what the scan saw of the table steers the next one like any other scan's
+        c->last_m = (long long)sl.last.m;
+        c->live_frac = c->ord.n > 0 ? (double)sl.last.live / (double)c->n : 0.0;
+        c->hot_bucket = sl.last.m > 4096 && (unsigned long long)sl.last.max_count * 64ull > sl.last.m;
+        if ((sl.variant & 0x400) && sl.last.amb > 4096 && sl.last.amb > (unsigned long long)c->n / 64) {
+            if (c->key_dirty) c->key_rebuild = true;
+            else if (sl.variant & 0x800) c->fkey_poor = true;
+            else c->key_poor = true;
+        }
+        sl.have_result = true;
+        c->res = &sl;
+        c->last_was_batch = false;
+        return PIE_OK;
+    }
     if (sl.fast) {
         if (sl.last.pad & 1u) {
             // a partition overflowed (skewed users): everything this attempt wrote is discarded and the same query
@@ -1246,7 +1576,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
-                       c->d_blk_off, sl.out_idx, c->cap_rows, c->d_key, c->d_fkey);
+                       c->d_blk_off, sl.out_idx, c->cap_rows, c->d_key, c->d_fkey, ord_mirror_of(c));
     PIE_HIP(c, hipGetLastError());
     PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
     PIE_HIP(c, hipStreamSynchronize(s));
@@ -1668,6 +1998,9 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
              (e = hipHostGetDevicePointer((void**)&s.h_sum_dev, s.h_sum, 0)) == hipSuccess;
         if (ok) memset(s.h_sum, 0, sizeof(HostSummary));
     }
+    ok = ok && (e = hipHostMalloc(&c->ord.h_stale, 64, hipHostMallocMapped)) == hipSuccess &&
+         (e = hipHostGetDevicePointer((void**)&c->ord.stale, c->ord.h_stale, 0)) == hipSuccess;
+    if (ok) memset(c->ord.h_stale, 0, 64);
     for (BatchSlot& b : c->bslot) {
         ok = ok && (e = hipHostMalloc(&b.h_sum, sizeof(HostSummary) * kBatchMax, hipHostMallocMapped)) == hipSuccess &&
              (e = hipHostGetDevicePointer((void**)&b.h_sum_dev, b.h_sum, 0)) == hipSuccess;
@@ -1686,6 +2019,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_RUN_SHIFT")) { const int r = atoi(v); if (r >= 0 && r <= 3) { c->run_shift = r; c->run_shift_pinned = true; } }
+    if (const char* v = getenv("PIE_ORDERED")) { const int m = atoi(v); if (m >= 0 && m <= 2) c->ord.mode = m; }
     if (const char* v = getenv("PIE_WAIT_DEADLINE_MS")) { const double d = atof(v); if (d > 0) c->wait_deadline_ms = d; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);
@@ -1796,6 +2130,7 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
         if (c->h_summary->bad_rows) // the rows were written beyond n: the table itself is unchanged
             return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", c->h_summary->bad_rows, n_users);
         c->n = old_n + (long long)k;
+        ord_invalidate(c);
         if (n_users > c->n_users) set_user_count(c, n_users);
         c->key_dirty = true;
         c->res = nullptr;
@@ -1985,10 +2320,14 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     PIE_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, k * 12, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end,
                        reinterpret_cast<const int*>(c->d_stage + k * 8), reinterpret_cast<const long long*>(c->d_stage), (long long)k, c->n,
-                       c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift);
+                       c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift, ord_mirror_of(c));
     PIE_HIP(c, hipGetLastError());
     c->key_dirty = true;
     PIE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ord.h_stale && *(volatile unsigned int*)c->ord.h_stale) { // a row the run does not hold is live again
+        *c->ord.h_stale = 0;
+        ord_invalidate(c);
+    }
     return PIE_OK;
 }
 
@@ -2514,6 +2853,29 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
         out->workspace_bytes += 2 * ((uint64_t)kBatchMax * (uint64_t)batch_users_stride(c) * 12 + (uint64_t)kBatchMax * (uint64_t)batch_out_stride(c) * 4 +
                                      ((uint64_t)users << c->bdshift) * sizeof(BktRec)) + 3 * (uint64_t)kBatchMax * (uint64_t)counts_span(c);
     out->index_build_ms = c->index_build_ms;
+    out->ordered_rows = c->ord.valid ? (uint64_t)c->ord.n : 0u;
+    // the run's columns (record 16 + end 8 + keys 3 per position, row -> position 4 per row) and its small per-unit arrays
+    out->ordered_bytes = c->ord.pay ? (uint64_t)c->ord.cap * (sizeof(OrdRec) + 8 + sizeof(lkey_t) + sizeof(fkey_t) + 4) +
+                                          (uint64_t)c->ord.units_cap * 12 + ((uint64_t)c->ord.cap / kOrdTile + 2) * kOrdSlices * 12 +
+                                          ((uint64_t)c->ord.cap_users + 1) * 8
+                                    : 0u;
+    out->ordered_build_ms = c->ord.build_ms;
+    out->ordered_builds = c->ord.builds;
+    return PIE_OK;
+}
+
+int pie_set_ordered_run(pie_ctx* c, int mode)
+{
+    if (!c) return PIE_E_INVAL;
+    if (mode < 0 || mode > 2) return fail(c, PIE_E_INVAL, "ordered-run mode must be 0 (never), 1 (adaptive) or 2 (always)");
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    c->ord.mode = mode;
+    c->ord.wanted = 0;
+    if (mode == 0) {
+        PIE_HIP(c, hipSetDevice(c->device));
+        PIE_HIP(c, hipStreamSynchronize(c->stream));
+        ord_free(c);
+    }
     return PIE_OK;
 }
 

@@ -1,0 +1,270 @@
+"""GPU: the ordered run (sph-pie_amd/csrc/pie_ordered.h: the table a second time in (user, start, row) order; a query is a
+filter over positions) against the oracle — bit-exact counts / offsets / idx — in both of its forms (dense, keyed on the 2- and
+the 1-byte key), on ragged / empty / skewed tables, after every writer of `end`, after the changes that invalidate it, and under
+the adaptive rule that builds it.  Through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT64_MIN = -(2 ** 63)
+ALL = 2 ** 64 - 1
+DAY = 86400 * 1000
+HOUR = 3600 * 1000
+SEED = 0x0D0E0D
+
+
+def assert_same(got, want, tag=""):
+    for name, a, b in zip(("counts", "offsets", "idx"), got, want):
+        assert a.dtype == b.dtype, (tag, name)
+        assert np.array_equal(a, b), (tag, name)
+
+
+def queries(oracle, cols):
+    """sparse (keyed form, fine key), mid (keyed on the 2-byte key), dense (dense form), everything, nothing, a cutoff taken from
+    the data, a `now` below every key base (key(now) == 0: every row is a candidate)"""
+    t0 = oracle.T0_MS
+    s = cols[0]
+    some_start = int(s[s.size // 3]) if s.size else t0
+    return [(t0 - 6 * HOUR, t0 - 61 * DAY, 0x5555555555555555),
+            (t0 - 10 * DAY, t0 - 61 * DAY, ALL),
+            (t0 - 100 * DAY, t0 - 61 * DAY, 0xAAAAAAAAAAAAAAAA),
+            (INT64_MIN, INT64_MIN, ALL),
+            (2 ** 62, INT64_MIN, ALL),
+            (t0 - 3 * DAY, some_start, 0x00000000FFFF0000 | 1),
+            (t0 - 4000 * DAY, INT64_MIN, ALL)]
+
+
+def check(ctx, oracle, cols, U, D, q, tag, want_ordered=True):
+    s, e, u, d = cols
+    now, cutoff, mask = q
+    lim = ALL if D >= 64 else (1 << D) - 1
+    ctx.set_disciplines(mask, D)
+    got = ctx.scan(now, cutoff)
+    assert_same(got, oracle.scan(s, e, u, d, U, now, cutoff, mask & lim), tag)
+    if want_ordered:
+        assert ctx.stats()["k1_variant"] & 0x2000, (tag, hex(ctx.stats()["k1_variant"]))
+
+
+@pytest.mark.parametrize("n,U,D,flags", [
+    (1, 1, 1, 0), (7, 3, 2, 1), (300, 50, 7, 0), (4097, 9, 7, 3), (70001, 333, 32, 0), (70001, 40000, 64, 2),
+    (1 << 20, 5000, 32, 3), (1 << 20, 600000, 32, 4), (1000003, 10, 5, 1), (262144, 1000, 32, 7),
+])
+def test_ordered_run_equals_the_oracle(pie, oracle, n, U, D, flags):
+    cols = oracle.gen(SEED + n, n, 0, n, U, D, flags)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_ordered_run(2)
+        forms = set()
+        for k, q in enumerate(queries(oracle, cols)):
+            check(ctx, oracle, cols, U, D, q, f"n={n} U={U} flags={flags} q{k}")
+            forms.add(ctx.stats()["k1_variant"])
+        if n >= 70001:
+            assert 0x2003 in forms and (0x2400 in forms or 0x2C00 in forms), [hex(f) for f in forms]
+        info = ctx.table_info()
+        assert info["ordered_builds"] == 1 and info["ordered_rows"] <= n and info["ordered_bytes"] > 0
+
+
+def test_ordered_run_empty_and_unselectable_tables(pie, oracle):
+    """no rows; only tombstones; only disciplines outside the table: the run holds nothing and every answer is empty"""
+    t0 = oracle.T0_MS
+    with pie.PieScan(0) as ctx:
+        ctx.set_ordered_run(2)
+        z = np.zeros(0, np.int64)
+        ctx.load_columns(z, z, np.zeros(0, np.int32), np.zeros(0, np.int32), 4)
+        got = ctx.scan(t0, INT64_MIN)
+        assert got[2].size == 0 and got[0].tolist() == [0, 0, 0, 0]
+        n = 5000
+        s = np.full(n, t0, np.int64)
+        u = (np.arange(n) % 7).astype(np.int32)
+        ctx.load_columns(s, np.full(n, INT64_MIN, np.int64), u, np.zeros(n, np.int32), 7)
+        assert ctx.scan(INT64_MIN, INT64_MIN)[2].size == 0
+        assert ctx.table_info()["ordered_rows"] == 0
+        ctx.load_columns(s, s + HOUR, u, np.full(n, 64, np.int32), 7)
+        assert ctx.scan(INT64_MIN, INT64_MIN)[2].size == 0
+
+
+def test_ordered_run_skewed_users_and_equal_keys(pie, oracle):
+    """a head user owning half the rows, starts and ends on whole hours (many equal sort keys, ties broken by row)"""
+    n, U, D = 400000, 2000, 16
+    s, e, u, d = [c.copy() for c in oracle.gen(SEED, n, 0, n, U, D, 0)]
+    rng = np.random.default_rng(5)
+    u = np.where(rng.random(n) < 0.5, 17, u).astype(np.int32)
+    s = (s // HOUR) * HOUR
+    e = (e // HOUR) * HOUR
+    cols = (s, e, u, d)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_ordered_run(2)
+        for k, q in enumerate(queries(oracle, cols)):
+            check(ctx, oracle, cols, U, D, q, f"skew q{k}")
+
+
+def test_ordered_run_follows_every_writer_of_end(pie, oracle):
+    """touch (set_end), delete (set_end to the tombstone), delete_user, prune_before, retention purge: the run's copies of
+    `end` and of both keys stay in step; a tombstoned row that comes back to life is not in the run — the run is dropped and
+    rebuilt; an append invalidates it."""
+    n, U, D = 200000, 700, 8
+    t0 = oracle.T0_MS
+    s, e, u, d = [c.copy() for c in oracle.gen(SEED + 1, n, 0, n, U, D, 0)]
+    rng = np.random.default_rng(11)
+    dead = rng.choice(n, 500, replace=False).astype(np.int32)
+    e[dead] = INT64_MIN                                      # tombstoned before the run is built: not in the run
+    qs = [(t0 - 6 * HOUR, t0 - 61 * DAY, ALL), (t0 - 100 * DAY, t0 - 61 * DAY, 0x55), (t0 - 30 * DAY, INT64_MIN, ALL)]
+
+    def all_queries(ctx, tag, want_ordered=True):
+        for k, q in enumerate(qs):
+            check(ctx, oracle, (s, e, u, d), U, D, q, f"{tag} q{k}", want_ordered)
+
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_ordered_run(2)
+        all_queries(ctx, "fresh")
+        assert ctx.table_info()["ordered_rows"] == n - 500
+        # touches: live again / further out / into the past, incl. values beyond the key range
+        rows = rng.choice(np.setdiff1d(np.arange(n), dead), 3000, replace=False).astype(np.int32)
+        new_end = np.where(rng.random(3000) < 0.5, t0 + rng.integers(0, 40 * DAY, 3000), t0 - rng.integers(0, 200 * DAY, 3000)).astype(np.int64)
+        ctx.set_end(rows, new_end)
+        e[rows] = new_end
+        all_queries(ctx, "touched")
+        # deletes
+        gone = rows[:700]
+        ctx.set_end(gone, np.full(700, INT64_MIN, np.int64))
+        e[gone] = INT64_MIN
+        all_queries(ctx, "deleted")
+        # delete_user / prune_before tombstone on the device
+        del_rows = ctx.delete_user(5)
+        assert np.array_equal(np.sort(del_rows), np.nonzero((u == 5) & (e != INT64_MIN))[0].astype(np.int32))
+        e[u == 5] = INT64_MIN
+        all_queries(ctx, "user deleted")
+        pruned = ctx.prune_before(int(t0 - 90 * DAY))
+        e[pruned] = INT64_MIN
+        all_queries(ctx, "pruned")
+        assert ctx.table_info()["ordered_builds"] == 1       # all of the above were mirrored, none rebuilt the run
+        # rows of the run brought back to life are still its rows
+        ctx.set_end(gone[:100], np.full(100, t0 + DAY, np.int64))
+        e[gone[:100]] = t0 + DAY
+        all_queries(ctx, "revived inside the run")
+        assert ctx.table_info()["ordered_builds"] == 1
+        # a row that was a tombstone when the run was built is not in it: reviving it drops the run, the next scan rebuilds
+        ctx.set_end(dead[:3], np.full(3, t0 + DAY, np.int64))
+        e[dead[:3]] = t0 + DAY
+        assert ctx.table_info()["ordered_rows"] == 0
+        all_queries(ctx, "revived outside the run")
+        assert ctx.table_info()["ordered_builds"] == 2
+        # append: the run no longer covers the table
+        k = 1000
+        a = [c.copy() for c in oracle.gen(SEED + 2, k, 0, k, U, D, 0)]
+        a[0] += 0
+        ctx.append_rows(*a, U)
+        s, e, u, d = [np.concatenate([x, y]) for x, y in zip((s, e, u, d), a)]
+        assert ctx.table_info()["ordered_rows"] == 0
+        all_queries(ctx, "appended")
+        assert ctx.table_info()["ordered_builds"] == 3
+
+
+def test_ordered_run_is_built_when_the_general_path_is_weak(pie, oracle):
+    """mode 1 (the default): sparse queries on evenly spread users never build it; the second dense query in a row does,
+    and from then on dense queries use it while sparse ones stay on the keyed general path; skewed users call for it too."""
+    n, U, D = 1 << 20, 3000, 32
+    t0 = oracle.T0_MS
+    cols = oracle.gen(SEED + 3, n, 0, n, U, D, 0)
+    sparse = (t0 - 6 * HOUR, t0 - 61 * DAY, 0x5555555555555555)
+    dense = (t0 - 100 * DAY, t0 - 61 * DAY, ALL)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        for k in range(4):
+            check(ctx, oracle, cols, U, D, sparse, f"sparse {k}", want_ordered=False)
+            assert not ctx.stats()["k1_variant"] & 0x2000
+        assert ctx.table_info()["ordered_builds"] == 0
+        check(ctx, oracle, cols, U, D, dense, "dense 0", want_ordered=False)      # nothing known yet
+        check(ctx, oracle, cols, U, D, dense, "dense 1", want_ordered=False)      # wanted once
+        check(ctx, oracle, cols, U, D, dense, "dense 2", want_ordered=False)      # wanted twice: built, used
+        assert ctx.stats()["k1_variant"] == 0x2003
+        assert ctx.table_info()["ordered_builds"] == 1
+        check(ctx, oracle, cols, U, D, dense, "dense 3")
+        check(ctx, oracle, cols, U, D, sparse, "sparse after dense")              # the last scan was dense: the run, keyed form
+        check(ctx, oracle, cols, U, D, sparse, "sparse again", want_ordered=False)
+        assert not ctx.stats()["k1_variant"] & 0x2000
+    # skew
+    s, e, u, d = [c.copy() for c in cols]
+    u = np.where(np.random.default_rng(2).random(n) < 0.3, 9, u).astype(np.int32)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        sparse_all = (sparse[0], sparse[1], ALL)
+        for k in range(4):
+            check(ctx, oracle, (s, e, u, d), U, D, sparse_all, f"skewed {k}", want_ordered=False)
+        assert ctx.stats()["k1_variant"] & 0x2000 and ctx.table_info()["ordered_builds"] == 1
+
+
+def test_ordered_run_two_scans_in_flight_and_batches(pie, oracle):
+    """pipelined begin / begin / finish / finish on the run; a batch whose queries fall back (dense) is served by it"""
+    n, U, D = 300000, 900, 16
+    t0 = oracle.T0_MS
+    cols = oracle.gen(SEED + 4, n, 0, n, U, D, 1)
+    s, e, u, d = cols
+    qs = [(t0 - 6 * HOUR - 1000 * k, t0 - (61 + k) * DAY) for k in range(6)] + [(t0 - 100 * DAY, t0 - 61 * DAY)]
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.set_ordered_run(2)
+        ctx.scan_begin(*qs[0])
+        for k in range(len(qs)):
+            if k + 1 < len(qs):
+                ctx.scan_begin(*qs[k + 1])
+            ctx.scan_finish()
+            assert_same(ctx.read_results(), oracle.scan(s, e, u, d, U, qs[k][0], qs[k][1], (1 << D) - 1), f"pipelined {k}")
+        batch = [(t0 - 100 * DAY, t0 - 61 * DAY, 0xFF), (t0 - 6 * HOUR, t0 - 61 * DAY, ALL), (t0 - 50 * DAY, INT64_MIN, 0xF0F0)]
+        ctx.scan_batch(batch)
+        for qi, (now, cutoff, mask) in enumerate(batch):
+            assert_same(ctx.batch_read_results(qi), oracle.scan(s, e, u, d, U, now, cutoff, mask & ((1 << D) - 1)), f"batch q{qi}")
+
+
+def test_ordered_run_is_built_under_a_pipelined_caller(pie, oracle):
+    """two scans in flight at every begin (bench.py's loop): the build takes the free slot while the caller's scan stays in
+    flight, and every answer before, at and after the build is exact"""
+    n, U, D = 1 << 20, 3000, 32
+    t0 = oracle.T0_MS
+    cols = oracle.gen(SEED + 5, n, 0, n, U, D, 0)
+    s, e, u, d = cols
+    qs = [(t0 - 100 * DAY - 1000 * k, t0 - 61 * DAY - 7 * k) for k in range(8)]
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.scan_begin(*qs[0])
+        forms = []
+        for k in range(len(qs)):
+            if k + 1 < len(qs):
+                ctx.scan_begin(*qs[k + 1])
+            ctx.scan_finish()
+            forms.append(ctx.stats()["k1_variant"])
+            assert_same(ctx.read_results(), oracle.scan(s, e, u, d, U, qs[k][0], qs[k][1], ALL), f"pipelined {k}")
+        assert ctx.table_info()["ordered_builds"] == 1
+        assert not forms[0] & 0x2000 and forms[-1] == 0x2003, [hex(f) for f in forms]
+
+
+def test_ordered_run_result_messages(pie, oracle):
+    """the packed exchange message (offsets | M | rows) of a scan served by the ordered run equals the one packed from
+    the oracle's answer"""
+    import torch
+    n, U, D = 200000, 500, 16
+    t0 = oracle.T0_MS
+    cols = oracle.gen(SEED + 6, n, 0, n, U, D, 0)
+    s, e, u, d = cols
+    u_pad = 512
+    cap = n
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.set_ordered_run(2)
+        msg = torch.zeros(u_pad + 2 + cap, dtype=torch.int32, device="cuda:0")
+        for now, cutoff in [(t0 - 100 * DAY, t0 - 61 * DAY), (t0 - 6 * HOUR, t0 - 61 * DAY)]:
+            ctx.scan_begin_packed(now, cutoff, msg.data_ptr(), u_pad, cap)
+            m, _ready = ctx.scan_finish_packed()
+            ctx.synchronize()
+            assert ctx.stats()["k1_variant"] & 0x2000
+            w = oracle.scan(s, e, u, d, U, now, cutoff, (1 << D) - 1)
+            got = msg.cpu().numpy()
+            assert m == w[2].size
+            assert np.array_equal(got[: U + 1], w[1].astype(np.int32)) and np.all(got[U + 1: u_pad + 2] == m)
+            assert np.array_equal(got[u_pad + 2: u_pad + 2 + m], w[2])

@@ -166,8 +166,10 @@ def test_k1_form_follows_live_fraction(pie, oracle):
 def test_streaming_form_aggregates_on_user_clustered_tables(pie, oracle):
     """Rows clustered by user + a dense query: the streaming form notices that most selected rows sit next to a row of
     the same user and switches to wave-aggregated histogram atomics (0x43); on a randomly ordered table it does not, and
-    it switches back when the table stops being clustered.  Same bytes throughout."""
+    it switches back when the table stops being clustered.  Same bytes throughout.  (The ordered run, which would take these
+    dense queries over from the third one on, is switched off: this test is about the general path's own forms.)"""
     with pie.PieScan(0) as ctx:
+        ctx.set_ordered_run(0)
         n, U, D = 600000, 2000, 32
         now = oracle.T0_MS - 100 * DAY                       # ~83 % of the rows live: streaming form
         for flags, want_form in ((2, 0x43), (0, 0x03)):
@@ -253,6 +255,7 @@ def test_scan_written_message_equals_the_pack_kernel(pie, oracle):
     s, e, u, d = oracle.gen(SEED, n, 0, n, U, D, 0)
     dev = torch.device("cuda", 0)
     with pie.PieScan(0) as ctx:
+        ctx.set_ordered_run(0)   # the general path's K2 is what writes the message here (tests/test_gpu_ordered.py has the run's)
         ctx.load_columns(s, e, u, d, U)
         ctx.set_disciplines(ALL, D)
         cases = [(oracle.T0_MS - 6 * 3600 * 1000, True), (oracle.T0_MS - 6 * 3600 * 1000, True),   # ~0.1 rows per user
@@ -416,12 +419,14 @@ def test_generator_parity(gpu_ctx, oracle):
         assert np.array_equal(a, b)
 
 
-def test_zipf_corpus_parity(pie, gpu_ctx, oracle):
+def test_zipf_corpus_parity(pie, gpu_ctx, oracle, request):
     """The skewed-user corpus (Zipf(1.1) thresholds from the host): generator and scan bit-exact vs the oracle; the head
     user's bucket goes through the tile + merge path."""
     n, U, D = 2 * 10 ** 6, 20000, 32
     cdf = pie.zipf_cdf(U)
     assert np.array_equal(cdf, oracle.zipf_cdf(U)) and np.all(np.diff(cdf.astype(np.float64)) >= 0)
+    gpu_ctx.set_ordered_run(0)   # the general path's big-bucket machinery is the subject (the ordered run would take a skewed table over)
+    request.addfinalizer(lambda: gpu_ctx.set_ordered_run(1))
     gpu_ctx.gen_synthetic_cdf(SEED, n, 0, n, U, D, 1, cdf)
     want_cols = oracle.gen_cdf(SEED, n, 0, n, U, D, 1, cdf)
     for a, b in zip(gpu_ctx.read_columns(), want_cols):

@@ -43,7 +43,8 @@ while time.time() < t_end:
     U = int(rng.choice([1, 3, 50, 1000, 40000, 600000]))
     D = int(rng.choice([1, 7, 32, 64]))
     flags = int(rng.integers(8))   # interval / user-clustered / creation-ordered, in any combination
-    what = "seed %d form %s n %d U %d D %d flags %d" % (case_seed, form, n, U, D, flags)
+    ordered = int(rng.choice([0, 1, 1, 2, 2]))   # the ordered run: never / adaptive / always (pinned forms never use it)
+    what = "seed %d form %s n %d U %d D %d flags %d ordered %d" % (case_seed, form, n, U, D, flags, ordered)
     try:
         s, e, u, d = [c.copy() for c in oracle.gen(int(rng.integers(1, 2 ** 60)), n, 0, n, U, D, flags)]
         if rng.random() < 0.3:   # heavy head user
@@ -56,6 +57,7 @@ while time.time() < t_end:
             mask = 2 ** 64 - 1
         m_eff = mask if D >= 64 else mask & ((1 << D) - 1)
         with pie.PieScan(0) as ctx:
+            ctx.set_ordered_run(ordered)
             ctx.load_columns(s, e, u, d, U)
             ctx.set_disciplines(mask, D)
             for rnd in range(int(rng.integers(2, 7))):
