@@ -46,6 +46,7 @@
     X(int, pie_expired_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_archive_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
+    X(int, pie_set_ordered_run, (pie_ctx *, int))                                                                   \
     X(int, pie_stats_get, (pie_ctx *, pie_stats *))                                                                 \
     X(int, pie_stats_reset, (pie_ctx *))                                                                            \
     X(int, pie_scan_batch, (pie_ctx *, const pie_query *, int, size_t *))                                           \
@@ -1244,7 +1245,7 @@ static napi_value fn_stats(napi_env env, napi_callback_info info)
     napi_set_named_property(env, o, name, v);
     PUT("rows", st.rows) PUT("users", st.users) PUT("selected", st.selected) PUT("algBytes", st.alg_bytes)
     PUT("k1MsSum", st.k1_ms_sum) PUT("scanMsSum", st.scan_ms_sum) PUT("nProfiled", st.n_profiled)
-    PUT("maxBucket", st.max_bucket)
+    PUT("maxBucket", st.max_bucket) PUT("k1Variant", st.k1_variant)
 #undef PUT
     return o;
 }
@@ -1261,6 +1262,19 @@ static napi_value fn_set_profiling(napi_env env, napi_callback_info info)
     return js_int(env, 0);
 }
 
+/* setOrderedRun(ctx, mode): 0 never, 1 where the general path is weak (default), 2 always (pie_set_ordered_run) */
+static napi_value fn_set_ordered_run(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t mode = 1;
+    CHECK(env, napi_get_value_int32(env, argv[1], &mode));
+    const int rc = p_pie_set_ordered_run(ctx, mode);
+    if (rc != 0) return throw_pie(env, ctx, rc);
+    return js_int(env, 0);
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     static const struct {
@@ -1272,6 +1286,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
+        {"setOrderedRun", fn_set_ordered_run},
         {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed},
         {"commCreate", fn_comm_create}, {"commDestroy", fn_comm_destroy}, {"commWorld", fn_comm_world}, {"commCtx", fn_comm_ctx},
         {"commGenSyntheticSharded", fn_comm_gen}, {"commScanBatchGather", fn_comm_scan_gather}, {"commReadGathered", fn_comm_read}, {"commUPad", fn_comm_upad},

@@ -32,6 +32,8 @@ function createStore(options){
   const opts = options || {};
   const native = pieNative.load();                 // throws if the addon / HIP library is missing
   const ctx = native.ctxCreate(opts.device === undefined ? 0 : opts.device);   // throws without a GPU
+  // the ordered run (pie_set_ordered_run): 0 never, 1 where the general path is weak (the library's default), 2 always
+  if(opts.orderedRun !== undefined){ native.setOrderedRun(ctx, opts.orderedRun); }
 
   const rowOfToken = new Map();                    // tokenHash -> row
   const rows = [];                                 // row -> {tokenHash|null, userId, createdAt, expiresAt}

@@ -501,6 +501,40 @@ function get(port, cookie){
     assert.throws(() => native.commWorld(comm), /communicator/);
     checks++;
   }
+  // ---- 8. the ordered run behind the store: same feeds as the general path, on a skewed table, after touches and deletes
+  {
+    const base = 1790000000000;
+    const mk = orderedRun => {
+      const st = createStore({orderedRun});
+      const toks = [];
+      for(let i = 0; i < 4000; i++){
+        fakeNow = base + i * 1013;
+        const uid = i % 3 === 0 ? 'head' : 'user-' + (i % 41);          // one user owns a third of the sessions
+        toks.push(st.createSession(uid, dc.DISCIPLINES[i % dc.DISCIPLINES.length].id).token);
+      }
+      return {st, toks};
+    };
+    const a = mk(2), b = mk(0);
+    const t1 = base + 4000 * 1013 + 7;
+    const same = (tag) => {
+      const ra = a.st.scanFeeds({now: t1, cutoff: base + 500000}), rb = b.st.scanFeeds({now: t1, cutoff: base + 500000});
+      eq(ra.m, rb.m, tag + ' m');
+      eq(Array.from(ra.counts), Array.from(rb.counts), tag + ' counts');
+      eq(Array.from(ra.idx.subarray(0, ra.m)), Array.from(rb.idx.subarray(0, rb.m)), tag + ' idx');
+      eq((a.st.native.stats(a.st.ctx).k1Variant & 0x2000) !== 0, true, tag + ' ran on the ordered run');
+      eq((b.st.native.stats(b.st.ctx).k1Variant & 0x2000) === 0, true, tag + ' general path');
+    };
+    fakeNow = t1;
+    same('fresh');
+    for(const s of [a, b]){
+      for(let i = 0; i < 4000; i += 7){ s.st.touchSession(s.toks[i]); }
+      for(let i = 3; i < 4000; i += 11){ s.st.deleteSession(s.toks[i]); }
+      s.st.deleteSessionsForUser('user-5');
+    }
+    same('touched and deleted');
+    a.st.close();
+    b.st.close();
+  }
   Date.now = realNow;
   console.log('host gpu_test ok: ' + checks + ' checks');
 })().catch(err => { console.error(err); process.exit(1); });
