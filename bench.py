@@ -191,6 +191,8 @@ def main():
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
                          "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
     ap.add_argument("--mixed-rows", type=int, default=1000, help="--mode mixed: sessions created and sessions touched per step")
+    ap.add_argument("--mixed-clock", choices=["query", "end"], default="query",
+                    help="--mode mixed: sessions are created at the query's clock (default) or after the corpus's last createdAt")
     ap.add_argument("--mode", choices=["scan", "expired", "mixed"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic); mixed: every step "
@@ -298,13 +300,17 @@ def main():
             for _ in range(k):
                 mixed_state["step"] += 1
                 t_step = now + mixed_state["step"] * 1000
+                # the clock sessions are created at: the query's `now` (the spec query sits 6 h before the corpus's last
+                # createdAt, so new rows fall among existing ones), or the corpus's end (a live store: created after everything)
+                t_new = (T0_MS if args.mixed_clock == "end" else now) + mixed_state["step"] * 1000
                 t_a = time.perf_counter()
-                st_new = np.full(kk, t_step, np.int64) - mixed_state["rng"].integers(0, 1000, kk)
+                # created within the last second, in order of creation (the order a store appends them in)
+                st_new = np.sort(np.full(kk, t_new, np.int64) - mixed_state["rng"].integers(0, 1000, kk))
                 ctx.append_rows(st_new, st_new + 43200000, mixed_state["rng"].integers(0, u_local, kk).astype(np.int32),
                                 mixed_state["rng"].integers(0, D, kk).astype(np.int32), u_local)
                 t_b = time.perf_counter()
                 rows = mixed_state["rng"].integers(0, ctx.n, kk).astype(np.int32)
-                ctx.set_end(rows, np.full(kk, t_step + 43200000, np.int64))
+                ctx.set_end(rows, np.full(kk, t_new + 43200000, np.int64))
                 t_c = time.perf_counter()
                 last = ctx.scan_device(t_step, cutoff)
                 t_d = time.perf_counter()
@@ -511,7 +517,7 @@ def main():
             "index": {"index_build_ms": info["index_build_ms"], "derived_bytes": info["derived_bytes"],
                       "table_bytes": info["table_bytes"], "workspace_bytes": info["workspace_bytes"],
                       "ordered_run": {"rows": info["ordered_rows"], "bytes": info["ordered_bytes"], "build_ms": info["ordered_build_ms"],
-                                      "builds": info["ordered_builds"]},
+                                      "builds": info["ordered_builds"], "positions": info["ordered_positions"], "respreads": info["ordered_respreads"]},
                       "note": "the keyed pass reads derived columns built at load (outside the timed region) and kept in step by every "
                               "writer of `end`; index_build_ms = one full build on this table"},
         }

@@ -242,10 +242,12 @@ typedef struct pie_table_info {
     uint64_t derived_bytes;   /* derived columns (2-byte key, 1-byte key, 16-byte payload record) */
     uint64_t workspace_bytes; /* per-scan workspace of the two slots + histogram spans */
     double index_build_ms;    /* host wall time of the last full build of the derived columns (kernels + syncs) */
-    uint64_t ordered_rows;    /* positions of the ordered run (0: there is none, or it was invalidated) */
-    uint64_t ordered_bytes;   /* device memory of the ordered run (31 B per row of capacity + small per-unit arrays) */
+    uint64_t ordered_rows;    /* rows the ordered run holds (0: there is none, or it was invalidated) */
+    uint64_t ordered_bytes;   /* device memory of the ordered run (27 B per position + 4 B per row of capacity + small arrays) */
     double ordered_build_ms;  /* host wall time of its last build (one all-selecting scan + a gather) */
     uint64_t ordered_builds;  /* times it was built for this context */
+    uint64_t ordered_positions; /* positions a scan of the run visits: its rows + the spare slots of every user's segment */
+    uint64_t ordered_respreads; /* times appends filled a segment and the run was moved into fresh segments (a linear pass) */
 } pie_table_info;
 int pie_table_info_get(pie_ctx *ctx, pie_table_info *out);
 /* The ordered run (sph-pie_amd/csrc/pie_ordered.h): the table's rows a second time, in (user, start, row) order — the order
@@ -253,9 +255,10 @@ int pie_table_info_get(pie_ctx *ctx, pie_table_info *out);
  * how rows are spread over users.  There is no counterpart in the reference (its Map is scanned per request,
  * server/sessionStore.js:55-73); results are identical to the general path's.  mode 0: never (frees it); 1 (default):
  * built and used when the general path is weak — a query selecting more than 1/24 of the rows, or skewed users — the second
- * time in a row such a query arrives; 2: always (built at the next scan).  Touches and deletes keep it in step; loads,
- * appends and sharding invalidate it (queries run on the general path until it is rebuilt).  PIE_ORDERED=0|1|2 sets the
- * mode a context starts with. */
+ * time in a row such a query arrives; 2: always (built at the next scan).  Touches and deletes keep it in step, and so do
+ * appends in time order (a session store's createSession: the new row goes into a spare slot at the end of its user's
+ * segment); loads, sharding, a full segment or an out-of-order append invalidate it (queries run on the general path until
+ * it is rebuilt).  PIE_ORDERED=0|1|2 sets the mode a context starts with. */
 int pie_set_ordered_run(pie_ctx *ctx, int mode);
 /* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
  * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */

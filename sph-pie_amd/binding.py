@@ -29,7 +29,8 @@ class PieTableInfo(C.Structure):
         ("struct_size", C.c_uint32), ("has_keys", C.c_uint32), ("rows", C.c_uint64), ("users", C.c_uint64),
         ("table_bytes", C.c_uint64), ("derived_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64),
         ("index_build_ms", C.c_double), ("ordered_rows", C.c_uint64), ("ordered_bytes", C.c_uint64),
-        ("ordered_build_ms", C.c_double), ("ordered_builds", C.c_uint64),
+        ("ordered_build_ms", C.c_double), ("ordered_builds", C.c_uint64), ("ordered_positions", C.c_uint64),
+        ("ordered_respreads", C.c_uint64),
     ]
 
 

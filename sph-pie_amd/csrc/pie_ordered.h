@@ -28,8 +28,9 @@
 // finishes last does X" is a counter, not a wait).
 //
 // Writers of `end` (touch, delete, purge) mirror their store into o_end / the keys through pos[] (OrdMirror in
-// pie_kernels.h); anything that changes the set of rows (load, append, shard) invalidates the run and the host falls
-// back to the general path until it is rebuilt.
+// pie_kernels.h).  Appends in time order (a session store's: createdAt = now) go into spare slots at the end of their
+// user's segment (k_ord_append).  A load, a re-shard, a full segment or an out-of-order append invalidates the run and the
+// host falls back to the general path until it is rebuilt.
 #pragma once
 
 namespace pie {
@@ -49,8 +50,11 @@ struct OrdCtl {
     unsigned int pad[3];
 };
 
-// out_idx of the all-selecting scan -> the run's columns
-__global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx, long long m, const PayRec* __restrict__ pay,
+// out_idx of the all-selecting scan -> the run's columns.  Entry i of the sorted list belongs to user u = pay[row].user and is
+// its (i - off[u])-th row; it goes to position uoff[u] + that rank: every user's segment starts at uoff[u] and ends in spare
+// slots (see k_ord_append).
+__global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx, long long m, const long long* __restrict__ off,
+                                                    const long long* __restrict__ uoff, const PayRec* __restrict__ pay,
                                                     const long long* __restrict__ end, const lkey_t* __restrict__ key,
                                                     const fkey_t* __restrict__ fkey, OrdRec* __restrict__ o_pay,
                                                     long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
@@ -59,15 +63,118 @@ __global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx,
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         const int r = idx[i];
         const PayRec p = pay[r];
+        const long long at = uoff[p.user] + (i - off[p.user]);
         OrdRec o;
         o.start = p.start;
         o.row = r;
         o.disc = p.disc;
-        o_pay[i] = o;
-        o_end[i] = end[r];
-        o_key[i] = key[r];
-        o_fkey[i] = fkey[r];
-        pos[r] = (int)i;
+        o_pay[at] = o;
+        o_end[at] = end[r];
+        o_key[at] = key[r];
+        o_fkey[at] = fkey[r];
+        pos[r] = (int)at;
+    }
+}
+
+// createSession on a table that has a run.  A user's segment ends in spare slots (a sixteenth of its rows + 16, filler records:
+// key 0, discipline -1, never selected).  A session store appends in time order — createdAt = now — so a new row of user u
+// belongs right behind u's last row: row t of the batch takes slot ufill[u] + (rows of u earlier in the batch), provided
+// its start is not below the start of the row before it in the segment (equal starts are in row order by construction: the
+// new row has the larger row id).  O(batch) work per row of the batch, nothing per row of the table.
+//   placed[t] = pass   the row went into the run in this pass
+//   stale[0]++         the row arrived out of time order: the run no longer describes the table (host: drop it)
+//   stale[1]++         its user's segment is full (host: k_ord_respread gives every segment fresh spare slots, then pass 2
+//                      places the rows left over)
+// stale[] is mapped host memory, read by the host after the append's one synchronisation.
+__global__ __launch_bounds__(256) void k_ord_append(const long long* __restrict__ st_start, const long long* __restrict__ st_end,
+                                                    const int* __restrict__ st_user, const int* __restrict__ st_disc, int k,
+                                                    long long row0, int n_users, long long key_base, int key_shift, long long fkey_base,
+                                                    int fkey_shift, const long long* __restrict__ uoff, const int* __restrict__ ufill,
+                                                    OrdRec* __restrict__ o_pay, long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
+                                                    fkey_t* __restrict__ o_fkey, int* __restrict__ pos, unsigned int* __restrict__ stale,
+                                                    const int* __restrict__ placed_in, int* __restrict__ placed, int pass)
+{
+    // the users of the batch's rows up to this block's last one, in LDS: every row compares itself with all earlier rows
+    // (pass 2: an earlier row that pass 1 placed is in the segment already and does not count: its entry is -1 here;
+    // pass 2 works from a copy of pass 1's outcome, placed_in, because rows of this launch write placed[] while others read)
+    __shared__ int lu[4096];
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int upto = min(k, (int)((blockIdx.x + 1) * blockDim.x));
+    for (int e = threadIdx.x; e < upto; e += blockDim.x) lu[e] = (pass == 1 || placed_in[e] == 0) ? st_user[e] : -1;
+    __syncthreads();
+    if (t >= k) return;
+    const int u = st_user[t];
+    if ((unsigned)u >= (unsigned)n_users) return; // the whole append is rejected by the caller
+    if (pass > 1 && placed_in[t] != 0) return;    // pass 2: only what pass 1 left over
+    if (pass == 1) placed[t] = 0;
+    int before = 0, last = -1;
+    for (int e = 0; e < t; ++e) {
+        const bool same = lu[e] == u;
+        before += same ? 1 : 0;
+        last = same ? e : last;
+    }
+    long long prev = last >= 0 ? st_start[last] : INT64_MIN;
+    const int fill = ufill[u];
+    const long long seg = uoff[u];
+    if (before == 0 && fill > 0) prev = o_pay[seg + fill - 1].start;
+    const long long slot = (long long)fill + before;
+    const long long sv = st_start[t];
+    if (sv < prev) {
+        __hip_atomic_fetch_add(&stale[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (slot >= uoff[u + 1] - seg) {
+        __hip_atomic_fetch_add(&stale[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const long long at = seg + slot;
+    const long long ev = st_end[t];
+    OrdRec o;
+    o.start = sv;
+    o.row = (int)(row0 + t);
+    o.disc = st_disc[t];
+    o_pay[at] = o;
+    o_end[at] = ev;
+    o_key[at] = (lkey_t)key_of(ev, key_base, key_shift);
+    o_fkey[at] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
+    pos[row0 + t] = (int)at;
+    placed[t] = pass;
+}
+
+__global__ __launch_bounds__(256) void k_ord_append_commit(const int* __restrict__ st_user, int k, int n_users, const int* __restrict__ placed,
+                                                           int pass, int* __restrict__ ufill, int* __restrict__ pend)
+{
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= k || (unsigned)st_user[t] >= (unsigned)n_users) return;
+    if (placed[t] == pass) atomicAdd(&ufill[st_user[t]], 1);
+    else if (placed[t] == 0 && pend) atomicAdd(&pend[st_user[t]], 1); // rows a re-spread has to make room for
+}
+
+// Fresh spare slots for every segment: the rows of the run move from (uoff_old, *_old) to (uoff_new, *_new), each user's rows
+// staying in order at the head of its new segment.  A linear pass over the positions — no sort, nothing of the table is read.
+__global__ __launch_bounds__(256) void k_ord_respread(long long n_old, int seg_users, const long long* __restrict__ uoff_old,
+                                                      const int* __restrict__ ufill, const long long* __restrict__ uoff_new,
+                                                      const OrdRec* __restrict__ pay_old, const long long* __restrict__ end_old,
+                                                      const lkey_t* __restrict__ key_old, const fkey_t* __restrict__ fkey_old,
+                                                      OrdRec* __restrict__ pay_new, long long* __restrict__ end_new,
+                                                      lkey_t* __restrict__ key_new, fkey_t* __restrict__ fkey_new, int* __restrict__ pos)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n_old; p += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = seg_users - 1; // the user whose segment holds p: the largest u with uoff_old[u] <= p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (uoff_old[mid] <= p) lo = mid;
+            else hi = mid - 1;
+        }
+        const long long j = p - uoff_old[lo];
+        if (j >= ufill[lo]) continue; // a spare slot
+        const long long at = uoff_new[lo] + j;
+        const OrdRec o = pay_old[p];
+        pay_new[at] = o;
+        end_new[at] = end_old[p];
+        key_new[at] = key_old[p];
+        fkey_new[at] = fkey_old[p];
+        pos[o.row] = (int)at;
     }
 }
 

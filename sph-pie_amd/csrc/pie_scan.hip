@@ -132,7 +132,8 @@ struct OrderedRun {
     int mode = 1;            // PIE_ORDERED: 0 = never, 1 = when the general path is weak (dense / skewed queries), 2 = always
     bool valid = false;
     long long n = 0;         // positions (= rows the all-selecting scan returned)
-    long long rows = 0;      // table rows the run was built from
+    long long rows = 0;      // table rows the run covers (built from, plus the appends it took)
+    long long held = 0;      // rows it holds (the selectable ones of those)
     long long cap = 0;       // positions the arrays hold
     int cap_users = 0;
     OrdRec* pay = nullptr;
@@ -140,7 +141,18 @@ struct OrderedRun {
     lkey_t* key = nullptr;
     fkey_t* fkey = nullptr;
     int* pos = nullptr;
-    long long* uoff = nullptr;
+    long long* uoff = nullptr;               // [users + 1] first position of every user's segment (rows, then spare slots)
+    int* ufill = nullptr;                    // [users] rows in the segment
+    int* pend = nullptr;                     // [users] rows of an append that found their segment full (re-spread)
+    int* placed = nullptr;                   // [2][4096] outcome per row of the append in progress (+ the copy pass 2 reads)
+    OrdRec* alt_pay = nullptr;               // the arrays a re-spread moves the run into (allocated at the first one), then swapped
+    long long* alt_end = nullptr;
+    lkey_t* alt_key = nullptr;
+    fkey_t* alt_fkey = nullptr;
+    long long* alt_uoff = nullptr;
+    unsigned long long respreads = 0;
+    int users = 0;                           // users that have a segment (>= n_users: room for users yet to come)
+    long long pos_cap = 0;                   // positions the arrays hold
     int* unit_count[2] = {nullptr, nullptr}; // alternate: the finish kernel of one ordered scan zeroes the other buffer
     int uc_next = 0;
     long long units_cap = 0;
@@ -154,6 +166,8 @@ struct OrderedRun {
     bool no_room = false;                    // the arrays did not fit: not tried again for this table
     char* sum[2] = {nullptr, nullptr};       // per scan slot: Summary + row-statistics slots + OrdCtl
     unsigned wanted = 0;     // consecutive scans that wanted the run while it was not there
+    unsigned need = 2;       // ... and how many of them it takes to build it: 2, more after a run that did not live long
+    unsigned long long built_at = 0; // scans_begun when it was last built
     unsigned long long builds = 0;
     double build_ms = 0;
 };
@@ -346,20 +360,37 @@ void free_batch(pie_ctx* c)
 void ord_free(pie_ctx* c)
 {
     OrderedRun& o = c->ord;
-    dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff);
+    dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed);
+    dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
     dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
     dfree(o.sum[0]); dfree(o.sum[1]);
     o.valid = false;
     o.no_room = false;
-    o.cap = 0; o.cap_users = 0; o.units_cap = 0; o.n = 0; o.rows = 0; o.wanted = 0;
+    o.cap = 0; o.cap_users = 0; o.units_cap = 0; o.n = 0; o.rows = 0; o.wanted = 0; o.need = 2;
 }
 
-// the set of rows changed (load, append, shard, key refit): the run no longer describes the table
-void ord_invalidate(pie_ctx* c)
+// The run no longer describes the table.  new_table: a load / re-shard — nothing is known about what comes.  Otherwise a row
+// arrived that the run could not take (out of time order, no room even after a re-spread) or one it does not hold came back
+// to life: a run that lived for fewer than 64 scans was not worth its build, so the next one takes four times as many
+// consecutive dense / skewed queries to come about (2, 8, 32, ... 4096); one that lived longer starts over at 2.
+void ord_invalidate(pie_ctx* c, bool new_table = false, bool out_of_order = false)
 {
-    c->ord.valid = false;
-    c->ord.wanted = 0;
+    OrderedRun& o = c->ord;
+    if (new_table) {
+        o.need = 2;
+        o.wanted = 0;
+    } else if (o.valid) {
+        // rows that arrive out of time order are how this table is fed: the run cannot live on it, one build was enough to learn that
+        if (out_of_order && c->scans_begun - o.built_at < 64) o.need = 4096u;
+        else o.need = c->scans_begun - o.built_at < 64 ? (o.need * 4 < 4096u ? o.need * 4 : 4096u) : 2u;
+        o.wanted = 0;
+    }
+    o.valid = false;
 }
+
+// spare slots every segment gets on top of a sixteenth of its rows: 16 where that costs under a quarter of the rows
+// (a user with a handful of rows then takes a few hundred appends' worth of new sessions before anything has to move), else 4
+int ord_spare(const pie_ctx* c) { return (long long)16 * c->cap_users <= c->cap_rows / 4 ? 16 : 4; }
 
 OrdMirror ord_mirror_of(const pie_ctx* c)
 {
@@ -486,7 +517,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
     if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
     int rc = sync_all(c);
     if (rc) return rc;
-    ord_invalidate(c);
+    ord_invalidate(c, keep_rows == 0);
     long long rows = n > 0 ? n : 1;
     if (rows > c->cap_rows || n_users > c->cap_users) {
         int users = n_users;
@@ -616,7 +647,9 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     hipStream_t s = c->stream;
     const int grid = c->n_cus * 8;
     const bool full_build = row0 == 0 || !c->key_ok || rebuild;
-    if (full_build) ord_invalidate(c); // the run carries copies of the keys
+    // the ordered run carries copies of both keys: a refit of the table's keys refits them from its copy of `end` (below);
+    // a first build means a new table, whose run went with the old one
+    if (full_build && !(rebuild && c->key_ok && c->ord.valid && c->ord.rows == c->n)) ord_invalidate(c);
     timespec tb0{};
     if (full_build) { // index_build_ms of pie_table_info: everything from here to the last key kernel's completion
         PIE_HIP(c, hipStreamSynchronize(s));
@@ -678,6 +711,12 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
     }
     hipLaunchKernelGGL(k_build_fine_key, dim3(grid), dim3(256), 0, s, c->d_end, row0, c->n, c->fkey_base, c->fkey_shift, c->d_fkey);
     PIE_HIP(c, hipGetLastError());
+    if (rebuild && c->ord.valid) { // filler positions hold end = 0 (or below every base): key 0 under any parameters
+        hipLaunchKernelGGL(k_build_key, dim3(grid), dim3(256), 0, s, c->ord.end, 0LL, c->ord.n, c->key_base, c->key_shift, c->ord.key,
+                           (const long long*)nullptr, (const int*)nullptr, (const int*)nullptr, (PayRec*)nullptr);
+        hipLaunchKernelGGL(k_build_fine_key, dim3(grid), dim3(256), 0, s, c->ord.end, 0LL, c->ord.n, c->fkey_base, c->fkey_shift, c->ord.fkey);
+        PIE_HIP(c, hipGetLastError());
+    }
     c->key_ok = true;
     if (full_build) {
         PIE_HIP(c, hipStreamSynchronize(s));
@@ -915,13 +954,23 @@ int ord_alloc(pie_ctx* c)
     OrderedRun& o = c->ord;
     if (o.pay && o.cap >= c->cap_rows && o.cap_users >= c->cap_users) return PIE_OK;
     ord_free(c);
-    const size_t padded = (((size_t)c->cap_rows + 1023) / 1024) * 1024 + 1024; // whole chunks of zero keys behind the last row
+    // positions: every row of capacity, a sixteenth more and four per user as spare slots; then whole chunks of zero keys
+    const size_t positions = (size_t)c->cap_rows + (size_t)c->cap_rows / 16 + (size_t)ord_spare(c) * (size_t)c->cap_users + 64;
+    const size_t padded = ((positions + 1023) / 1024) * 1024 + 1024;
+    // a scan stages one 4-byte entry per position in the slot's record staging (sel): a table with far more users than rows
+    // (four spare slots each) does not fit there, and has no use for the run anyway
+    if ((padded + kOrdTile) * 4 > (size_t)c->sel_cap * sizeof(SelRec)) {
+        o.no_room = true;
+        return PIE_OK;
+    }
     const size_t units = ((padded / 512 + 8 + 1023) / 1024) * 1024;              // the smallest unit is a 512-position chunk; whole groups
     const size_t tiles = padded / kOrdTile + 2;
     const bool ok = hipMalloc(&o.pay, padded * sizeof(OrdRec)) == hipSuccess && hipMalloc(&o.end, padded * 8) == hipSuccess &&
                     hipMalloc(&o.key, padded * sizeof(lkey_t)) == hipSuccess && hipMalloc(&o.fkey, padded * sizeof(fkey_t)) == hipSuccess &&
                     hipMalloc(&o.pos, (size_t)c->cap_rows * 4 + 64) == hipSuccess &&
                     hipMalloc(&o.uoff, ((size_t)c->cap_users + 1) * 8) == hipSuccess &&
+                    hipMalloc(&o.ufill, ((size_t)c->cap_users + 1) * 4) == hipSuccess &&
+                    hipMalloc(&o.pend, ((size_t)c->cap_users + 1) * 4) == hipSuccess && hipMalloc(&o.placed, 2 * 4096 * 4) == hipSuccess &&
                     hipMalloc(&o.unit_count[0], units * 4) == hipSuccess && hipMalloc(&o.unit_count[1], units * 4) == hipSuccess &&
                     hipMalloc(&o.unit_local, units * 4) == hipSuccess && hipMalloc(&o.group_sum, (units / 1024 + 2) * 8) == hipSuccess &&
                     hipMalloc(&o.group_base, (units / 1024 + 2) * 8) == hipSuccess &&
@@ -935,6 +984,7 @@ int ord_alloc(pie_ctx* c)
         return PIE_OK;
     }
     o.cap = c->cap_rows;
+    o.pos_cap = (long long)positions;
     o.cap_users = c->cap_users;
     o.units_cap = (long long)units;
     return PIE_OK;
@@ -988,8 +1038,27 @@ int build_ordered(pie_ctx* c)
     c->bdshift_want = k.bdshift_want; c->batch_poor = k.batch_poor;
     if (rc) return rc;
     const long long m = (long long)built->last.m;
-    const size_t padded = (((size_t)o.cap + 1023) / 1024) * 1024 + 1024;
+    // segments: user u's rows, then spare slots for the rows to come (k_ord_append); users that do not exist yet get four
+    const int seg_users = c->cap_users;
+    std::vector<int> cnt((size_t)seg_users + 1, 0);
+    PIE_HIP(c, hipMemcpyAsync(cnt.data(), built->counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    std::vector<long long> seg((size_t)seg_users + 1);
+    long long total = 0;
+    const int spare = ord_spare(c);
+    for (int u = 0; u < seg_users; ++u) {
+        seg[(size_t)u] = total;
+        total += (long long)cnt[(size_t)u] + cnt[(size_t)u] / 16 + spare;
+    }
+    seg[(size_t)seg_users] = total;
+    if (total > o.pos_cap) { o.no_room = true; return PIE_OK; } // cannot happen by ord_alloc's sizing; stay on the general path
+    const size_t padded = (((size_t)o.pos_cap + 1023) / 1024) * 1024 + 1024;
+    PIE_HIP(c, hipMemcpyAsync(o.uoff, seg.data(), ((size_t)seg_users + 1) * 8, hipMemcpyHostToDevice, s));
+    PIE_HIP(c, hipMemcpyAsync(o.ufill, cnt.data(), ((size_t)seg_users + 1) * 4, hipMemcpyHostToDevice, s));
+    PIE_HIP(c, hipMemsetAsync(o.pend, 0, ((size_t)seg_users + 1) * 4, s));
     PIE_HIP(c, hipMemsetAsync(o.pos, 0xFF, (size_t)o.cap * 4, s));
+    PIE_HIP(c, hipMemsetAsync(o.pay, 0xFF, padded * sizeof(OrdRec), s)); // filler: discipline -1, never selected
+    PIE_HIP(c, hipMemsetAsync(o.end, 0, padded * 8, s));
     PIE_HIP(c, hipMemsetAsync(o.key, 0, padded * sizeof(lkey_t), s));
     PIE_HIP(c, hipMemsetAsync(o.fkey, 0, padded * sizeof(fkey_t), s));
     PIE_HIP(c, hipMemsetAsync(o.unit_count[0], 0, (size_t)o.units_cap * 4, s));
@@ -997,11 +1066,10 @@ int build_ordered(pie_ctx* c)
     PIE_HIP(c, hipMemsetAsync(o.sum[0], 0, ord_sum_bytes(), s));
     PIE_HIP(c, hipMemsetAsync(o.sum[1], 0, ord_sum_bytes(), s));
     if (m > 0) {
-        hipLaunchKernelGGL(k_ord_gather, dim3(c->n_cus * 16), dim3(256), 0, s, built->out_idx, m, c->d_pay, c->d_end, c->d_key, c->d_fkey,
-                           o.pay, o.end, o.key, o.fkey, o.pos);
+        hipLaunchKernelGGL(k_ord_gather, dim3(c->n_cus * 16), dim3(256), 0, s, built->out_idx, m, built->offsets, o.uoff, c->d_pay, c->d_end,
+                           c->d_key, c->d_fkey, o.pay, o.end, o.key, o.fkey, o.pos);
         PIE_HIP(c, hipGetLastError());
     }
-    PIE_HIP(c, hipMemcpyAsync(o.uoff, built->offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, s));
     PIE_HIP(c, hipStreamSynchronize(s));
     *o.h_stale = 0;
     // the build's scan is not a result: the caller's last one (in the other slot) stays readable, and the next scan takes
@@ -1009,15 +1077,97 @@ int build_ordered(pie_ctx* c)
     built->have_result = false;
     c->res = (k.res && k.res != built) ? k.res : nullptr;
     c->next_slot = k.next_slot;
-    o.n = m;
+    o.n = total;
+    o.held = m;
+    o.users = seg_users;
     o.rows = c->n;
     o.uc_next = 0;
     o.valid = true;
     o.wanted = 0;
+    o.built_at = c->scans_begun;
     o.builds++;
     timespec t1{};
     clock_gettime(CLOCK_MONOTONIC, &t1);
     o.build_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    return PIE_OK;
+}
+
+constexpr int kOrdAppendMax = 4096; // rows of one append the run takes (each row looks at the batch's earlier rows)
+
+void launch_ord_append(pie_ctx* c, hipStream_t s, size_t k, long long row0, int n_users, int pass)
+{
+    OrderedRun& o = c->ord;
+    const unsigned grid = (unsigned)((k + 255) / 256);
+    const int* st_user = reinterpret_cast<const int*>(c->d_stage + k * 16);
+    if (pass == 2) (void)hipMemcpyAsync(o.placed + kOrdAppendMax, o.placed, k * 4, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_ord_append, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(c->d_stage),
+                       reinterpret_cast<const long long*>(c->d_stage + k * 8), st_user, reinterpret_cast<const int*>(c->d_stage + k * 20), (int)k,
+                       row0, n_users, c->key_base, c->key_shift, c->fkey_base, c->fkey_shift, o.uoff, o.ufill, o.pay, o.end, o.key, o.fkey,
+                       o.pos, o.stale, o.placed + kOrdAppendMax, o.placed, pass);
+    hipLaunchKernelGGL(k_ord_append_commit, dim3(grid), dim3(256), 0, s, st_user, (int)k, n_users, o.placed, pass, o.ufill,
+                       pass == 1 ? o.pend : (int*)nullptr);
+}
+
+// Segments are full: give every user fresh spare slots (its rows, the rows of this append still waiting, a sixteenth more,
+// four) and move the run there — a linear pass, no sort.  Then the waiting rows of the append (still in the staging block)
+// take their places.  Returns with the run valid, or invalid when it no longer fits / the second pass failed too.
+int ord_respread(pie_ctx* c, size_t k, long long row0, int n_users)
+{
+    OrderedRun& o = c->ord;
+    hipStream_t s = c->stream;
+    const size_t padded = (((size_t)o.pos_cap + 1023) / 1024) * 1024 + 1024;
+    if (!o.alt_pay) {
+        const bool ok = hipMalloc(&o.alt_pay, padded * sizeof(OrdRec)) == hipSuccess && hipMalloc(&o.alt_end, padded * 8) == hipSuccess &&
+                        hipMalloc(&o.alt_key, padded * sizeof(lkey_t)) == hipSuccess && hipMalloc(&o.alt_fkey, padded * sizeof(fkey_t)) == hipSuccess &&
+                        hipMalloc(&o.alt_uoff, ((size_t)o.cap_users + 1) * 8) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
+            ord_invalidate(c);
+            return PIE_OK;
+        }
+    }
+    const int seg_users = o.users;
+    std::vector<int> fill((size_t)seg_users + 1), pend((size_t)seg_users + 1);
+    PIE_HIP(c, hipMemcpyAsync(fill.data(), o.ufill, (size_t)seg_users * 4, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipMemcpyAsync(pend.data(), o.pend, (size_t)seg_users * 4, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipMemsetAsync(o.pend, 0, ((size_t)seg_users + 1) * 4, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    std::vector<long long> seg((size_t)seg_users + 1);
+    long long total = 0;
+    for (int u = 0; u < seg_users; ++u) {
+        seg[(size_t)u] = total;
+        const long long rows = (long long)fill[(size_t)u] + pend[(size_t)u];
+        total += rows + rows / 16 + ord_spare(c);
+    }
+    seg[(size_t)seg_users] = total;
+    if (total > o.pos_cap) { // the table has outgrown what the run's arrays were sized for: a rebuild re-allocates
+        ord_free(c);
+        return PIE_OK;
+    }
+    PIE_HIP(c, hipMemcpyAsync(o.alt_uoff, seg.data(), ((size_t)seg_users + 1) * 8, hipMemcpyHostToDevice, s));
+    PIE_HIP(c, hipMemsetAsync(o.alt_pay, 0xFF, padded * sizeof(OrdRec), s));
+    PIE_HIP(c, hipMemsetAsync(o.alt_end, 0, padded * 8, s));
+    PIE_HIP(c, hipMemsetAsync(o.alt_key, 0, padded * sizeof(lkey_t), s));
+    PIE_HIP(c, hipMemsetAsync(o.alt_fkey, 0, padded * sizeof(fkey_t), s));
+    hipLaunchKernelGGL(k_ord_respread, dim3(c->n_cus * 16), dim3(256), 0, s, o.n, seg_users, o.uoff, o.ufill, o.alt_uoff, o.pay, o.end, o.key,
+                       o.fkey, o.alt_pay, o.alt_end, o.alt_key, o.alt_fkey, o.pos);
+    PIE_HIP(c, hipGetLastError());
+    std::swap(o.pay, o.alt_pay);
+    std::swap(o.end, o.alt_end);
+    std::swap(o.key, o.alt_key);
+    std::swap(o.fkey, o.alt_fkey);
+    std::swap(o.uoff, o.alt_uoff);
+    o.n = total;
+    o.respreads++;
+    o.h_stale[0] = o.h_stale[1] = 0;
+    launch_ord_append(c, s, k, row0, n_users, 2);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipStreamSynchronize(s));
+    if (*(volatile unsigned int*)&o.h_stale[0] || *(volatile unsigned int*)&o.h_stale[1]) {
+        o.h_stale[0] = o.h_stale[1] = 0;
+        ord_invalidate(c);
+    }
     return PIE_OK;
 }
 
@@ -1138,7 +1288,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg, int msg_u_
     // in a row such a query arrives with nothing in flight and the table unchanged (a first dense query may be the only one).
     bool ord_route = false;
     if (!c->d_qual && !c->k1_pinned && c->key_ok && !c->ord.no_room && ordered_wanted(c)) {
-        if (!c->ord.valid && c->n_flight <= 1 && (c->ord.mode == 2 || ++c->ord.wanted >= 2)) {
+        if (!c->ord.valid && c->n_flight <= 1 && (c->ord.mode == 2 || ++c->ord.wanted >= c->ord.need)) {
             int rc = build_ordered(c);
             if (rc) return rc;
         }
@@ -2124,13 +2274,32 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
                            reinterpret_cast<const int*>(c->d_stage + k * 20), (long long)k, old_n, n_users, c->d_start, c->d_end, c->d_user,
                            c->d_disc, c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift, c->d_pay,
                            &c->d_summary->bad_rows);
+        // the ordered run takes rows that arrive in time order into the spare slots of their users' segments
+        bool ord_kept = false;
+        if (c->ord.valid && c->ord.rows == old_n && k <= (size_t)kOrdAppendMax && n_users <= c->ord.users && c->key_ok) {
+            launch_ord_append(c, s, k, old_n, n_users, 1); // pend[] is all zero between appends (build and re-spread leave it so)
+            ord_kept = true;
+        }
         PIE_HIP(c, hipGetLastError());
         PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
-        if (c->h_summary->bad_rows) // the rows were written beyond n: the table itself is unchanged
+        if (c->h_summary->bad_rows) { // the rows were written beyond n: the table itself is unchanged
+            if (ord_kept) ord_invalidate(c); // ... but some of them may sit in the run's spare slots
             return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", c->h_summary->bad_rows, n_users);
+        }
         c->n = old_n + (long long)k;
-        ord_invalidate(c);
+        if (ord_kept) {
+            volatile unsigned int* st = c->ord.h_stale; // [0] rows out of time order, [1] rows whose segment was full
+            if (st[0] == 0 && st[1] != 0) {
+                int rc2 = ord_respread(c, k, old_n, n_users);
+                if (rc2) return rc2;
+            } else if (st[0] != 0) ord_invalidate(c, false, true);
+            c->ord.h_stale[0] = c->ord.h_stale[1] = 0;
+            if (c->ord.valid) {
+                c->ord.rows = c->n;
+                c->ord.held += (long long)k;
+            }
+        } else ord_invalidate(c);
         if (n_users > c->n_users) set_user_count(c, n_users);
         c->key_dirty = true;
         c->res = nullptr;
@@ -2853,14 +3022,16 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
         out->workspace_bytes += 2 * ((uint64_t)kBatchMax * (uint64_t)batch_users_stride(c) * 12 + (uint64_t)kBatchMax * (uint64_t)batch_out_stride(c) * 4 +
                                      ((uint64_t)users << c->bdshift) * sizeof(BktRec)) + 3 * (uint64_t)kBatchMax * (uint64_t)counts_span(c);
     out->index_build_ms = c->index_build_ms;
-    out->ordered_rows = c->ord.valid ? (uint64_t)c->ord.n : 0u;
+    out->ordered_rows = c->ord.valid ? (uint64_t)c->ord.held : 0u;
+    out->ordered_positions = c->ord.valid ? (uint64_t)c->ord.n : 0u;
     // the run's columns (record 16 + end 8 + keys 3 per position, row -> position 4 per row) and its small per-unit arrays
-    out->ordered_bytes = c->ord.pay ? (uint64_t)c->ord.cap * (sizeof(OrdRec) + 8 + sizeof(lkey_t) + sizeof(fkey_t) + 4) +
-                                          (uint64_t)c->ord.units_cap * 12 + ((uint64_t)c->ord.cap / kOrdTile + 2) * kOrdSlices * 12 +
-                                          ((uint64_t)c->ord.cap_users + 1) * 8
+    out->ordered_bytes = c->ord.pay ? (uint64_t)c->ord.pos_cap * (sizeof(OrdRec) + 8 + sizeof(lkey_t) + sizeof(fkey_t)) + (uint64_t)c->ord.cap * 4 +
+                                          (uint64_t)c->ord.units_cap * 12 + ((uint64_t)c->ord.pos_cap / kOrdTile + 2) * kOrdSlices * 12 +
+                                          ((uint64_t)c->ord.cap_users + 1) * 12
                                     : 0u;
     out->ordered_build_ms = c->ord.build_ms;
     out->ordered_builds = c->ord.builds;
+    out->ordered_respreads = c->ord.respreads;
     return PIE_OK;
 }
 

@@ -62,7 +62,7 @@ def test_ordered_run_equals_the_oracle(pie, oracle, n, U, D, flags):
         if n >= 70001:
             assert 0x2003 in forms and (0x2400 in forms or 0x2C00 in forms), [hex(f) for f in forms]
         info = ctx.table_info()
-        assert info["ordered_builds"] == 1 and info["ordered_rows"] <= n and info["ordered_bytes"] > 0
+        assert info["ordered_builds"] == 1 and info["ordered_rows"] <= n <= info["ordered_positions"] and info["ordered_bytes"] > 0
 
 
 def test_ordered_run_empty_and_unselectable_tables(pie, oracle):
@@ -152,15 +152,81 @@ def test_ordered_run_follows_every_writer_of_end(pie, oracle):
         assert ctx.table_info()["ordered_rows"] == 0
         all_queries(ctx, "revived outside the run")
         assert ctx.table_info()["ordered_builds"] == 2
-        # append: the run no longer covers the table
+        # an append out of time order (old starts): the run no longer describes the table
         k = 1000
         a = [c.copy() for c in oracle.gen(SEED + 2, k, 0, k, U, D, 0)]
-        a[0] += 0
         ctx.append_rows(*a, U)
         s, e, u, d = [np.concatenate([x, y]) for x, y in zip((s, e, u, d), a)]
         assert ctx.table_info()["ordered_rows"] == 0
         all_queries(ctx, "appended")
         assert ctx.table_info()["ordered_builds"] == 3
+
+
+def test_ordered_run_takes_appends_in_time_order(pie, oracle):
+    """createSession: rows whose start is not below their user's last start go into the spare slots of the user's segment — the
+    run stays valid (no rebuild), answers stay exact, touches of the new rows are mirrored; users that did not exist when the
+    run was built have segments too; when a segment fills up the run is re-spread (a linear move into fresh segments, no rebuild)
+    and the rows left over take their places; a row out of time order drops the run."""
+    n, U, D = 200000, 300, 8                                                      # ~666 rows per user: ~45 spare slots each
+    t0 = oracle.T0_MS
+    s, e, u, d = [c.copy() for c in oracle.gen(SEED + 7, n, 0, n, U, D, 0)]
+    qs = [(t0 + 6 * HOUR, t0 - 61 * DAY, ALL), (t0 - 100 * DAY, t0 - 61 * DAY, 0x55), (t0 + 2 * DAY, INT64_MIN, ALL), (INT64_MIN, INT64_MIN, ALL)]
+    rng = np.random.default_rng(3)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_ordered_run(2)
+
+        def all_queries(tag, n_users):
+            for k, q in enumerate(qs):
+                check(ctx, oracle, (s, e, u, d), n_users, D, q, f"{tag} q{k}")
+        all_queries("fresh", U)
+        now = t0 + HOUR
+        # the first append (of a new user) outgrows the loaded table's row and user capacity: the table is re-allocated (twice
+        # the size, room for as many users again) and the run goes with it
+        n_users = U + 1
+        ctx.append_rows(np.array([now], np.int64), np.array([now + HOUR], np.int64), np.array([U], np.int32), np.array([0], np.int32), n_users)
+        s, e, u, d = np.append(s, now), np.append(e, now + HOUR), np.append(u, U).astype(np.int32), np.append(d, 0).astype(np.int32)
+        assert ctx.table_info()["ordered_rows"] == 0
+        all_queries("grown", n_users)
+        assert ctx.table_info()["ordered_builds"] == 2
+        for step in range(12):
+            k = int(rng.integers(1, 200))
+            now += int(rng.integers(0, 5000))
+            s2 = np.sort(now + rng.integers(0, 3, k)).astype(np.int64)            # equal and ascending starts inside one batch
+            e2 = s2 + 12 * HOUR
+            if step == 5:
+                n_users = U + 8                                                   # users the run has only empty segments for
+            u2 = rng.integers(0, n_users, k).astype(np.int32)
+            if step % 3 == 0:
+                u2[: min(k, 5)] = 11                                              # the same user several times in one batch
+            d2 = rng.integers(0, D, k).astype(np.int32)
+            ctx.append_rows(s2, e2, u2, d2, n_users)
+            s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]), np.concatenate([d, d2])
+            now = int(s2[-1])
+            if step % 4 == 1:                                                     # touch some of the rows just appended
+                rows = np.arange(s.size - k, s.size, 3, dtype=np.int32)
+                ne = (e[rows] + rng.integers(-20 * HOUR, 20 * HOUR, rows.size)).astype(np.int64)
+                ctx.set_end(rows, ne)
+                e[rows] = ne
+            info = ctx.table_info()
+            assert info["ordered_builds"] == 2 and info["ordered_rows"] == s.size, (step, info)
+            all_queries(f"step {step}", n_users)
+        # one user's segment fills up many times over in ONE append: a re-spread makes room for all of it
+        k = 4000
+        s2 = np.full(k, now + 10, np.int64)
+        before = ctx.table_info()["ordered_respreads"]
+        ctx.append_rows(s2, s2 + HOUR, np.full(k, 11, np.int32), np.zeros(k, np.int32), n_users)
+        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + HOUR]), np.concatenate([u, np.full(k, 11, np.int32)]), np.concatenate([d, np.zeros(k, np.int32)])
+        info = ctx.table_info()
+        assert info["ordered_rows"] == s.size and info["ordered_respreads"] == before + 1 and info["ordered_builds"] == 2
+        all_queries("segment overflow", n_users)
+        now += 10
+        # a batch out of time order inside itself
+        s2 = np.array([now + 100, now + 50], np.int64)
+        ctx.append_rows(s2, s2 + HOUR, np.array([3, 3], np.int32), np.zeros(2, np.int32), n_users)
+        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + HOUR]), np.concatenate([u, [3, 3]]).astype(np.int32), np.concatenate([d, [0, 0]]).astype(np.int32)
+        assert ctx.table_info()["ordered_rows"] == 0
+        all_queries("out of order", n_users)
 
 
 def test_ordered_run_is_built_when_the_general_path_is_weak(pie, oracle):

@@ -74,7 +74,10 @@ while time.time() < t_end:
                     e[gone] = INT64_MIN
                 elif r < 0.4 and n < 400000:
                     k = int(rng.integers(1, 3000))
-                    s2 = rng.integers(T0 - 150 * DAY, T0 + 300 * DAY, k).astype(np.int64)
+                    if rng.random() < 0.6:   # a session store's appends: created now, i.e. not before anything the table holds
+                        s2 = (int(s.max()) + np.sort(rng.integers(0, 4000, k))).astype(np.int64)
+                    else:
+                        s2 = rng.integers(T0 - 150 * DAY, T0 + 300 * DAY, k).astype(np.int64)
                     e2 = s2 + rng.integers(-50 * DAY, 50 * DAY, k)
                     u2, d2 = rng.integers(0, U, k).astype(np.int32), rng.integers(0, D, k).astype(np.int32)
                     ctx.append_rows(s2, e2, u2, d2, U)
