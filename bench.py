@@ -442,6 +442,8 @@ def main():
         kname = kernel_name(variant, rides, args.mode)
         if batch_ms is not None:
             kname = "k_scan_batch_with_tail<8, true, %s, %d>" % ("unsigned char" if variant & 0x800 else "unsigned short", 4 if Q <= 4 else 8)
+            if variant & 0x2000:
+                kname = "k_ord_batch_scan<%s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local

@@ -62,7 +62,8 @@ typedef struct pie_stats {
     uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first,
                               0x400 keyed: streams the 2-byte liveness key instead of the `end` column, 0x800 the 1-byte key,
                               0x1000 batched: the last finished call was a batch, `selected` sums its queries,
-                              0x2000 ordered run: 0x2003 dense form, 0x2400 / 0x2C00 keyed form on the 2- / 1-byte key) */
+                              0x2000 ordered run: 0x2003 dense form, 0x2400 / 0x2C00 keyed form on the 2- / 1-byte key,
+                              0x3400 / 0x3C00 a batch on the ordered run) */
     uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
     uint64_t live;         /* rows with end > now seen by the last scan */
     uint64_t candidates;   /* keyed form: rows whose key was >= the query's, i.e. payload records the table pass gathered */

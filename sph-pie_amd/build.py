@@ -66,7 +66,7 @@ def _run(cmd, cwd=None):
 def build_hip(force=False):
     """hipcc --offload-arch=gfx950 -> sph-pie_amd/libpie_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "pie_scan.hip"), os.path.join(CSRC, "pie_comm.hip"), os.path.join(CSRC, "pie_kernels.h"),
-            os.path.join(REPO, "include", "pie_scan.h")]
+            os.path.join(CSRC, "pie_ordered.h"), os.path.join(REPO, "include", "pie_scan.h")]
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # pie_comm.hip opens RCCL with dlopen at run time (no link-time dependency: the scan library loads without RCCL)
     return _build(HIP_LIB, srcs, lambda out: [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",

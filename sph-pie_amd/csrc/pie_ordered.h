@@ -432,14 +432,23 @@ __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict
 constexpr int kOrdGroupShift = 10;
 constexpr int kOrdGroup = 1 << kOrdGroupShift;
 
+// blockIdx.y = query of a batch (strides 0 and one row of blocks for a single scan): every query has its own counts, prefixes,
+// counter and summary
 __global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit_count, long long n_units, int* __restrict__ unit_local,
                                                     long long* __restrict__ group_sum, long long* __restrict__ group_base,
-                                                    OrdCtl* __restrict__ ctl, Summary* __restrict__ summary)
+                                                    OrdCtl* __restrict__ ctl, Summary* __restrict__ summary, long long unit_stride,
+                                                    long long group_stride, long long sum_stride_bytes)
 {
     __shared__ int wsum[4];
     __shared__ long long wsum64[4];
     __shared__ bool is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unit_count += (long long)blockIdx.y * unit_stride;
+    unit_local += (long long)blockIdx.y * unit_stride;
+    group_sum += (long long)blockIdx.y * group_stride;
+    group_base += (long long)blockIdx.y * group_stride;
+    ctl += blockIdx.y;
+    summary = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)blockIdx.y * sum_stride_bytes);
     const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
     for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const long long u = (g << kOrdGroupShift) + 4 * (long long)threadIdx.x; // unit_count is padded to whole groups of zeros
@@ -606,9 +615,12 @@ __global__ __launch_bounds__(256) void k_ord_emit(const long long* __restrict__ 
 // last.  (A "last block publishes" tail inside k_ord_emit would cost every one of its thousands of blocks a device-scope
 // fence — an L2 write-back each, right after the row list was written — and an atomic on one address: measured 0.25 ms on
 // the dense query.  A kernel boundary orders the same thing for a few microseconds.)
-__global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summary, HostSummary* __restrict__ host, unsigned long long seq)
+__global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summary, HostSummary* __restrict__ host, unsigned long long seq,
+                                                    long long sum_stride_bytes)
 {
     const int lane = threadIdx.x;
+    summary = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)blockIdx.x * sum_stride_bytes); // a batch: one block per query
+    host += blockIdx.x;
     unsigned long long live = 0, amb = 0, cand = 0;
     unsigned int chunk_max = 0;
     sum_row_stats(summary, lane, live, amb, &cand, &chunk_max);
@@ -630,6 +642,319 @@ __global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summar
         summary->max_count = 0; // m stays: the pack kernel reads it from here, and the next prefix overwrites it
         host->s = out;
         __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batched form: Q queries, one pass over the key column
+
+// A table whose users are skewed cannot run the general batched pass (a head user's rows do not fit any union bucket), so
+// its batches used to run as Q single scans, each streaming the key column again.  On the run a batch is ONE pass: the
+// candidates are the positions whose key reaches the smallest key(now) of the batch, every candidate is evaluated against
+// all queries (one 16-byte gather, `end` only where some query's key cannot decide), and a position that any query selects
+// is staged once, in position order, as {position, query mask}.
+//   k_ord_batch_scan    key stream -> union staging records + per-chunk union counts
+//   k_ord_batch_count   per chunk and query: how many of the chunk's records carry the query's bit
+//   k_ord_prefix        (gridDim.y = Q) per-query exclusive prefix of those counts
+//   k_ord_batch_emit    per chunk: every query's row list (the record's row id is fetched once, then compacted per query
+//                       by ballot); per user: every query's offset and count
+//   k_ord_publish       (gridDim.x = Q) summaries
+struct OrdBatchQuery {
+    long long now, cutoff;
+    unsigned long long mask;
+    unsigned now_key;
+    unsigned pad;
+};
+struct OrdBatchArgs {
+    int n_q;
+    unsigned min_key;
+    OrdBatchQuery q[kBatchMax];
+};
+struct alignas(8) OrdUnion {
+    unsigned pos;
+    unsigned qmask;
+};
+
+template <class KT>
+__global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
+                                                        const KT* __restrict__ key, long long n_ord, long long n_chunks, OrdBatchArgs a,
+                                                        OrdUnion* __restrict__ ustage, int* __restrict__ ucount,
+                                                        Summary* __restrict__ summary)
+{
+    constexpr int kPerLane = 16 / (int)sizeof(KT);
+    constexpr int kChunk = kPerLane * kWave;
+    constexpr int kChunkShift = sizeof(KT) == 1 ? 10 : 9;
+    constexpr int kRing = 2 * kChunk;
+    constexpr int kUnroll = 4;
+    __shared__ int ring_s[4][kRing];
+    __shared__ KT ringk_s[4][kRing];
+    __shared__ int blk_cand, blk_chunk_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { blk_cand = 0; blk_chunk_max = 0; }
+    __syncthreads();
+    int* ring = ring_s[wave];
+    KT* ringk = ringk_s[wave];
+    int head = 0, fill = 0, ncand = 0, chunk_max = 0;
+    int cur_chunk = -1, cur_cnt = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int nq = a.n_q;
+
+    bool a_have = false, a_valid = false, a_amb = false;
+    int a_pos = 0x7FFFFFFF;
+    unsigned a_key = 0;
+    OrdRec a_pay;
+    a_pay.start = 0; a_pay.row = 0; a_pay.disc = -1;
+    long long a_end = 0;
+
+    auto step_b = [&]() {
+        if (!a_have) return;
+        a_have = false;
+        unsigned qmask = 0;
+        if (a_valid) {
+            const int dv = a_pay.disc;
+            const bool disc_ok = (unsigned)dv < 64u;
+            for (int q = 0; q < nq; ++q) { // wave-uniform loop over the queries' scalars
+                const OrdBatchQuery& Q = a.q[q];
+                const bool live = a_key > Q.now_key || (a_key == Q.now_key && a_end > Q.now);
+                const bool p = live & (a_pay.start >= Q.cutoff) & disc_ok & (((Q.mask >> (dv & 63)) & 1ull) != 0);
+                qmask |= (p ? 1u : 0u) << q;
+            }
+        }
+        ncand += __popcll(__ballot(a_valid));
+        const bool sel = qmask != 0;
+        const unsigned long long sb = __ballot(sel);
+        if (sb == 0) return;
+        const int ch = a_pos >> kChunkShift;
+        const int ch_below = __shfl_up(ch, 1, kWave);
+        const unsigned long long hb = __ballot(lane == 0 || ch != ch_below);
+        const int first = 63 - __clzll((long long)(hb & le));
+        int rank = __popcll(sb & lt & ~((1ull << first) - 1ull));
+        if (ch == cur_chunk) rank += cur_cnt;
+        const unsigned long long ha = hb & ~le;
+        const int seg_end = ha ? __ffsll((long long)ha) - 1 : 64;
+        const unsigned long long upto = seg_end == 64 ? ~0ull : ((1ull << seg_end) - 1ull);
+        const bool last_of_seg = sel && (sb & ~le & upto) == 0;
+        const int last = 63 - __clzll((long long)sb);
+        const int new_chunk = __shfl(ch, last, kWave);
+        const int new_cnt = __shfl(rank, last, kWave) + 1;
+        if (sel) {
+            OrdUnion r;
+            r.pos = (unsigned)a_pos;
+            r.qmask = qmask;
+            ustage[((long long)ch << kChunkShift) + rank] = r;
+            if (last_of_seg && ch != new_chunk) ucount[ch] = rank + 1;
+        }
+        if (cur_chunk >= 0 && cur_chunk != new_chunk && __ballot(sel && ch == cur_chunk) == 0 && lane == 0) ucount[cur_chunk] = cur_cnt;
+        cur_chunk = new_chunk;
+        cur_cnt = new_cnt;
+    };
+    auto step_a = [&](int cnt) {
+        a_valid = false;
+        a_amb = false;
+        a_pos = 0x7FFFFFFF;
+        if (lane < cnt) {
+            const int slot = (head + lane) & (kRing - 1);
+            a_pos = ring[slot];
+            a_key = ringk[slot];
+            if (a_pos < n_ord) {
+                a_valid = true;
+                a_pay = pay[a_pos];
+                for (int q = 0; q < nq; ++q) a_amb |= a_key == a.q[q].now_key;
+                if (a_amb) a_end = end[a_pos];
+            }
+        }
+        a_have = true;
+        head = (head + cnt) & (kRing - 1);
+        fill -= cnt;
+    };
+
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
+    const unsigned mk = a.min_key;
+    const unsigned nk_ge = sizeof(KT) == 2 ? (mk | (mk << 16)) : mk * 0x01010101u;
+    auto row_bits = [&](unsigned g0, unsigned g1, unsigned g2, unsigned g3) -> unsigned {
+        if constexpr (sizeof(KT) == 1) {
+            auto nib = [](unsigned g) { return ((((g >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+            return nib(g0) | (nib(g1) << 4) | (nib(g2) << 8) | (nib(g3) << 12);
+        } else {
+            auto two = [](unsigned g) { return ((g >> 15) & 1u) | ((g >> 30) & 2u); };
+            return two(g0) | (two(g1) << 2) | (two(g2) << 4) | (two(g3) << 6);
+        }
+    };
+    const long long W = (long long)gridDim.x * 4;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    for (long long cb = gw; cb < n_chunks; cb += W * kUnroll) {
+        u4_t kv[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const long long ch = cb + (long long)j * W;
+            kv[j] = (u4_t){0u, 0u, 0u, 0u};
+            if (ch < n_chunks) kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const long long ch = cb + (long long)j * W;
+            if (ch >= n_chunks) continue;
+            const unsigned ge = row_bits(((kv[j].x | kTop) - nk_ge) & kTop, ((kv[j].y | kTop) - nk_ge) & kTop,
+                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop);
+            const int cnt = __popc(ge);
+            const int incl = wave_incl_scan_i32(cnt, lane);
+            const int total = __shfl(incl, 63, kWave);
+            if (total == 0) continue;
+            chunk_max = max(chunk_max, total);
+            int w = head + fill + incl - cnt;
+            const int p0 = (int)(ch << kChunkShift) + kPerLane * lane;
+            unsigned m = ge;
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                unsigned kq;
+                if constexpr (sizeof(KT) == 1) {
+                    const unsigned word = (b >> 2) == 0 ? kv[j].x : (b >> 2) == 1 ? kv[j].y : (b >> 2) == 2 ? kv[j].z : kv[j].w;
+                    kq = (word >> (8 * (b & 3))) & 0xFFu;
+                } else {
+                    const unsigned word = (b >> 1) == 0 ? kv[j].x : (b >> 1) == 1 ? kv[j].y : (b >> 1) == 2 ? kv[j].z : kv[j].w;
+                    kq = (word >> (16 * (b & 1))) & 0xFFFFu;
+                }
+                ring[w & (kRing - 1)] = p0 + b;
+                ringk[w & (kRing - 1)] = (KT)kq;
+                ++w;
+                m &= m - 1;
+            }
+            fill += total;
+            __builtin_amdgcn_wave_barrier();
+            while (fill >= kWave) {
+                step_b();
+                step_a(kWave);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (fill > 0) {
+        step_b();
+        step_a(fill);
+    }
+    step_b();
+    if (cur_chunk >= 0 && lane == 0) ucount[cur_chunk] = cur_cnt;
+    if (lane == 0 && ncand) atomicAdd(&blk_cand, ncand);
+    if (lane == 0 && chunk_max) atomicMax(&blk_chunk_max, chunk_max);
+    __syncthreads();
+    if (threadIdx.x == 0) add_row_stats(summary, 0, 0, (int)blockIdx.x, blk_cand, blk_chunk_max);
+}
+
+// one wave per chunk: cq[q][chunk] = records of the chunk that carry query q's bit (zeros for empty chunks: every entry written)
+__global__ __launch_bounds__(256) void k_ord_batch_count(const OrdUnion* __restrict__ ustage, const int* __restrict__ ucount,
+                                                         long long n_chunks, int chunk_shift, int n_q, int* __restrict__ cq,
+                                                         long long unit_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long padded = ((n_chunks + kOrdGroup - 1) >> kOrdGroupShift) << kOrdGroupShift; // the prefix reads whole groups
+    for (long long ch = wv; ch < padded; ch += n_waves) {
+        const int cnt = ch < n_chunks ? ucount[ch] : 0;
+        int tot = 0; // lane q < n_q ends up with query q's count
+        for (int j0 = 0; j0 < cnt; j0 += 64) {
+            const unsigned qm = j0 + lane < cnt ? ustage[(ch << chunk_shift) + j0 + lane].qmask : 0u;
+            for (int q = 0; q < n_q; ++q) {
+                const int c = __popcll(__ballot((qm >> q) & 1u));
+                if (lane == q) tot += c;
+            }
+        }
+        if (lane < n_q) cq[(long long)lane * unit_stride + ch] = tot;
+    }
+}
+
+// Blocks [0, copy_blocks): one wave per chunk writes every query's rows of that chunk.  Blocks behind them: thread t of
+// user-block b has user b * 255 + t and computes every query's offset of that user.
+__global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restrict__ uoff, int n_users, long long n_ord, int chunk_shift,
+                                                        long long n_chunks, int n_q, const OrdUnion* __restrict__ ustage,
+                                                        const int* __restrict__ ucount, const int* __restrict__ unit_local,
+                                                        const long long* __restrict__ group_base, long long unit_stride,
+                                                        long long group_stride, const OrdRec* __restrict__ pay, int* __restrict__ out_idx,
+                                                        long long out_stride, long long* __restrict__ offsets, int* __restrict__ counts_ord,
+                                                        long long users_stride, int copy_blocks, Summary* __restrict__ summary,
+                                                        long long sum_stride_bytes, int* __restrict__ zero_counts, long long zero_n)
+{
+    __shared__ int soff[kBatchMax][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
+    if ((int)blockIdx.x < copy_blocks) {
+        for (long long ch = (long long)blockIdx.x * 4 + wave; ch < n_chunks; ch += (long long)copy_blocks * 4) {
+            const int cnt = ucount[ch];
+            if (cnt == 0) continue; // wave-uniform
+            int running[kBatchMax];
+#pragma unroll
+            for (int q = 0; q < kBatchMax; ++q) running[q] = 0;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                OrdUnion r;
+                r.pos = 0; r.qmask = 0;
+                int row = 0;
+                if (j0 + lane < cnt) {
+                    r = ustage[(ch << chunk_shift) + j0 + lane];
+                    row = pay[r.pos].row;
+                }
+#pragma unroll
+                for (int q = 0; q < kBatchMax; ++q) {
+                    if (q >= n_q) break; // wave-uniform
+                    const bool sel = (r.qmask >> q) & 1u;
+                    const unsigned long long b = __ballot(sel);
+                    if (b == 0) continue;
+                    if (sel) {
+                        const long long at = group_base[(long long)q * group_stride + (ch >> kOrdGroupShift)] +
+                                             unit_local[(long long)q * unit_stride + ch] + running[q] + prefix_in_ballot(b);
+                        if (at < out_stride) out_idx[(long long)q * out_stride + at] = row; // a list beyond the batch's row capacity is rerun
+                    }
+                    running[q] += __popcll(b);
+                }
+            }
+        }
+        return;
+    }
+    const long long u = (long long)((int)blockIdx.x - copy_blocks) * 255 + threadIdx.x;
+    int below[kBatchMax]; // records of my chunk before my segment start, per query
+#pragma unroll
+    for (int q = 0; q < kBatchMax; ++q) below[q] = 0;
+    long long ch = -1;
+    bool at_end = true;
+    if (u <= n_users) {
+        const long long qpos = uoff[u];
+        at_end = qpos >= n_ord;
+        if (!at_end) {
+            ch = qpos >> chunk_shift;
+            const int cnt = ucount[ch];
+            const OrdUnion* rec = ustage + (ch << chunk_shift);
+            for (int j = 0; j < cnt; ++j) {
+                const OrdUnion r = rec[j];
+                if (r.pos >= (unsigned)qpos) break; // staged in position order
+#pragma unroll
+                for (int q = 0; q < kBatchMax; ++q) below[q] += (r.qmask >> q) & 1u;
+            }
+        }
+    }
+    for (int q = 0; q < n_q; ++q) {
+        long long my = 0;
+        if (u <= n_users) {
+            const long long* gb = group_base + (long long)q * group_stride;
+            my = at_end ? gb[n_groups] : gb[ch >> kOrdGroupShift] + unit_local[(long long)q * unit_stride + ch] + below[q];
+            offsets[(long long)q * users_stride + u] = my;
+        }
+        soff[q][threadIdx.x] = (int)my;
+    }
+    __syncthreads();
+    for (int q = 0; q < n_q; ++q) {
+        int cnt = 0;
+        if (threadIdx.x < 255 && u < n_users) {
+            cnt = soff[q][threadIdx.x + 1] - soff[q][threadIdx.x];
+            counts_ord[(long long)q * users_stride + u] = cnt;
+        }
+        int mx = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, kWave));
+        if (lane == 0 && mx > 0) {
+            Summary* sq = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)q * sum_stride_bytes);
+            atomicMax(&sq->max_count, (unsigned)mx);
+        }
     }
 }
 

@@ -101,6 +101,7 @@ struct Slot {
 struct BatchSlot {
     int n_q = 0;
     bool in_flight = false, k2_pending = false, have_result = false;
+    bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no K2, nothing rides
     bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
     bool fine_key = false;
     unsigned long long seq = 0;
@@ -151,6 +152,13 @@ struct OrderedRun {
     fkey_t* alt_fkey = nullptr;
     long long* alt_uoff = nullptr;
     unsigned long long respreads = 0;
+    // batched form: per query unit counts / prefixes / group sums, one summary set per batch slot
+    int* bq_count = nullptr;
+    int* bq_local = nullptr;
+    long long* bq_gsum = nullptr;
+    long long* bq_gbase = nullptr;
+    OrdCtl* bq_ctl = nullptr;
+    char* bq_sum[2] = {nullptr, nullptr};
     int users = 0;                           // users that have a segment (>= n_users: room for users yet to come)
     long long pos_cap = 0;                   // positions the arrays hold
     int* unit_count[2] = {nullptr, nullptr}; // alternate: the finish kernel of one ordered scan zeroes the other buffer
@@ -362,6 +370,7 @@ void ord_free(pie_ctx* c)
     OrderedRun& o = c->ord;
     dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed);
     dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
+    dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
     dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
     dfree(o.sum[0]); dfree(o.sum[1]);
     o.valid = false;
@@ -1171,6 +1180,95 @@ int ord_respread(pie_ctx* c, size_t k, long long row0, int n_users)
     return PIE_OK;
 }
 
+long long batch_users_stride(const pie_ctx* c);
+long long batch_out_stride(const pie_ctx* c);
+
+// the batched form's per-query arrays (allocated at the first ordered batch)
+int ord_batch_alloc(pie_ctx* c)
+{
+    OrderedRun& o = c->ord;
+    if (o.bq_count) return PIE_OK;
+    const size_t units = (size_t)o.units_cap, groups = units / 1024 + 2;
+    const bool ok = hipMalloc(&o.bq_count, (size_t)kBatchMax * units * 4) == hipSuccess &&
+                    hipMalloc(&o.bq_local, (size_t)kBatchMax * units * 4) == hipSuccess &&
+                    hipMalloc(&o.bq_gsum, (size_t)kBatchMax * groups * 8) == hipSuccess &&
+                    hipMalloc(&o.bq_gbase, (size_t)kBatchMax * groups * 8) == hipSuccess &&
+                    hipMalloc(&o.bq_ctl, (size_t)kBatchMax * sizeof(OrdCtl)) == hipSuccess &&
+                    hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess &&
+                    hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
+        return PIE_E_NOMEM;
+    }
+    PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kBatchMax * sizeof(OrdCtl), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
+    return PIE_OK;
+}
+
+// can this batch run on the ordered run?  (a table whose batches the general pass cannot hold: skewed users)
+bool ordered_batch_wanted(const pie_ctx* c)
+{
+    const OrderedRun& o = c->ord;
+    if (o.mode == 0 || !o.valid || o.rows != c->n || c->d_qual || !c->key_ok || c->key_poor) return false;
+    if (!(o.mode == 2 || c->batch_poor || c->hot_bucket)) return false;
+    // union staging records (8 B per position) live in the scan slots' record staging
+    const size_t padded = (((size_t)o.pos_cap + 1023) / 1024) * 1024 + 1024;
+    return (padded + kOrdTile) * sizeof(OrdUnion) <= (size_t)c->sel_cap * sizeof(SelRec);
+}
+
+// five launches: key stream -> union records; per-query chunk counts; per-query prefix; row lists + offsets; summaries
+void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
+{
+    OrderedRun& o = c->ord;
+    const int bi = (int)(&b - c->bslot);
+    char* sums = o.bq_sum[bi];
+    int* uc = o.unit_count[o.uc_next];
+    int* uc_other = o.unit_count[o.uc_next ^ 1];
+    o.uc_next ^= 1;
+    OrdUnion* ustage = reinterpret_cast<OrdUnion*>(c->slot[bi].sel);
+    OrdBatchArgs a;
+    a.n_q = b.n_q;
+    const unsigned impossible = fine ? 0xFFu : 0xFFFFu; // a query that falls back carries a key no row can reach
+    unsigned mk = impossible;
+    for (int q = 0; q < b.n_q; ++q) {
+        a.q[q].now = qs[q].now;
+        a.q[q].cutoff = qs[q].cutoff;
+        a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));
+        a.q[q].now_key = b.fallback[q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
+        a.q[q].pad = 0;
+        if (a.q[q].now_key < mk) mk = a.q[q].now_key;
+    }
+    a.min_key = mk;
+    const int chunk_shift = fine ? 10 : 9;
+    const long long n_chunks = (o.n + (1 << chunk_shift) - 1) >> chunk_shift;
+    const long long units_stride = o.units_cap, group_stride = o.units_cap / 1024 + 2, sum_stride = (long long)ord_sum_bytes();
+    Summary* sum0 = reinterpret_cast<Summary*>(sums);
+    if (fine) {
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 3 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 3;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
+    } else {
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
+    }
+    if (b.ev_index >= 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
+    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, b.n_q, o.bq_count, units_stride);
+    long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
+    if (n_groups < 1) n_groups = 1;
+    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)b.n_q), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase, o.bq_ctl,
+                       sum0, units_stride, group_stride, sum_stride);
+    const int copy_blocks = c->n_cus * 8;
+    const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
+    hipLaunchKernelGGL(k_ord_batch_emit, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks,
+                       b.n_q, ustage, uc, o.bq_local, o.bq_gbase, units_stride, group_stride, o.pay, b.out_idx, batch_out_stride(c), b.offsets,
+                       b.counts_ord, batch_users_stride(c), copy_blocks, sum0, sum_stride, uc_other, o.units_cap);
+    hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)b.n_q), dim3(64), 0, s, sum0, b.h_sum_dev, b.seq, sum_stride);
+}
+
 // should this query run on the ordered run?  (mode 1: where the general path is weak)
 bool ordered_wanted(const pie_ctx* c)
 {
@@ -1239,7 +1337,7 @@ void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long lon
     long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
     if (n_groups < 1) n_groups = 1;
     const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
-    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, uc, n_units, o.unit_local, o.group_sum, o.group_base, ctl, sum);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, uc, n_units, o.unit_local, o.group_sum, o.group_base, ctl, sum, 0LL, 0LL, 0LL);
     const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
     if (keyed) {
         const int copy_blocks = c->n_cus * 8;
@@ -1253,7 +1351,7 @@ void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long lon
                            uc, o.unit_local, o.group_base, n_units, stage, o.pay, o.tile_ballot, o.tile_prefix, sl.out_idx, sl.offsets,
                            sl.counts_ord, (int)copy_blocks, sum, uc_other, o.units_cap);
     }
-    hipLaunchKernelGGL(k_ord_publish, dim3(1), dim3(64), 0, s, sum, sl.h_sum_dev, sl.seq);
+    hipLaunchKernelGGL(k_ord_publish, dim3(1), dim3(64), 0, s, sum, sl.h_sum_dev, sl.seq, 0LL);
 }
 
 int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg = nullptr, int msg_u_pad = 0, long long msg_cap = 0,
@@ -1846,7 +1944,9 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     b.msg_counts = msg_counts; b.msg_counts_stride = msg_counts_stride;
     for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; }
     b.ev_index = -1;
-    b.unsupported = !batch_supported(c) || c->key_poor || c->batch_poor;
+    b.ordered = false;
+    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c);
+    b.unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
     if (b.unsupported) { // finish() runs every query on the general path
         for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
         b.in_flight = true;
@@ -1895,6 +1995,23 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         }
     }
     b.fine_key = fine;
+    if (ord_batch) {
+        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for all queries
+        rc = ord_batch_alloc(c);
+        if (rc) return rc;
+        BatchSlot& prev = c->bslot[c->b_next ^ 1];
+        if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
+        b.seq = ++c->bseq_counter;
+        c->scans_begun++;
+        launch_ordered_batch(c, b, s, qs, fine);
+        PIE_HIP(c, hipGetLastError());
+        b.ordered = true;
+        b.k2_pending = false;
+        b.in_flight = true;
+        c->b_flight++;
+        c->b_next ^= 1;
+        return PIE_OK;
+    }
     // spans: this batch's set and the one its K2 zeroes
     b.span = c->bspan[c->bspan_next];
     c->bspan_next = (c->bspan_next + 1) % 3;
@@ -2079,7 +2196,27 @@ int batch_finish(pie_ctx* c, int* ready_out)
             else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
         }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
-        choose_run_shift(c, b.last[0].cand, b.last[0].chunk_max, b.fine_key);
+        if (!b.ordered) choose_run_shift(c, b.last[0].cand, b.last[0].chunk_max, b.fine_key);
+        if (b.ordered && (b.msg || b.msg_counts)) {
+            // the ordered chain writes no messages: pack them from the finished lists (the queries that fall back pack their own)
+            all_ready = false;
+            const int bi = (int)(&b - c->bslot);
+            for (int q = 0; q < b.n_q; ++q) {
+                if (b.fallback[q]) continue;
+                const Summary* sq = reinterpret_cast<const Summary*>(c->ord.bq_sum[bi] + (size_t)q * ord_sum_bytes());
+                if (b.msg) {
+                    const long long total = (long long)b.msg_u_pad + 2 + (long long)((long long)b.last[q].m < b.msg_cap ? (long long)b.last[q].m : b.msg_cap);
+                    unsigned blocks = (unsigned)((total + 255) / 256);
+                    if (blocks > (unsigned)c->n_cus * 8) blocks = (unsigned)c->n_cus * 8;
+                    hipLaunchKernelGGL(k_pack_results, dim3(blocks ? blocks : 1u), dim3(256), 0, s, b.offsets + (long long)q * batch_users_stride(c), c->n_users,
+                                       b.msg_u_pad, sq, b.out_idx + (long long)q * batch_out_stride(c), b.msg_cap, b.msg + (long long)q * b.msg_stride);
+                }
+                if (b.msg_counts)
+                    PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, b.counts_ord + (long long)q * batch_users_stride(c),
+                                              (size_t)c->n_users * 4, hipMemcpyDefault, s));
+            }
+            PIE_HIP(c, hipGetLastError());
+        }
     }
     b.in_flight = false;
     c->b_flight--;
@@ -3116,7 +3253,7 @@ int pie_stats_get(pie_ctx* c, pie_stats* out)
         out->max_bucket = mx;
         out->n_segments = out->n_big = 0;
         out->k1_blocks = (uint32_t)b.k1_blocks;
-        out->k1_variant = b.unsupported ? 0u : (0x1485u | (b.fine_key ? 0x800u : 0u));
+        out->k1_variant = b.unsupported ? 0u : b.ordered ? (0x3400u | (b.fine_key ? 0x800u : 0u)) : (0x1485u | (b.fine_key ? 0x800u : 0u));
         out->key_ambiguous = 0;
         out->live = 0;
         out->candidates = b.unsupported ? 0 : b.last[0].cand;

@@ -334,3 +334,106 @@ def test_ordered_run_result_messages(pie, oracle):
             assert m == w[2].size
             assert np.array_equal(got[: U + 1], w[1].astype(np.int32)) and np.all(got[U + 1: u_pad + 2] == m)
             assert np.array_equal(got[u_pad + 2: u_pad + 2 + m], w[2])
+
+
+def skewed_table(oracle, n, U, D, seed, head_share=0.4):
+    s, e, u, d = [c.copy() for c in oracle.gen(seed, n, 0, n, U, D, 0)]
+    rng = np.random.default_rng(seed)
+    u = np.where(rng.random(n) < head_share, 7 % U, u).astype(np.int32)
+    return s, e, u, d
+
+
+@pytest.mark.parametrize("n,U,D", [(400000, 2000, 16), (70001, 333, 7), (1 << 20, 50000, 64)])
+@pytest.mark.parametrize("nq", [1, 5, 16])
+def test_ordered_batch_equals_separate_scans(pie, oracle, n, U, D, nq):
+    """Q queries in ONE pass over the run's key column (the batched form a skewed table's batches take): every query's
+    counts / offsets / idx equal the oracle's, with mixed now / cutoff / mask, a dense query that is taken out of the batch,
+    a query that selects nothing, 1-byte and 2-byte key streams."""
+    t0 = oracle.T0_MS
+    cols = skewed_table(oracle, n, U, D, SEED + n + nq)
+    s, e, u, d = cols
+    lim = ALL if D >= 64 else (1 << D) - 1
+    masks = [0x5555555555555555, ALL, 0xAAAAAAAAAAAAAAAA, 0x00000000FFFF0000 | 3, 0x1]
+    base = [(t0 - 6 * HOUR - 977 * i - (i % 3) * HOUR, t0 - (61 + i % 4) * DAY - 13 * i, masks[i % len(masks)]) for i in range(nq)]
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.set_ordered_run(2)
+        ctx.scan(t0 - 6 * HOUR, t0 - 61 * DAY)                                   # builds the run
+        assert ctx.table_info()["ordered_builds"] == 1
+        variants = [base]
+        if nq >= 5:
+            mid = list(base)
+            mid[1] = (t0 - 100 * DAY, t0 - 61 * DAY, ALL)                          # dense: leaves the batch, runs as a single scan
+            mid[2] = (2 ** 62, INT64_MIN, ALL)                                     # nothing is live
+            mid[3] = (t0 - 9 * DAY, INT64_MIN, 0xFF)                               # below the 1-byte key's base: the 2-byte stream
+            variants.append(mid)
+        for vi, qs in enumerate(variants):
+            ctx.scan_batch_begin(qs)
+            ms = ctx.scan_batch_finish()
+            assert ctx.stats()["k1_variant"] & 0x3000 == 0x3000            # a batch, on the ordered run
+            for qi, (now, cutoff, mask) in enumerate(qs):
+                w = oracle.scan(s, e, u, d, U, now, cutoff, mask & lim)
+                assert ms[qi] == w[2].size, (vi, qi)
+                assert_same(ctx.batch_read_results(qi), w, f"variant {vi} q{qi}")
+                for uu in (0, 7 % U, U - 1):
+                    assert np.array_equal(ctx.batch_read_user_feed(qi, uu), w[2][w[1][uu]:w[1][uu + 1]])
+
+
+def test_ordered_batch_pipelined_with_messages_and_changes(pie, oracle):
+    """two batches in flight; per-query messages packed from the ordered batch; touches and in-order appends between batches"""
+    import torch
+    n, U, D = 300000, 900, 16
+    t0 = oracle.T0_MS
+    s, e, u, d = skewed_table(oracle, n, U, D, SEED + 99)
+    lim = (1 << D) - 1
+    u_pad, cap = U + 5, 60000
+    stride = u_pad + 2 + cap
+    rng = np.random.default_rng(8)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.set_ordered_run(2)
+        ctx.scan(t0 - 6 * HOUR, t0 - 61 * DAY)
+        batches = [[(t0 - 6 * HOUR - 1000 * (3 * b + i), t0 - (61 + i) * DAY, ALL if i % 2 else 0x0F0F) for i in range(4 + b)] for b in range(4)]
+        ctx.scan_batch_begin(batches[0])
+        for k in range(len(batches)):
+            if k + 1 < len(batches):
+                ctx.scan_batch_begin(batches[k + 1])
+            ms = ctx.scan_batch_finish()
+            for qi, (now, cutoff, mask) in enumerate(batches[k]):
+                w = oracle.scan(s, e, u, d, U, now, cutoff, mask & lim)
+                assert ms[qi] == w[2].size
+                assert_same(ctx.batch_read_results(qi), w, f"pipelined batch {k} q{qi}")
+        # messages
+        msg = torch.full((4 * stride,), -7, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        qs = batches[1][:4]
+        ctx.scan_batch_begin_packed(qs, msg.data_ptr(), stride, u_pad, cap)
+        ms, _ready = ctx.scan_batch_finish(packed=True)
+        ctx.synchronize()
+        got = msg.cpu().numpy()
+        for qi, (now, cutoff, mask) in enumerate(qs):
+            w = oracle.scan(s, e, u, d, U, now, cutoff, mask & lim)
+            m = w[2].size
+            a = got[qi * stride:(qi + 1) * stride]
+            assert ms[qi] == m and np.array_equal(a[: U + 1], w[1].astype(np.int32)) and np.all(a[U + 1: u_pad + 2] == m)
+            assert np.array_equal(a[u_pad + 2: u_pad + 2 + m], w[2])
+        # the table changes between batches: touches, deletes, in-order appends (the first append re-allocates: one rebuild)
+        now = t0 + HOUR
+        for step in range(4):
+            rows = rng.choice(s.size, 500, replace=False).astype(np.int32)
+            ne = np.where(rng.random(500) < 0.2, INT64_MIN, now + rng.integers(0, 12 * HOUR, 500)).astype(np.int64)
+            ctx.set_end(rows, ne)
+            e[rows] = ne
+            k = 300
+            s2 = np.sort(now + rng.integers(0, 2000, k)).astype(np.int64)
+            u2 = np.where(rng.random(k) < 0.4, 7, rng.integers(0, U, k)).astype(np.int32)
+            d2 = rng.integers(0, D, k).astype(np.int32)
+            ctx.append_rows(s2, s2 + 12 * HOUR, u2, d2, U)
+            s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + 12 * HOUR]), np.concatenate([u, u2]), np.concatenate([d, d2])
+            now = int(s2[-1]) + 1
+            qs = [(now + 1000 * i, t0 - (61 + i) * DAY, ALL) for i in range(6)]
+            got = ctx.scan_batch(qs)
+            for qi, (nw, ct, mk) in enumerate(qs):
+                assert_same(got[qi], oracle.scan(s, e, u, d, U, nw, ct, mk & lim), f"changed step {step} q{qi}")
