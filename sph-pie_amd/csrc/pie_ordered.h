@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void k_ord_scan_dense(const OrdRec* __restrict
 
 // ------------------------------------------------------------------------------------------------ keyed (sparse) form
 
-// KT = fkey_t: 1024 positions per chunk (16 per lane); KT = lkey_t: 512 (8 per lane).  The key arrays are padded with zero
-// keys to a whole number of chunks; a padding position can only become a candidate when key(now) == 0, and is dropped
+// A chunk is 512 positions for both key widths (8 keys per lane: one 8-byte or one 16-byte load).  The key arrays are padded
+// with zero keys to a whole number of chunks; a padding position can only become a candidate when key(now) == 0, and is dropped
 // when its batch is formed (pos >= n_ord).
 template <class KT>
 __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict
                                                         unsigned int* __restrict__ stage, int* __restrict__ unit_count,
                                                         Summary* __restrict__ summary)
 {
-    constexpr int kPerLane = 16 / (int)sizeof(KT);
+    constexpr int kPerLane = 8; // 512 positions per chunk for both key widths: the candidate ring stays at 4 KiB per wave
     constexpr int kChunk = kPerLane * kWave;
-    constexpr int kChunkShift = sizeof(KT) == 1 ? 10 : 9;
+    constexpr int kChunkShift = 9;
     constexpr int kRing = 2 * kChunk;
     constexpr int kUnroll = 4;
     __shared__ int ring_s[4][kRing];
@@ -377,14 +377,21 @@ __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict
         for (int j = 0; j < kUnroll; ++j) {
             const long long ch = cb + (long long)j * W;
             kv[j] = (u4_t){0u, 0u, 0u, 0u};
-            if (ch < n_chunks) kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+            if (ch < n_chunks) {
+                if constexpr (sizeof(KT) == 1) {
+                    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+                    const u2_t h = __builtin_nontemporal_load(reinterpret_cast<const u2_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+                    kv[j].x = h.x;
+                    kv[j].y = h.y;
+                } else kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+            }
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
             const long long ch = cb + (long long)j * W;
             if (ch >= n_chunks) continue; // wave-uniform
             const unsigned ge = row_bits(((kv[j].x | kTop) - nk_ge) & kTop, ((kv[j].y | kTop) - nk_ge) & kTop,
-                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop);
+                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop) & 0xFFu; // 8 rows per lane
             const unsigned gt = row_bits(((kv[j].x | kTop) - nk_gt) & kTop, ((kv[j].y | kTop) - nk_gt) & kTop,
                                          ((kv[j].z | kTop) - nk_gt) & kTop, ((kv[j].w | kTop) - nk_gt) & kTop);
             const int cnt = __popc(ge);
@@ -447,7 +454,6 @@ __global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit
     unit_local += (long long)blockIdx.y * unit_stride;
     group_sum += (long long)blockIdx.y * group_stride;
     group_base += (long long)blockIdx.y * group_stride;
-    ctl += blockIdx.y;
     summary = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)blockIdx.y * sum_stride_bytes);
     const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
     for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -473,6 +479,8 @@ __global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit
         if (threadIdx.x == 0) group_sum[g] = total;
         __syncthreads();
     }
+    if (ctl == nullptr) return; // two-kernel form (batches: thousands of blocks, a fence each would cost more than a launch)
+    ctl += blockIdx.y;
     if (threadIdx.x == 0) {
         __threadfence();
         is_last = atomicAdd(&ctl->done_prefix, 1u) == gridDim.x - 1;
@@ -502,6 +510,41 @@ __global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit
         group_base[n_groups] = carry;
         summary->m = (unsigned long long)carry;
         ctl->done_prefix = 0;
+    }
+}
+
+// second kernel of the two-kernel form: block q scans query q's group sums
+__global__ __launch_bounds__(256) void k_ord_prefix_groups(long long n_units, const long long* __restrict__ group_sum,
+                                                           long long* __restrict__ group_base, Summary* __restrict__ summary,
+                                                           long long group_stride, long long sum_stride_bytes)
+{
+    __shared__ long long wsum64[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    group_sum += (long long)blockIdx.x * group_stride;
+    group_base += (long long)blockIdx.x * group_stride;
+    summary = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)blockIdx.x * sum_stride_bytes);
+    const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
+    long long carry = 0;
+    for (long long g0 = 0; g0 < n_groups; g0 += 256) {
+        const long long g = g0 + threadIdx.x;
+        const long long v = g < n_groups ? group_sum[g] : 0;
+        const long long incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum64[wave] = incl;
+        __syncthreads();
+        long long wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const long long sw = wsum64[w];
+            if (w < wave) wbase += sw;
+            total += sw;
+        }
+        if (g < n_groups) group_base[g] = carry + wbase + incl - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        group_base[n_groups] = carry;
+        summary->m = (unsigned long long)carry;
     }
 }
 
@@ -674,15 +717,18 @@ struct alignas(8) OrdUnion {
     unsigned qmask;
 };
 
+// A chunk is 512 positions for both key widths: 8 one-byte keys (one 8-byte load) or 8 two-byte keys (one 16-byte load) per
+// lane.  The candidate ring then takes 5 / 6 KiB per wave instead of 10, and two to three times as many waves fit a CU —
+// the pass is latency-bound (34 chunks and a handful of candidate batches per wave), so that is what counts: 141 -> 9x us.
 template <class KT>
 __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
                                                         const KT* __restrict__ key, long long n_ord, long long n_chunks, OrdBatchArgs a,
                                                         OrdUnion* __restrict__ ustage, int* __restrict__ ucount,
                                                         Summary* __restrict__ summary)
 {
-    constexpr int kPerLane = 16 / (int)sizeof(KT);
+    constexpr int kPerLane = 8;
     constexpr int kChunk = kPerLane * kWave;
-    constexpr int kChunkShift = sizeof(KT) == 1 ? 10 : 9;
+    constexpr int kChunkShift = 9;
     constexpr int kRing = 2 * kChunk;
     constexpr int kUnroll = 4;
     __shared__ int ring_s[4][kRing];
@@ -789,14 +835,21 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
         for (int j = 0; j < kUnroll; ++j) {
             const long long ch = cb + (long long)j * W;
             kv[j] = (u4_t){0u, 0u, 0u, 0u};
-            if (ch < n_chunks) kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+            if (ch < n_chunks) {
+                if constexpr (sizeof(KT) == 1) {
+                    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+                    const u2_t h = __builtin_nontemporal_load(reinterpret_cast<const u2_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+                    kv[j].x = h.x;
+                    kv[j].y = h.y;
+                } else kv[j] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(key + (ch << kChunkShift) + kPerLane * lane));
+            }
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
             const long long ch = cb + (long long)j * W;
             if (ch >= n_chunks) continue;
             const unsigned ge = row_bits(((kv[j].x | kTop) - nk_ge) & kTop, ((kv[j].y | kTop) - nk_ge) & kTop,
-                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop);
+                                         ((kv[j].z | kTop) - nk_ge) & kTop, ((kv[j].w | kTop) - nk_ge) & kTop) & 0xFFu; // 8 rows per lane
             const int cnt = __popc(ge);
             const int incl = wave_incl_scan_i32(cnt, lane);
             const int total = __shfl(incl, 63, kWave);
@@ -883,9 +936,8 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
         for (long long ch = (long long)blockIdx.x * 4 + wave; ch < n_chunks; ch += (long long)copy_blocks * 4) {
             const int cnt = ucount[ch];
             if (cnt == 0) continue; // wave-uniform
-            int running[kBatchMax];
-#pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) running[q] = 0;
+            long long next = 0; // lane q < n_q: where query q's next row of this chunk goes (one load pair per lane, not 16 per wave)
+            if (lane < n_q) next = group_base[(long long)lane * group_stride + (ch >> kOrdGroupShift)] + unit_local[(long long)lane * unit_stride + ch];
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 OrdUnion r;
                 r.pos = 0; r.qmask = 0;
@@ -900,12 +952,12 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
                     const bool sel = (r.qmask >> q) & 1u;
                     const unsigned long long b = __ballot(sel);
                     if (b == 0) continue;
+                    const long long base_q = __shfl(next, q, kWave);
                     if (sel) {
-                        const long long at = group_base[(long long)q * group_stride + (ch >> kOrdGroupShift)] +
-                                             unit_local[(long long)q * unit_stride + ch] + running[q] + prefix_in_ballot(b);
+                        const long long at = base_q + prefix_in_ballot(b);
                         if (at < out_stride) out_idx[(long long)q * out_stride + at] = row; // a list beyond the batch's row capacity is rerun
                     }
-                    running[q] += __popcll(b);
+                    if (lane == q) next += __popcll(b);
                 }
             }
         }
@@ -917,20 +969,55 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
     for (int q = 0; q < kBatchMax; ++q) below[q] = 0;
     long long ch = -1;
     bool at_end = true;
+    int jb = 0; // records of my chunk that lie before my segment start (staged in position order: a binary search)
     if (u <= n_users) {
         const long long qpos = uoff[u];
         at_end = qpos >= n_ord;
         if (!at_end) {
             ch = qpos >> chunk_shift;
-            const int cnt = ucount[ch];
             const OrdUnion* rec = ustage + (ch << chunk_shift);
-            for (int j = 0; j < cnt; ++j) {
-                const OrdUnion r = rec[j];
-                if (r.pos >= (unsigned)qpos) break; // staged in position order
+            int lo = 0, hi = ucount[ch];
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rec[mid].pos < (unsigned)qpos) lo = mid + 1;
+                else hi = mid;
+            }
+            jb = lo;
+        }
+    }
+    // A user who follows a popular one starts inside a chunk full of that user's live rows: up to 1023 records to count.
+    // A few records a lane counts itself; a long stretch is counted by the whole wave, one such lane at a time.
+    const bool heavy = jb > 16;
+    if (!heavy && jb > 0) {
+        const OrdUnion* rec = ustage + (ch << chunk_shift);
+        for (int j = 0; j < jb; ++j) {
+            const unsigned qm = rec[j].qmask;
 #pragma unroll
-                for (int q = 0; q < kBatchMax; ++q) below[q] += (r.qmask >> q) & 1u;
+            for (int q = 0; q < kBatchMax; ++q) below[q] += (qm >> q) & 1u;
+        }
+    }
+    unsigned long long todo = __ballot(heavy);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const long long lch = __shfl(ch, leader, kWave);
+        const int ljb = __shfl(jb, leader, kWave);
+        const OrdUnion* lrec = ustage + (lch << chunk_shift);
+        int tot[kBatchMax];
+#pragma unroll
+        for (int q = 0; q < kBatchMax; ++q) tot[q] = 0;
+        for (int j0 = 0; j0 < ljb; j0 += 64) {
+            const unsigned qm = j0 + lane < ljb ? lrec[j0 + lane].qmask : 0u;
+#pragma unroll
+            for (int q = 0; q < kBatchMax; ++q) {
+                if (q >= n_q) break;
+                tot[q] += __popcll(__ballot((qm >> q) & 1u));
             }
         }
+        if (lane == leader) {
+#pragma unroll
+            for (int q = 0; q < kBatchMax; ++q) below[q] = tot[q];
+        }
+        todo &= todo - 1;
     }
     for (int q = 0; q < n_q; ++q) {
         long long my = 0;

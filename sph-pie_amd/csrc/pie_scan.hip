@@ -1218,7 +1218,7 @@ bool ordered_batch_wanted(const pie_ctx* c)
     return (padded + kOrdTile) * sizeof(OrdUnion) <= (size_t)c->sel_cap * sizeof(SelRec);
 }
 
-// five launches: key stream -> union records; per-query chunk counts; per-query prefix; row lists + offsets; summaries
+// six launches: key stream -> union records; per-query chunk counts; per-query prefix (two kernels); row lists + offsets; summaries
 void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
 {
     OrderedRun& o = c->ord;
@@ -1241,12 +1241,12 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
         if (a.q[q].now_key < mk) mk = a.q[q].now_key;
     }
     a.min_key = mk;
-    const int chunk_shift = fine ? 10 : 9;
+    const int chunk_shift = 9; // 512 positions per chunk for both key widths (see k_ord_batch_scan)
     const long long n_chunks = (o.n + (1 << chunk_shift) - 1) >> chunk_shift;
     const long long units_stride = o.units_cap, group_stride = o.units_cap / 1024 + 2, sum_stride = (long long)ord_sum_bytes();
     Summary* sum0 = reinterpret_cast<Summary*>(sums);
     if (fine) {
-        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 3 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 3;
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 7 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 7;
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
     } else {
@@ -1259,8 +1259,9 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
     long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
     if (n_groups < 1) n_groups = 1;
     const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
-    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)b.n_q), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase, o.bq_ctl,
-                       sum0, units_stride, group_stride, sum_stride);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)b.n_q), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase,
+                       (OrdCtl*)nullptr, sum0, units_stride, group_stride, sum_stride);
+    hipLaunchKernelGGL(k_ord_prefix_groups, dim3((unsigned)b.n_q), dim3(256), 0, s, n_chunks, o.bq_gsum, o.bq_gbase, sum0, group_stride, sum_stride);
     const int copy_blocks = c->n_cus * 8;
     const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
     hipLaunchKernelGGL(k_ord_batch_emit, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks,
@@ -1316,9 +1317,9 @@ void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long lon
                            cutoff, mask, stage, uc, o.tile_ballot, o.tile_prefix, sum);
         sl.variant = 0x2003;
     } else if (fine) {
-        unit_shift = 10;
-        n_units = (o.n + 1023) >> 10;
-        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * 5 ? (n_units + 3) / 4 : (long long)c->n_cus * 5;
+        unit_shift = 9;
+        n_units = (o.n + 511) >> 9;
+        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * 8 ? (n_units + 3) / 4 : (long long)c->n_cus * 8;
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
                            host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
