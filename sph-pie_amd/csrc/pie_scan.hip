@@ -1996,30 +1996,6 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         }
     }
     b.fine_key = fine;
-    if (ord_batch) {
-        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for all queries
-        rc = ord_batch_alloc(c);
-        if (rc) return rc;
-        BatchSlot& prev = c->bslot[c->b_next ^ 1];
-        if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
-        b.seq = ++c->bseq_counter;
-        c->scans_begun++;
-        launch_ordered_batch(c, b, s, qs, fine);
-        PIE_HIP(c, hipGetLastError());
-        b.ordered = true;
-        b.k2_pending = false;
-        b.in_flight = true;
-        c->b_flight++;
-        c->b_next ^= 1;
-        return PIE_OK;
-    }
-    // spans: this batch's set and the one its K2 zeroes
-    b.span = c->bspan[c->bspan_next];
-    c->bspan_next = (c->bspan_next + 1) % 3;
-    b.zero_span = c->bspan[(c->bspan_next + 1) % 3];
-    b.seq = ++c->bseq_counter;
-    const int plan = fine ? 3 : 2;
-    b.k1_blocks = c->plan_blocks[plan];
     if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
         if (c->ring_used == kEventRing) {
             rc = resolve_events(c);
@@ -2036,6 +2012,31 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
             b.ev_index = c->ring_used++;
         }
     }
+    if (ord_batch) {
+        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for all queries
+        rc = ord_batch_alloc(c);
+        if (rc) return rc;
+        BatchSlot& prev = c->bslot[c->b_next ^ 1];
+        if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
+        b.seq = ++c->bseq_counter;
+        c->scans_begun++;
+        if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
+        launch_ordered_batch(c, b, s, qs, fine);
+        PIE_HIP(c, hipGetLastError());
+        b.ordered = true;
+        b.k2_pending = false;
+        b.in_flight = true;
+        c->b_flight++;
+        c->b_next ^= 1;
+        return PIE_OK;
+    }
+    // spans: this batch's set and the one its K2 zeroes
+    b.span = c->bspan[c->bspan_next];
+    c->bspan_next = (c->bspan_next + 1) % 3;
+    b.zero_span = c->bspan[(c->bspan_next + 1) % 3];
+    b.seq = ++c->bseq_counter;
+    const int plan = fine ? 3 : 2;
+    b.k1_blocks = c->plan_blocks[plan];
     c->scans_begun++;
     BatchSlot& other = c->bslot[c->b_next ^ 1];
     const bool ride = c->b_flight == 1 && other.in_flight && other.k2_pending && !c->no_ride;
