@@ -3,7 +3,7 @@
 profiles/traffic.json (HBM bytes per launch of every table-pass kernel the command ran), which bench.py quotes as
 roofline.traffic for the kernel it timed.
 
-usage: tools/pmc_traffic.py <gpurun_out dir> <tag>
+usage: tools/pmc_traffic.py <gpurun_out dir> <tag> [traffic file name, default traffic.json] [workload description]
 
 gfx950 corrections (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
 FETCH_SIZE counts 128-B read requests at 64 B, so read bytes = 2 x FETCH_SIZE x 1024.  Cross-check kept beside it:
@@ -21,13 +21,15 @@ import sys
 def summarise(path):
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("void pie::", "").strip()
+        name = r["Kernel_Name"].split("(")[0].replace("void pie::", "").replace("pie::", "").strip()
         acc.setdefault((name, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     return acc
 
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    out_name = sys.argv[3] if len(sys.argv) > 3 else "traffic.json"
+    workload = sys.argv[4] if len(sys.argv) > 4 else "bench.py default: 1e8 sessions / 1e5 users / 32 disciplines, random order, auth variant, spec query"
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     per = collections.OrderedDict()   # kernel -> counter -> (dispatches, mean)
     for kind in ("fetch", "write", "rdreq"):
@@ -40,7 +42,7 @@ def main():
             w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max"])
             for (k, c), v in acc.items():
                 w.writerow([k, c, len(v), sum(v) / len(v), min(v), max(v)])
-                if k.startswith("k_scan_") or k.startswith("k_expired_stage"):
+                if k.startswith("k_scan_") or k.startswith("k_expired_stage") or k.startswith("k_ord_"):
                     per.setdefault(k, {})[c] = (len(v), sum(v) / len(v))
     stats = glob.glob(os.path.join(root, "%s_stats" % tag, "*", "*kernel_stats.csv"))
     avg_ns = {}
@@ -49,7 +51,7 @@ def main():
             text = f.read()
             g.write(text)
         for r in csv.DictReader(open(stats[0])):
-            avg_ns[r["Name"].split("(")[0].replace("void pie::", "").strip()] = (int(r["Calls"]), float(r["AverageNs"]))
+            avg_ns[r["Name"].split("(")[0].replace("void pie::", "").replace("pie::", "").strip()] = (int(r["Calls"]), float(r["AverageNs"]))
     kernels = collections.OrderedDict()
     for k, c in per.items():
         if "FETCH_SIZE" not in c:
@@ -68,13 +70,13 @@ def main():
     out = {
         "source": "profiles/%s_{fetch,write,rdreq}.summary.csv + profiles/%s_kernel_stats.csv (tools/run_pmc.sh %s)" % (tag, tag, tag),
         "tag": tag,
-        "workload": "bench.py default: 1e8 sessions / 1e5 users / 32 disciplines, random order, auth variant, spec query",
+        "workload": workload,
         "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum (separate passes, --kernel-trace only); read = 2 x "
                   "FETCH_SIZE KiB (gfx950 half-count of 128-B requests), write = WRITE_SIZE KiB; kernel time from a separate "
                   "--kernel-trace --stats run of the same command",
         "kernels": kernels,
     }
-    with open(os.path.join(out_dir, "traffic.json"), "w") as f:
+    with open(os.path.join(out_dir, out_name), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): PMC passes for the scan kernels, each in its own rocprofv3 run (counters only with
 # --kernel-trace, as the pool requires), then a kernel-trace --stats run of the same command.  The command is bench.py's
 # default workload, so one set of passes covers the headline kernel AND the every-byte form of roofline_full_read.
-# usage: tools/run_pmc.sh <tag> [extra bench.py flags]    -> gpurun_out/<tag>_{fetch,write,rdreq,stats}/... + profiles/traffic.json
+# usage: [TRAFFIC_OUT=traffic_x.json TRAFFIC_WORKLOAD="..."] tools/run_pmc.sh <tag> [extra bench.py flags]    -> gpurun_out/<tag>_{fetch,write,rdreq,stats}/... + profiles/traffic.json
 set -o pipefail
 tag=${1:-pmc}
 shift
@@ -12,4 +12,4 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_write -- $cmd > gpurun_out/${tag}_write.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d gpurun_out/${tag}_rdreq -- $cmd > gpurun_out/${tag}_rdreq.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 30 --warmup 5 --repeat 2 --no-cpu-baseline $* > gpurun_out/${tag}_stats.log 2>&1 &&
-python3 tools/pmc_traffic.py gpurun_out ${tag}
+python3 tools/pmc_traffic.py gpurun_out ${tag} ${TRAFFIC_OUT:-traffic.json} "${TRAFFIC_WORKLOAD:-bench.py default: 1e8 sessions / 1e5 users / 32 disciplines, random order, auth variant, spec query}"
