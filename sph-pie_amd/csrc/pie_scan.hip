@@ -2338,6 +2338,7 @@ int pie_ctx_destroy(pie_ctx* c)
     for (BatchSlot& b : c->bslot) {
         if (b.h_sum) (void)hipHostFree(b.h_sum);
     }
+    if (c->ord.h_stale) (void)hipHostFree(c->ord.h_stale);
     if (c->d_summary) (void)hipFree(c->d_summary);
     if (c->d_range) (void)hipFree(c->d_range);
     if (c->d_hist) (void)hipFree(c->d_hist);
