@@ -55,23 +55,26 @@ struct OrdCtl {
 // slots (see k_ord_append).
 __global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx, long long m, const long long* __restrict__ off,
                                                     const long long* __restrict__ uoff, const PayRec* __restrict__ pay,
-                                                    const long long* __restrict__ end, const lkey_t* __restrict__ key,
-                                                    const fkey_t* __restrict__ fkey, OrdRec* __restrict__ o_pay,
+                                                    const long long* __restrict__ end, long long key_base, int key_shift,
+                                                    long long fkey_base, int fkey_shift, OrdRec* __restrict__ o_pay,
                                                     long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
                                                     fkey_t* __restrict__ o_fkey, int* __restrict__ pos)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
         const int r = idx[i];
         const PayRec p = pay[r];
+        const long long ev = end[r];
         const long long at = uoff[p.user] + (i - off[p.user]);
         OrdRec o;
         o.start = p.start;
         o.row = r;
         o.disc = p.disc;
         o_pay[at] = o;
-        o_end[at] = end[r];
-        o_key[at] = key[r];
-        o_fkey[at] = fkey[r];
+        o_end[at] = ev;
+        // the keys are a function of `end` and the table's key parameters: computed, not gathered (each gather of a scattered
+        // row costs a 128-byte fetch whatever it reads: two of them instead of four)
+        o_key[at] = (lkey_t)key_of(ev, key_base, key_shift);
+        o_fkey[at] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
         pos[r] = (int)at;
     }
 }

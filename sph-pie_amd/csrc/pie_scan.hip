@@ -1045,7 +1045,12 @@ int build_ordered(pie_ctx* c)
     c->key_poor = k.key_poor; c->fkey_poor = k.fkey_poor; c->live_frac = k.live_frac; c->last_m = k.last_m; c->hot = k.hot;
     c->hot_seen = k.hot_seen; c->hot_age = k.hot_age; c->last_was_batch = k.last_was_batch; c->run_shift = k.run_shift;
     c->bdshift_want = k.bdshift_want; c->batch_poor = k.batch_poor;
-    if (rc) return rc;
+    if (rc) { // the caller's last result and slot order are as they were; the failed scan left nothing in flight of its own
+        built->have_result = false;
+        c->res = (k.res && k.res != built) ? k.res : nullptr;
+        c->next_slot = k.next_slot;
+        return rc;
+    }
     const long long m = (long long)built->last.m;
     // segments: user u's rows, then spare slots for the rows to come (k_ord_append); users that do not exist yet get four
     const int seg_users = c->cap_users;
@@ -1076,7 +1081,7 @@ int build_ordered(pie_ctx* c)
     PIE_HIP(c, hipMemsetAsync(o.sum[1], 0, ord_sum_bytes(), s));
     if (m > 0) {
         hipLaunchKernelGGL(k_ord_gather, dim3(c->n_cus * 16), dim3(256), 0, s, built->out_idx, m, built->offsets, o.uoff, c->d_pay, c->d_end,
-                           c->d_key, c->d_fkey, o.pay, o.end, o.key, o.fkey, o.pos);
+                           c->key_base, c->key_shift, c->fkey_base, c->fkey_shift, o.pay, o.end, o.key, o.fkey, o.pos);
         PIE_HIP(c, hipGetLastError());
     }
     PIE_HIP(c, hipStreamSynchronize(s));

@@ -790,7 +790,7 @@ def test_config4_user_hash_shards_reassemble(pie, gpu_ctx, oracle):
     assert seen_users == U and wi.size > U
 
 
-def test_full_size_properties_1e8(gpu_ctx, oracle):
+def test_full_size_properties_1e8(gpu_ctx, oracle, request):
     """BASELINE config 3 (10^8 / 10^5 / 32): properties that need no full-size oracle run, plus an exact
     oracle comparison on the selected rows only."""
     n, U, D = 10 ** 8, 10 ** 5, 32
@@ -850,3 +850,26 @@ def test_full_size_properties_1e8(gpu_ctx, oracle):
     assert np.unique(grp[heads]).size == heads.size                           # each group is one contiguous run
     assert np.all(np.diff(first[grp[heads]]) > 0)                             # groups in order of first appearance
     assert np.all((np.diff(q_arch) > 0) | (np.diff(grp) != 0))                # table order inside a group
+    # the ordered run at full size (sph-pie_amd/csrc/pie_ordered.h): the spec query (keyed form), a query that selects a
+    # quarter of the table (dense form: 2.5 x 10^7 rows out) and the 16-query batch, each exact against the oracle
+    gpu_ctx.set_ordered_run(2)
+    request.addfinalizer(lambda: gpu_ctx.set_ordered_run(1))
+    gpu_ctx.set_disciplines(mask, D)
+    c3, o3, i3 = gpu_ctx.scan(now, cutoff)
+    assert gpu_ctx.stats()["k1_variant"] & 0x2400 == 0x2400
+    assert np.array_equal(c3, wc) and np.array_equal(o3, wo) and np.array_equal(i3, wi)
+    wide_now = oracle.T0_MS - 100 * DAY
+    c4, o4, i4 = gpu_ctx.scan(wide_now, cutoff)
+    assert gpu_ctx.stats()["k1_variant"] == 0x2003
+    w4 = oracle.scan_mt(*cols, U, wide_now, cutoff, mask & ((1 << D) - 1), 16)
+    assert i4.size == w4[2].size and i4.size > n // 5
+    assert np.array_equal(c4, w4[0]) and np.array_equal(o4, w4[1]) and np.array_equal(i4, w4[2])
+    del w4, i4
+    gpu_ctx.set_disciplines(ALL, D)
+    got_run = gpu_ctx.scan_batch(queries)
+    assert gpu_ctx.stats()["k1_variant"] & 0x3000 == 0x3000
+    for q in range(len(queries)):
+        for a, b in zip(got_run[q], got[q]):                                  # `got` was checked against the oracle above
+            assert np.array_equal(a, b), q
+    info = gpu_ctx.table_info()
+    assert info["ordered_builds"] >= 1 and info["ordered_rows"] == n
