@@ -11,7 +11,8 @@
 // in position order, ARE the answer (idx = their row ids, offsets[u] = selected positions before uoff[u]).  No atomics,
 // no sort, no dependence on how the rows are spread over the users; every kernel below is a straight pass:
 //
-//   k_ord_scan_dense    every position: 2-byte key + 16-byte record (18 B/row, `end` only for ambiguous keys); per 4096-position
+//   k_ord_scan_dense    every position's 2-byte key; the 16-byte record of every 64-position slice that holds a row that may be
+//                       live (`end` only for ambiguous keys): at most 18 B/row, less the more rows are dead; per 4096-position
 //                       tile the selected row ids go to the staging array in order, with the tile's count and its 64 slice
 //                       ballots / prefixes (what a rank lookup needs)
 //   k_ord_scan_keyed    the sparse form: streams only the key column (1 or 2 B/row), candidates of a chunk queue up IN POSITION
@@ -204,17 +205,25 @@ __global__ __launch_bounds__(256) void k_ord_scan_dense(const OrdRec* __restrict
         int running = 0;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
-            OrdRec r[8];
+            // keys first (2 B per position), records only for the 64-position slices that hold a row that may be live: in run
+            // order a user's rows ascend in start — and with it in end — so the rows a query finds dead are long stretches
+            // at the head of every segment, and their 16-byte records are never fetched
             unsigned k[8];
+            unsigned long long may[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const long long p = w0 + (h * 8 + j) * 64 + lane;
-                k[j] = 0;
+                k[j] = p < n_ord ? (unsigned)__builtin_nontemporal_load(key + p) : 0u;
+            }
+            OrdRec r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long p = w0 + (h * 8 + j) * 64 + lane;
+                may[j] = __ballot(p < n_ord && k[j] >= now_key);
                 r[j].start = 0;
                 r[j].row = 0;
                 r[j].disc = -1;
-                if (p < n_ord) {
-                    k[j] = __builtin_nontemporal_load(key + p);
+                if (may[j] != 0 && p < n_ord) { // wave-uniform test first: a dead slice costs no load at all
                     const ll2_t raw = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(pay + p));
                     r[j].start = raw.x;
                     r[j].row = (int)(raw.y & 0xFFFFFFFFll);
@@ -224,6 +233,10 @@ __global__ __launch_bounds__(256) void k_ord_scan_dense(const OrdRec* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const long long p = w0 + (h * 8 + j) * 64 + lane;
+                if (may[j] == 0) { // nothing of this slice can be selected
+                    if (lane == 0) sball[wave * 16 + h * 8 + j] = 0ull;
+                    continue;
+                }
                 const bool valid = p < n_ord;
                 const bool amb = valid && k[j] == now_key;
                 bool live = valid && k[j] > now_key;
