@@ -257,9 +257,10 @@ int pie_table_info_get(pie_ctx *ctx, pie_table_info *out);
  * server/sessionStore.js:55-73); results are identical to the general path's.  mode 0: never (frees it); 1 (default):
  * built and used when the general path is weak — a query selecting more than 1/24 of the rows, or skewed users — the second
  * time in a row such a query arrives; 2: always (built at the next scan).  Touches and deletes keep it in step, and so do
- * appends in time order (a session store's createSession: the new row goes into a spare slot at the end of its user's
- * segment); loads, sharding, a full segment or an out-of-order append invalidate it (queries run on the general path until
- * it is rebuilt).  PIE_ORDERED=0|1|2 sets the mode a context starts with. */
+ * appends: a new row is inserted at its place in its user's segment, which ends in spare slots — for a session store's
+ * createSession that place is the end; a row a little late shifts the few behind it; a full segment moves the run into
+ * fresh segments (a linear pass).  Loads, sharding and back-fills (a row more than 256 rows back in its segment) invalidate
+ * it (queries run on the general path until it is rebuilt).  PIE_ORDERED=0|1|2 sets the mode a context starts with. */
 int pie_set_ordered_run(pie_ctx *ctx, int mode);
 /* 0: off.  n >= 1: every n-th scan carries HIP events around K1 and around the whole scan (an event between two
  * kernels costs a few microseconds of pipeline drain, so a benchmark samples). */

@@ -29,9 +29,10 @@
 // finishes last does X" is a counter, not a wait).
 //
 // Writers of `end` (touch, delete, purge) mirror their store into o_end / the keys through pos[] (OrdMirror in
-// pie_kernels.h).  Appends in time order (a session store's: createdAt = now) go into spare slots at the end of their
-// user's segment (k_ord_append).  A load, a re-shard, a full segment or an out-of-order append invalidates the run and the
-// host falls back to the general path until it is rebuilt.
+// pie_kernels.h).  Appends are inserted at their place in their user's segment, which ends in spare slots (k_ord_append: a
+// session store's rows arrive in time order, i.e. at the end; a late row shifts the few behind it).  A load, a re-shard or a
+// row that arrives far out of order (a back-fill) invalidates the run and the host falls back to the general path until it
+// is rebuilt; a full segment is handled by a re-spread.
 #pragma once
 
 namespace pie {
@@ -81,77 +82,112 @@ __global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx,
 }
 
 // createSession on a table that has a run.  A user's segment ends in spare slots (a sixteenth of its rows + 16, filler records:
-// key 0, discipline -1, never selected).  A session store appends in time order — createdAt = now — so a new row of user u
-// belongs right behind u's last row: row t of the batch takes slot ufill[u] + (rows of u earlier in the batch), provided
-// its start is not below the start of the row before it in the segment (equal starts are in row order by construction: the
-// new row has the larger row id).  O(batch) work per row of the batch, nothing per row of the table.
+// key 0, discipline -1, never selected).  A new row of user u is INSERTED into u's segment at its place in (start, row)
+// order — behind every row whose start is not above its own: the new row has the largest row id.  A session store creates
+// sessions now, so that place is almost always the end of the segment (one compare); a row that arrives a little late
+// (clock jitter between front-ends, a batch that is not sorted, a corpus whose last sessions lie "after now") shifts the
+// few rows behind it by one slot.  All rows of one user in a batch are handled by ONE thread — the one whose row is the
+// user's first in the batch — in batch order, so rows of the same user never race; different users are different threads.
+// O(batch) + the shifts per row of the batch, nothing per row of the table.
 //   placed[t] = pass   the row went into the run in this pass
-//   stale[0]++         the row arrived out of time order: the run no longer describes the table (host: drop it)
-//   stale[1]++         its user's segment is full (host: k_ord_respread gives every segment fresh spare slots, then pass 2
-//                      places the rows left over)
+//   stale[0]++         the row would have to move more than kOrdShiftMax rows (a back-fill, not a session store's append):
+//                      the host drops the run
+//   stale[1]++, pend[u]++   its user's segment is full: the host re-spreads (k_ord_respread gives every segment fresh spare
+//                      slots), then pass 2 places the rows left over
 // stale[] is mapped host memory, read by the host after the append's one synchronisation.
+constexpr int kOrdShiftMax = 256;
+
 __global__ __launch_bounds__(256) void k_ord_append(const long long* __restrict__ st_start, const long long* __restrict__ st_end,
                                                     const int* __restrict__ st_user, const int* __restrict__ st_disc, int k,
                                                     long long row0, int n_users, long long key_base, int key_shift, long long fkey_base,
-                                                    int fkey_shift, const long long* __restrict__ uoff, const int* __restrict__ ufill,
+                                                    int fkey_shift, const long long* __restrict__ uoff, int* __restrict__ ufill,
                                                     OrdRec* __restrict__ o_pay, long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
                                                     fkey_t* __restrict__ o_fkey, int* __restrict__ pos, unsigned int* __restrict__ stale,
-                                                    const int* __restrict__ placed_in, int* __restrict__ placed, int pass)
+                                                    const int* __restrict__ placed_in, int* __restrict__ placed, int* __restrict__ pend, int pass)
 {
-    // the users of the batch's rows up to this block's last one, in LDS: every row compares itself with all earlier rows
-    // (pass 2: an earlier row that pass 1 placed is in the segment already and does not count: its entry is -1 here;
-    // pass 2 works from a copy of pass 1's outcome, placed_in, because rows of this launch write placed[] while others read)
-    __shared__ int lu[4096];
+    // the users of the batch's rows, in LDS (pass 2: a row that pass 1 placed is in its segment already: entry -1)
+    __shared__ __attribute__((aligned(16))) int lu[4096];
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int upto = min(k, (int)((blockIdx.x + 1) * blockDim.x));
-    for (int e = threadIdx.x; e < upto; e += blockDim.x) lu[e] = (pass == 1 || placed_in[e] == 0) ? st_user[e] : -1;
+    for (int e = threadIdx.x; e < ((k + 3) & ~3); e += blockDim.x) lu[e] = (e < k && (pass == 1 || placed_in[e] == 0)) ? st_user[e] : -1;
     __syncthreads();
     if (t >= k) return;
-    const int u = st_user[t];
-    if ((unsigned)u >= (unsigned)n_users) return; // the whole append is rejected by the caller
-    if (pass > 1 && placed_in[t] != 0) return;    // pass 2: only what pass 1 left over
-    if (pass == 1) placed[t] = 0;
-    int before = 0, last = -1;
-    for (int e = 0; e < t; ++e) {
-        const bool same = lu[e] == u;
-        before += same ? 1 : 0;
-        last = same ? e : last;
+    const int u = lu[t];
+    if ((unsigned)u >= (unsigned)n_users) { // pass 1: the whole append is rejected by the caller; pass 2: nothing left to do for this row
+        if (pass == 1) placed[t] = 0;
+        return;
     }
-    long long prev = last >= 0 ? st_start[last] : INT64_MIN;
-    const int fill = ufill[u];
+    // rows of my user before / behind mine in the batch: counted four at a time without an early exit (a loop that may leave
+    // at every entry waits for every LDS read in turn: 90 us for a batch of 1 000)
+    int before = 0, later = 0;
+    const int k4 = (k + 3) & ~3; // lu[] entries in [k, k4) are never equal to a valid user: set below
+    for (int e0 = 0; e0 < k4; e0 += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(&lu[e0]);
+        const int m0 = v.x == u, m1 = v.y == u, m2 = v.z == u, m3 = v.w == u;
+        before += (m0 & (e0 < t)) + (m1 & (e0 + 1 < t)) + (m2 & (e0 + 2 < t)) + (m3 & (e0 + 3 < t));
+        later += (m0 & (e0 > t)) + (m1 & (e0 + 1 > t)) + (m2 & (e0 + 2 > t)) + (m3 & (e0 + 3 > t));
+    }
+    if (before) return; // an earlier row of the batch has my user: its thread places mine too
+    int fill = ufill[u];
     const long long seg = uoff[u];
-    if (before == 0 && fill > 0) prev = o_pay[seg + fill - 1].start;
-    const long long slot = (long long)fill + before;
-    const long long sv = st_start[t];
-    if (sv < prev) {
-        __hip_atomic_fetch_add(&stale[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
+    const long long cap = uoff[u + 1] - seg;
+    auto place = [&](int e) { // insert row e of the batch into my user's segment
+        const long long sv = st_start[e];
+        int at = fill; // behind every row whose start is <= sv: usually the end of the segment
+        if (fill > 0 && o_pay[seg + fill - 1].start > sv) {
+            int lo = 0, hi = fill - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (o_pay[seg + mid].start <= sv) lo = mid + 1;
+                else hi = mid;
+            }
+            at = lo;
+        }
+        if (fill >= cap) {
+            placed[e] = 0;
+            if (pend) pend[u] += 1;
+            __hip_atomic_fetch_add(&stale[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        if (fill - at > kOrdShiftMax) {
+            placed[e] = 0;
+            __hip_atomic_fetch_add(&stale[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        for (int i = fill - 1; i >= at; --i) { // make room: the rows behind the new one move up by one slot
+            const OrdRec m = o_pay[seg + i];
+            o_pay[seg + i + 1] = m;
+            o_end[seg + i + 1] = o_end[seg + i];
+            o_key[seg + i + 1] = o_key[seg + i];
+            o_fkey[seg + i + 1] = o_fkey[seg + i];
+            pos[m.row] = (int)(seg + i + 1);
+        }
+        const long long ev = st_end[e];
+        OrdRec o;
+        o.start = sv;
+        o.row = (int)(row0 + e);
+        o.disc = st_disc[e];
+        o_pay[seg + at] = o;
+        o_end[seg + at] = ev;
+        o_key[seg + at] = (lkey_t)key_of(ev, key_base, key_shift);
+        o_fkey[seg + at] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
+        pos[row0 + e] = (int)(seg + at);
+        placed[e] = pass;
+        ++fill;
+    };
+    if (later == 0) place(t); // the usual case: one row of this user in the batch — no second look at the batch
+    else {
+        int todo = later + 1; // my row and the later ones of my user, in batch order
+        for (int e0 = t & ~3; e0 < k4 && todo > 0; e0 += 4) {
+            const int4 v = *reinterpret_cast<const int4*>(&lu[e0]);
+            if (!((v.x == u) | (v.y == u) | (v.z == u) | (v.w == u))) continue;
+            for (int e = e0 < t ? t : e0; e < e0 + 4; ++e)
+                if (lu[e] == u) {
+                    --todo;
+                    place(e);
+                }
+        }
     }
-    if (slot >= uoff[u + 1] - seg) {
-        __hip_atomic_fetch_add(&stale[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    const long long at = seg + slot;
-    const long long ev = st_end[t];
-    OrdRec o;
-    o.start = sv;
-    o.row = (int)(row0 + t);
-    o.disc = st_disc[t];
-    o_pay[at] = o;
-    o_end[at] = ev;
-    o_key[at] = (lkey_t)key_of(ev, key_base, key_shift);
-    o_fkey[at] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
-    pos[row0 + t] = (int)at;
-    placed[t] = pass;
-}
-
-__global__ __launch_bounds__(256) void k_ord_append_commit(const int* __restrict__ st_user, int k, int n_users, const int* __restrict__ placed,
-                                                           int pass, int* __restrict__ ufill, int* __restrict__ pend)
-{
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= k || (unsigned)st_user[t] >= (unsigned)n_users) return;
-    if (placed[t] == pass) atomicAdd(&ufill[st_user[t]], 1);
-    else if (placed[t] == 0 && pend) atomicAdd(&pend[st_user[t]], 1); // rows a re-spread has to make room for
+    ufill[u] = fill;
 }
 
 // Fresh spare slots for every segment: the rows of the run move from (uoff_old, *_old) to (uoff_new, *_new), each user's rows

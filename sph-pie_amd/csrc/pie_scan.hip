@@ -1117,9 +1117,7 @@ void launch_ord_append(pie_ctx* c, hipStream_t s, size_t k, long long row0, int 
     hipLaunchKernelGGL(k_ord_append, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(c->d_stage),
                        reinterpret_cast<const long long*>(c->d_stage + k * 8), st_user, reinterpret_cast<const int*>(c->d_stage + k * 20), (int)k,
                        row0, n_users, c->key_base, c->key_shift, c->fkey_base, c->fkey_shift, o.uoff, o.ufill, o.pay, o.end, o.key, o.fkey,
-                       o.pos, o.stale, o.placed + kOrdAppendMax, o.placed, pass);
-    hipLaunchKernelGGL(k_ord_append_commit, dim3(grid), dim3(256), 0, s, st_user, (int)k, n_users, o.placed, pass, o.ufill,
-                       pass == 1 ? o.pend : (int*)nullptr);
+                       o.pos, o.stale, o.placed + kOrdAppendMax, o.placed, pass == 1 ? o.pend : (int*)nullptr, pass);
 }
 
 // Segments are full: give every user fresh spare slots (its rows, the rows of this append still waiting, a sixteenth more,

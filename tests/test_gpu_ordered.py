@@ -152,7 +152,7 @@ def test_ordered_run_follows_every_writer_of_end(pie, oracle):
         assert ctx.table_info()["ordered_rows"] == 0
         all_queries(ctx, "revived outside the run")
         assert ctx.table_info()["ordered_builds"] == 2
-        # an append out of time order (old starts): the run no longer describes the table
+        # a back-fill (starts anywhere in the last 120 days: rows that belong hundreds of rows back): the run is dropped
         k = 1000
         a = [c.copy() for c in oracle.gen(SEED + 2, k, 0, k, U, D, 0)]
         ctx.append_rows(*a, U)
@@ -166,7 +166,8 @@ def test_ordered_run_takes_appends_in_time_order(pie, oracle):
     """createSession: rows whose start is not below their user's last start go into the spare slots of the user's segment — the
     run stays valid (no rebuild), answers stay exact, touches of the new rows are mirrored; users that did not exist when the
     run was built have segments too; when a segment fills up the run is re-spread (a linear move into fresh segments, no rebuild)
-    and the rows left over take their places; a row out of time order drops the run."""
+    and the rows left over take their places; rows a little out of time order are inserted at their places; a back-fill (a row that
+    belongs hundreds of rows back) drops the run."""
     n, U, D = 200000, 300, 8                                                      # ~666 rows per user: ~45 spare slots each
     t0 = oracle.T0_MS
     s, e, u, d = [c.copy() for c in oracle.gen(SEED + 7, n, 0, n, U, D, 0)]
@@ -221,13 +222,21 @@ def test_ordered_run_takes_appends_in_time_order(pie, oracle):
         assert info["ordered_rows"] == s.size and info["ordered_respreads"] == before + 1 and info["ordered_builds"] == 2
         all_queries("segment overflow", n_users)
         now += 10
-        # a batch out of time order inside itself
-        s2 = np.array([now + 100, now + 50], np.int64)
-        ctx.append_rows(s2, s2 + HOUR, np.array([3, 3], np.int32), np.zeros(2, np.int32), n_users)
-        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + HOUR]), np.concatenate([u, [3, 3]]).astype(np.int32), np.concatenate([d, [0, 0]]).astype(np.int32)
+        # a batch out of time order inside itself, and rows a little late (before the rows just appended): inserted at their
+        # places, the few rows behind them shift
+        s2 = np.array([now + 100, now + 50, now - 3, now + 70, now - 40000], np.int64)
+        u2 = np.array([3, 3, 12, 3, 12], np.int32)
+        ctx.append_rows(s2, s2 + HOUR, u2, np.zeros(5, np.int32), n_users)
+        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + HOUR]), np.concatenate([u, u2]).astype(np.int32), np.concatenate([d, np.zeros(5, np.int32)]).astype(np.int32)
+        info = ctx.table_info()
+        assert info["ordered_rows"] == s.size and info["ordered_builds"] == 2
+        all_queries("a little out of order", n_users)
+        # a back-fill: a row that belongs hundreds of rows back in its user's segment drops the run
+        s2 = np.array([t0 - 100 * DAY], np.int64)
+        ctx.append_rows(s2, s2 + HOUR, np.array([11], np.int32), np.zeros(1, np.int32), n_users)
+        s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, s2 + HOUR]), np.concatenate([u, [11]]).astype(np.int32), np.concatenate([d, [0]]).astype(np.int32)
         assert ctx.table_info()["ordered_rows"] == 0
-        all_queries("out of order", n_users)
-
+        all_queries("back-fill", n_users)
 
 def test_ordered_run_is_built_when_the_general_path_is_weak(pie, oracle):
     """mode 1 (the default): sparse queries on evenly spread users never build it; the second dense query in a row does,
