@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_ord_scan_dense(const OrdRec* __restrict
 // A chunk is 512 positions for both key widths (8 keys per lane: one 8-byte or one 16-byte load).  The key arrays are padded
 // with zero keys to a whole number of chunks; a padding position can only become a candidate when key(now) == 0, and is dropped
 // when its batch is formed (pos >= n_ord).
-template <class KT>
+template <class KT, int UNROLL = 4>
 __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
                                                         const KT* __restrict__ key, long long n_ord, long long n_chunks,
                                                         long long now, unsigned now_key, long long cutoff, unsigned long long mask,
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_ord_scan_keyed(const OrdRec* __restrict
     constexpr int kChunk = kPerLane * kWave;
     constexpr int kChunkShift = 9;
     constexpr int kRing = 2 * kChunk;
-    constexpr int kUnroll = 4;
+    constexpr int kUnroll = UNROLL;
     __shared__ int ring_s[4][kRing];
     __shared__ int blk_live, blk_amb, blk_cand, blk_chunk_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -772,7 +772,7 @@ struct alignas(8) OrdUnion {
 // A chunk is 512 positions for both key widths: 8 one-byte keys (one 8-byte load) or 8 two-byte keys (one 16-byte load) per
 // lane.  The candidate ring then takes 5 / 6 KiB per wave instead of 10, and two to three times as many waves fit a CU —
 // the pass is latency-bound (34 chunks and a handful of candidate batches per wave), so that is what counts: 141 -> 9x us.
-template <class KT>
+template <class KT, int UNROLL = 4>
 __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
                                                         const KT* __restrict__ key, long long n_ord, long long n_chunks, OrdBatchArgs a,
                                                         OrdUnion* __restrict__ ustage, int* __restrict__ ucount,
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
     constexpr int kChunk = kPerLane * kWave;
     constexpr int kChunkShift = 9;
     constexpr int kRing = 2 * kChunk;
-    constexpr int kUnroll = 4;
+    constexpr int kUnroll = UNROLL;
     __shared__ int ring_s[4][kRing];
     __shared__ KT ringk_s[4][kRing];
     __shared__ int blk_cand, blk_chunk_max;

@@ -1249,8 +1249,14 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
     const long long units_stride = o.units_cap, group_stride = o.units_cap / 1024 + 2, sum_stride = (long long)ord_sum_bytes();
     Summary* sum0 = reinterpret_cast<Summary*>(sums);
     if (fine) {
-        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 7 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 7;
+        const int gm = getenv("PIE_ORD_GRID") ? atoi(getenv("PIE_ORD_GRID")) : 12;
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * gm ? (n_chunks + 3) / 4 : (long long)c->n_cus * gm;
         if (grid < 1) grid = 1;
+        if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 8)
+            hipLaunchKernelGGL((k_ord_batch_scan<fkey_t, 8>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
+        else if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 2)
+            hipLaunchKernelGGL((k_ord_batch_scan<fkey_t, 2>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
+        else
         hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
     } else {
         long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
@@ -1322,8 +1328,16 @@ void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long lon
     } else if (fine) {
         unit_shift = 9;
         n_units = (o.n + 511) >> 9;
-        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * 8 ? (n_units + 3) / 4 : (long long)c->n_cus * 8;
+        const int gm = getenv("PIE_ORD_GRID") ? atoi(getenv("PIE_ORD_GRID")) : 12; // blocks per CU (profiles/r02_ze_ord_keyed_grid_unroll_sweep.txt)
+        long long grid = (n_units + 3) / 4 < (long long)c->n_cus * gm ? (n_units + 3) / 4 : (long long)c->n_cus * gm;
         if (grid < 1) grid = 1;
+        if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 8)
+            hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t, 8>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
+                               host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
+        else if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 2)
+            hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t, 2>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
+                               host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
+        else
         hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
                            host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
         sl.variant = 0x2C00;
