@@ -53,7 +53,7 @@ def kernel_name(variant, rides, mode):
         return "k_expired_stage<8>" if os.environ.get("PIE_EXPIRED_ON_END") else "k_expired_stage_keyed<2>"
     if variant & 0x2000:   # the ordered run (pie_ordered.h)
         if variant & 0x400:
-            return "k_ord_scan_keyed<%s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
+            return "k_ord_scan_keyed<%s, 4>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         return "k_ord_scan_dense"
     if variant & 0x400:
         kt = "unsigned char" if variant & 0x800 else "unsigned short"
@@ -72,10 +72,11 @@ def kernel_name(variant, rides, mode):
     return "k_scan_compact<%d, %s, %s, false, false>" % (un, "true" if variant & 1 else "false", "true" if variant & 2 else "false")
 
 
-def pmc_traffic(kname, default_workload):
-    """HBM bytes per launch of `kname` from the committed rocprofv3 PMC summary of this command (profiles/traffic.json,
-    written by tools/pmc_traffic.py), or None.  Only quoted for the workload it was measured on."""
-    path = os.path.join(REPO, "profiles", "traffic.json")
+def pmc_traffic(kname, default_workload, fname="traffic.json"):
+    """HBM bytes per launch of `kname` from the committed rocprofv3 PMC summary of this command (profiles/traffic.json, or
+    traffic_wide.json / traffic_zipf.json for those two secondary workloads; written by tools/pmc_traffic.py), or None.
+    Only quoted for the workload it was measured on."""
+    path = os.path.join(REPO, "profiles", fname)
     if not default_workload or not os.path.exists(path):
         return None, None
     doc = json.load(open(path))
@@ -443,16 +444,34 @@ def main():
         if batch_ms is not None:
             kname = "k_scan_batch_with_tail<8, true, %s, %d>" % ("unsigned char" if variant & 0x800 else "unsigned short", 4 if Q <= 4 else 8)
             if variant & 0x2000:
-                kname = "k_ord_batch_scan<%s>" % ("unsigned char" if variant & 0x800 else "unsigned short")
+                kname = "k_ord_batch_scan<%s, 4>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local
         traffic_doc, traffic_src = pmc_traffic(kname, default_workload and (batch_ms is None or Q == 16))
+        # the two secondary workloads of the ordered run that have PMC passes of their own
+        base_shape = (N, U, D, args.order, args.variant, args.mode, world) == (10 ** 8, 10 ** 5, 32, "random", "auth", "scan", 1)
+        if base_shape and batch_ms is None and args.query == "wide" and args.users_dist == "uniform":
+            traffic_doc, traffic_src = pmc_traffic(kname, True, "traffic_wide.json")
+        if base_shape and batch_ms is None and args.query == "spec" and args.users_dist == "zipf":
+            traffic_doc, traffic_src = pmc_traffic(kname, True, "traffic_zipf.json")
         traffic = traffic_doc["hbm_bytes_per_launch"] if traffic_doc else None
         # byte model from the run's own counters (keyed form): key stream + one 128-B sector per candidate payload record
         # and per ambiguous `end` + one 64-B write per selected row (bucket slot) + K2's outputs
         model = None
-        if batch_ms is not None:
+        if variant & 0x2000:
+            # the ordered run (pie_ordered.h): positions = rows + spare slots; dense form: every key, the 16-byte record of every
+            # slice that may hold a live row (bounded by all of them), 4 B staged per selected row; keyed forms: the key
+            # stream, one 64-B sector per candidate record (a user's candidates are neighbours), 4 / 8 B staged per selected row
+            pos_n = info["ordered_positions"] or n_local
+            kb = 1 if variant & 0x800 else 2
+            if not variant & 0x400:
+                model = pos_n * 2 + pos_n * 16 + int(m) * 4
+            elif batch_ms is not None:
+                model = pos_n * kb + st["candidates"] * 64 + max(batch_ms) * 8
+            else:
+                model = pos_n * kb + st["candidates"] * 64 + int(m) * 4
+        elif batch_ms is not None:
             kb = 1 if variant & 0x800 else 2
             # one union bucket store per selected row (whatever Q), Q sets of counts / offsets / row lists
             model = n_local * kb + st["candidates"] * 128 + max(batch_ms) * 64 + sum(batch_ms) * 4 + Q * u_local * 12
