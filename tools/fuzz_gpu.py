@@ -74,8 +74,11 @@ while time.time() < t_end:
                     e[gone] = INT64_MIN
                 elif r < 0.4 and n < 400000:
                     k = int(rng.integers(1, 3000))
-                    if rng.random() < 0.6:   # a session store's appends: created now, i.e. not before anything the table holds
+                    mode = rng.random()
+                    if mode < 0.4:   # a session store's appends: created now, i.e. not before anything the table holds
                         s2 = (int(s.max()) + np.sort(rng.integers(0, 4000, k))).astype(np.int64)
+                    elif mode < 0.7:   # ... a little late and not sorted: inserted a few rows before the end of their users' segments
+                        s2 = (int(s.max()) - rng.integers(0, 20000, k)).astype(np.int64)
                     else:
                         s2 = rng.integers(T0 - 150 * DAY, T0 + 300 * DAY, k).astype(np.int64)
                     e2 = s2 + rng.integers(-50 * DAY, 50 * DAY, k)
