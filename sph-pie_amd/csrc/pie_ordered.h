@@ -7,7 +7,8 @@
 // None of that work depends on the query: (user, start, row) is a property of the TABLE.  The ordered run stores the
 // rows once in that order — the result of the all-selecting scan, i.e. built by the general path itself — as
 //     o_pay[i] = {start, row, disc}   o_end[i]   o_key[i] / o_fkey[i] (the liveness keys of o_end)   pos[row] = i
-// plus uoff[u], the first position of user u.  A query is then a FILTER over positions 0 .. n_ord: the selected positions,
+// plus uoff[u], the first position of user u's segment (its rows, then spare slots holding filler records: key 0,
+// discipline -1, never selected).  A query is then a FILTER over positions 0 .. n_ord: the selected positions,
 // in position order, ARE the answer (idx = their row ids, offsets[u] = selected positions before uoff[u]).  No atomics,
 // no sort, no dependence on how the rows are spread over the users; every kernel below is a straight pass:
 //
