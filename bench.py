@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE corpus of --rows sharded by user hash (BASELINE configs[3]); weak = --rows per rank")
     ap.add_argument("--gather-batch", type=int, default=8, help="multi-GPU: scans per all-gather (1 = one gather per scan)")
+    ap.add_argument("--exchange", choices=["union", "lists"], default="union",
+                    help="multi-GPU, batched scans: what a step's all-gather moves — union: per user the union of the Q row lists "
+                         "+ a query mask per row (an eighth of the bytes; falls back to lists on skewed users); lists: Q messages")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
                          "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
@@ -285,7 +288,26 @@ def main():
     # the batch: Q requests that arrived within a few seconds of each other — each samples its own clock (sessionStore.js:67),
     # same day's cutoff, same role mask; query 0 is the single-query workload
     batch_queries = [(now - 977 * q, cutoff, mask) for q in range(Q)]
-    bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather) if gather and Q > 1 else None
+    bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=args.exchange == "union") \
+        if gather and Q > 1 else None
+    exchange_state = {"format": args.exchange if bfeeds is not None else None, "fallback": None}
+
+    def exchange_steps(k):
+        """k batched steps with their all-gathers; the union form declines on skewed users (every rank sees it in the gathered
+        lengths, so every rank switches together) and the per-query messages take over"""
+        nonlocal bfeeds
+        from sph_pie_amd.shard import UnionOverflow
+        try:
+            last = bfeeds.run_steps(k, batch_queries)
+            if last is None:  # a row list outgrew the messages: capacity was raised, once more
+                last = bfeeds.run_steps(1, batch_queries)
+            return last
+        except UnionOverflow as ex:
+            while ctx._batches:   # nothing of the declined run stays in flight
+                ctx.scan_batch_finish()
+            exchange_state["format"], exchange_state["fallback"] = "lists", str(ex)
+            bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=False)
+            return exchange_steps(k)
 
     def run_steps(k):
         """k steps; with the exchange step the all-gather of step i overlaps the scan of step i+1."""
@@ -329,10 +351,7 @@ def main():
                 return last
             return ctx.scan_pipelined(k, now, cutoff)
         if bfeeds is not None:
-            last = bfeeds.run_steps(k, batch_queries)
-            if last is None:  # a row list outgrew the messages: capacity was raised, once more
-                last = bfeeds.run_steps(1, batch_queries)
-            return last
+            return exchange_steps(k)
         last = feeds.run_steps(k, now, cutoff)
         if last is None:  # a row list outgrew the message: capacity was raised, redo synchronously once
             last = feeds.scan_and_gather(now, cutoff)
@@ -392,7 +411,11 @@ def main():
         batch_ms = list(last)
         last = batch_ms[0]
     elif Q > 1 and gather and args.mode == "scan":
-        batch_ms = [int(x) for x in last["lengths"][rank]]
+        if "u_offsets" in last:   # union exchange: a query's rows are the union rows that carry its bit
+            mk = last["masks"][rank][: int(last["lengths"][rank])]
+            batch_ms = [int(((mk >> q) & 1).sum()) for q in range(Q)]
+        else:
+            batch_ms = [int(x) for x in last["lengths"][rank]]
     m = batch_ms[0] if (batch_ms is not None and gather) else (last if not gather else int(last["lengths"][rank]))
     ms_per_step = statistics.median(region_ms)
     k1_ms = statistics.median(kernel_ms_regions) if kernel_ms_regions else 0.0
@@ -403,10 +426,20 @@ def main():
         # the gathered lists of this rank (as every rank received them) against this rank's own result of the same query
         if bfeeds is not None:
             ok = True
+            union = "u_offsets" in last
+            if union:   # every query's list is a filter of the union rows (in order); the offsets follow from the masks
+                mu = int(last["lengths"][rank])
+                u_rows, u_masks = last["rows"][rank].cpu().numpy()[:mu], last["masks"][rank].cpu().numpy()[:mu]
+                u_off = last["u_offsets"][rank].cpu().numpy()[: u_local + 1].astype(np.int64)
             for q, (qn, qc, qm) in enumerate(batch_queries):
                 ctx.set_disciplines(qm, D)
                 ctx.scan_device(qn, qc)
                 _, own_off, own_idx = ctx.read_results()
+                if union:
+                    sel = ((u_masks >> q) & 1) == 1
+                    csum = np.concatenate([[0], np.cumsum(sel)])
+                    ok = ok and np.array_equal(u_rows[sel], own_idx) and np.array_equal(csum[u_off], own_off)
+                    continue
                 ok = ok and int(last["lengths"][rank, q]) == own_idx.size and \
                     np.array_equal(last["offsets"][rank, q].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
                     np.array_equal(last["rows"][rank, q].cpu().numpy()[: own_idx.size], own_idx)
@@ -498,6 +531,11 @@ def main():
                        "note": "every region is exactly --steps steps between barrier + synchronize fences (max over ranks); "
                                "value and ms_per_step are the median region"},
             "scan_only_ms_per_step": scan_only_ms, "gather_verified": gather_ok,
+            "exchange": None if bfeeds is None else {
+                "format": exchange_state["format"], "fallback": exchange_state["fallback"],
+                "bytes_per_rank_per_step": int(bfeeds.sets["L"]) * 4 * (1 if bfeeds.union else Q) if bfeeds.sets else None,
+                "note": "what every rank contributes to a step's all-gather (and receives from every other rank): union = per user "
+                        "the union of the Q row lists in (start, row) order + a query mask per row; lists = Q messages of offsets + rows"},
             "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {

@@ -192,6 +192,14 @@ int pie_scan_batch_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
 int pie_batch_read_results(pie_ctx *ctx, int qi, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                            size_t *m_out);
 int pie_batch_result_device_ptrs(pie_ctx *ctx, int qi, void **counts_dev, void **offsets_dev, void **idx_dev);
+/* The UNION message of the last finished batch, for the multi-GPU exchange.  The queries of a batch are
+ * requests of the same few seconds and select almost the same rows; per user the union of their row lists in (start, row)
+ * order with a query mask per row carries every query's feed in 8 B per union row instead of 4 B per row per query:
+ *   dst (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | masks[0..cap) ],   u_pad + 2 + 2 * cap words
+ * Feed(q, u) = the rows of rows[uoff[u] : uoff[u+1]] whose mask has bit q, in that order (uoff[u] = Mu for u >= users).
+ * Rows beyond cap are dropped (Mu says how many there are); Mu = -1: a user's union exceeds 32 rows (skewed users) — use the
+ * per-query messages.  Enqueued on the context's stream (pie_ctx_aux_stream); dst is device-visible memory. */
+int pie_batch_pack_union_device(pie_ctx *ctx, void *dst_i32, size_t u_pad, size_t cap);
 /* One user's feed of query `qi` of the last finished batch (as pie_read_user_feed): the per-request read of a server that
  * answers the requests of one event-loop turn with one batch. */
 int pie_batch_read_user_feed(pie_ctx *ctx, int qi, int32_t user, int32_t *idx_out, size_t idx_cap, size_t *k_out);

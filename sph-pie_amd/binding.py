@@ -83,6 +83,7 @@ _SIGS = [
     ("pie_host_free", C.c_int, [_P, _P]),
     ("pie_set_scan_form", C.c_int, [_P, C.c_int]),
     ("pie_set_ordered_run", C.c_int, [_P, C.c_int]),
+    ("pie_batch_pack_union_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
     ("pie_scan_batch_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
@@ -412,6 +413,10 @@ class PieScan:
         self._check(rc)
         ms = [int(m[k]) for k in range(nq)]
         return (ms, bool(ready.value)) if packed else ms
+
+    def batch_pack_union_device(self, dst_ptr, u_pad, cap):
+        """Union message of the last finished batch into device memory (pie_batch_pack_union_device); enqueued, not waited for."""
+        self._check(self._lib.pie_batch_pack_union_device(self._ctx, dst_ptr, int(u_pad), int(cap)))
 
     def batch_read_results(self, qi):
         """Host copies (counts, offsets, idx) of query qi of the last finished batch."""

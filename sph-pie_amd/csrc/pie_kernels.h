@@ -2762,6 +2762,168 @@ __global__ __launch_bounds__(256) void k_pack_results(const long long* __restric
     }
 }
 
+// The UNION message of a batch (multi-GPU exchange).  The Q queries of a batch are requests of the same few seconds: their
+// row lists are almost the same rows, Q times over.  Per user the union of the Q lists, in (start, row) order, with a query
+// mask per row, is what the exchange needs to move — 8 B per union row instead of 4 B per row per query:
+//   [ uoff[0..u_pad] (exclusive offsets into the union rows, = Mu for u >= U) | Mu | rows[0..cap) | masks[0..cap) ]   int32 words
+// Feed(q, u) = the rows of rows[uoff[u] : uoff[u+1]] whose mask has bit q, in that order.  Built from the finished per-query
+// lists, whichever path produced them: one thread per user merges its (short) lists; a user with more than kUnionMax (32) union
+// rows makes the message unusable (Mu = -1: the caller falls back to the per-query messages).
+constexpr int kUnionMax = 32;
+constexpr int kUnionThreads = 128;
+struct UnionLists {
+    const int* idx[kBatchMax]; // row list of query q (device)
+};
+struct alignas(8) UnionRow {
+    int row;
+    unsigned mask;
+};
+
+// one thread per user; its working list lives in LDS, slot-major ([slot][thread]: neighbouring threads touch neighbouring
+// words), so the duplicate search and the insertion sort index it freely without touching global memory
+__global__ __launch_bounds__(kUnionThreads) void k_union_collect(int n_q, int n_users, const long long* __restrict__ offsets,
+                                                                 long long users_stride, UnionLists lists,
+                                                                 const long long* __restrict__ start, UnionRow* __restrict__ scratch,
+                                                                 int* __restrict__ ucnt, int* __restrict__ over)
+{
+    __shared__ int l_row[kUnionMax][kUnionThreads];
+    __shared__ unsigned l_mask[kUnionMax][kUnionThreads];
+    __shared__ long long l_start[kUnionMax][kUnionThreads];
+    const int t = threadIdx.x;
+    const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (u >= n_users) return;
+    int n = 0;
+    bool overflow = false;
+    for (int q = 0; q < n_q; ++q) {
+        const long long lo = offsets[(long long)q * users_stride + u], hi = offsets[(long long)q * users_stride + u + 1];
+        for (long long j = lo; j < hi; ++j) {
+            const int r = lists.idx[q][j];
+            int at = -1;
+            for (int i = 0; i < n; ++i)
+                if (l_row[i][t] == r) at = i;
+            if (at >= 0) l_mask[at][t] |= 1u << q;
+            else if (n < kUnionMax) {
+                l_row[n][t] = r;
+                l_mask[n][t] = 1u << q;
+                l_start[n][t] = start[r];
+                ++n;
+            } else overflow = true;
+        }
+    }
+    // (start, row) order: insertion sort of a handful of rows
+    for (int i = 1; i < n; ++i) {
+        const int xr = l_row[i][t];
+        const unsigned xm = l_mask[i][t];
+        const long long xs = l_start[i][t];
+        int j = i - 1;
+        while (j >= 0) {
+            const long long ys = l_start[j][t];
+            const int yr = l_row[j][t];
+            if (ys < xs || (ys == xs && yr < xr)) break;
+            l_row[j + 1][t] = yr;
+            l_mask[j + 1][t] = l_mask[j][t];
+            l_start[j + 1][t] = ys;
+            --j;
+        }
+        l_row[j + 1][t] = xr;
+        l_mask[j + 1][t] = xm;
+        l_start[j + 1][t] = xs;
+    }
+    UnionRow* mine = scratch + (long long)u * kUnionMax;
+    for (int i = 0; i < n; ++i) {
+        UnionRow x;
+        x.row = l_row[i][t];
+        x.mask = l_mask[i][t];
+        mine[i] = x;
+    }
+    ucnt[u] = n;
+    if (overflow) atomicOr(over, 1);
+}
+
+// The general batched pass already holds the union: one bucket slot {start, row, query mask} per row that any query selected
+// (scan_batch_body), counted in the union histogram.  One thread per user orders its slots — a few contiguous 16-byte loads,
+// no chasing through Q row lists (the generic form above is latency-bound: three dependent loads per row and query).
+__global__ __launch_bounds__(kUnionThreads) void k_union_from_buckets(int n_users, const int* __restrict__ counts,
+                                                                      const BktRec* __restrict__ direct, int dshift,
+                                                                      UnionRow* __restrict__ scratch, int* __restrict__ ucnt,
+                                                                      int* __restrict__ over)
+{
+    __shared__ int l_row[kUnionMax][kUnionThreads];
+    __shared__ unsigned l_mask[kUnionMax][kUnionThreads];
+    __shared__ long long l_start[kUnionMax][kUnionThreads];
+    const int t = threadIdx.x;
+    const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (u >= n_users) return;
+    int n = counts[hist_index(u, n_users)];
+    if (n > (1 << dshift) || n > kUnionMax) { // cannot happen for a batch without overflow; never read beyond the slots
+        atomicOr(over, 1);
+        n = n > kUnionMax ? kUnionMax : n;
+        if (n > (1 << dshift)) n = 1 << dshift;
+    }
+    const BktRec* slots = direct + ((long long)u << dshift);
+    for (int i = 0; i < n; ++i) {
+        const BktRec r = slots[i];
+        l_row[i][t] = r.idx;
+        l_mask[i][t] = (unsigned)r.pad;
+        l_start[i][t] = r.start;
+    }
+    for (int i = 1; i < n; ++i) {
+        const int xr = l_row[i][t];
+        const unsigned xm = l_mask[i][t];
+        const long long xs = l_start[i][t];
+        int j = i - 1;
+        while (j >= 0) {
+            const long long ys = l_start[j][t];
+            const int yr = l_row[j][t];
+            if (ys < xs || (ys == xs && yr < xr)) break;
+            l_row[j + 1][t] = yr;
+            l_mask[j + 1][t] = l_mask[j][t];
+            l_start[j + 1][t] = ys;
+            --j;
+        }
+        l_row[j + 1][t] = xr;
+        l_mask[j + 1][t] = xm;
+        l_start[j + 1][t] = xs;
+    }
+    UnionRow* mine = scratch + (long long)u * kUnionMax;
+    for (int i = 0; i < n; ++i) {
+        UnionRow x;
+        x.row = l_row[i][t];
+        x.mask = l_mask[i][t];
+        mine[i] = x;
+    }
+    ucnt[u] = n;
+}
+
+// uoff[u] = group_base[u >> 10] + unit_local[u]: the two-level prefix of the union counts (k_ord_prefix + k_ord_prefix_groups,
+// the kernels the ordered run uses for its unit counts)
+__global__ __launch_bounds__(256) void k_union_write(int n_users, int u_pad, const int* __restrict__ unit_local,
+                                                     const long long* __restrict__ group_base, const int* __restrict__ ucnt,
+                                                     const UnionRow* __restrict__ scratch, const int* __restrict__ over, long long cap,
+                                                     int* __restrict__ dst)
+{
+    const long long n_groups = ((long long)n_users + 1023) >> 10;
+    const long long mu = group_base[n_groups];
+    const int bad = *over;
+    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u <= (long long)u_pad + 1; u += (long long)gridDim.x * blockDim.x) {
+        if (u < n_users) dst[u] = (int)(group_base[u >> 10] + unit_local[u]);
+        else if (u <= u_pad) dst[u] = (int)mu;
+        else dst[u] = bad ? -1 : (int)mu; // the word behind the offsets: Mu, or -1 when a user's union outgrew kUnionMax
+    }
+    int* rows = dst + u_pad + 2;
+    int* masks = rows + cap;
+    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += (long long)gridDim.x * blockDim.x) {
+        const long long at = group_base[u >> 10] + unit_local[u];
+        const int n = ucnt[u];
+        const UnionRow* mine = scratch + u * kUnionMax;
+        for (int i = 0; i < n; ++i)
+            if (at + i < cap) {
+                rows[at + i] = mine[i].row;
+                masks[at + i] = (int)mine[i].mask;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ table maintenance
 
 __global__ __launch_bounds__(256) void k_set_end(long long* __restrict__ end, const int* __restrict__ rows,

@@ -101,6 +101,7 @@ struct Slot {
 struct BatchSlot {
     int n_q = 0;
     bool in_flight = false, k2_pending = false, have_result = false;
+    int dshift = 4;                    // union bucket capacity (log2) the batch ran with
     bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no K2, nothing rides
     bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
     bool fine_key = false;
@@ -253,6 +254,11 @@ struct pie_ctx {
     bool fast_enabled = false; // the partitioned path is opt-in (PIE_FAST_PATH=1): measured at parity with the general
     bool fast_env = false;     // path (0.179 vs 0.177 ms/step), so the simpler path stays the default; an overflow turns it off for the table
 
+    UnionRow* d_union = nullptr;   // pie_batch_pack_union_device: per user kUnionMax union rows
+    int* d_union_cnt = nullptr;    // ... their counts, padded with zeros to whole groups of 1024 (the two-level prefix reads groups)
+    int* d_union_local = nullptr;  // ... prefix inside the group
+    long long* d_union_off = nullptr; // ... group sums | group bases | a Summary the prefix kernel writes M into | the overflow flag
+    int union_users = 0;
     OrderedRun ord;
     bool ord_building = false;  // the scan being begun is the ordered run's build
     Slot slot[2];
@@ -416,6 +422,8 @@ OrdMirror ord_mirror_of(const pie_ctx* c)
 
 void free_table(pie_ctx* c)
 {
+    dfree(c->d_union); dfree(c->d_union_cnt); dfree(c->d_union_local); dfree(c->d_union_off);
+    c->union_users = 0;
     ord_free(c);
     free_batch(c);
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
@@ -2013,6 +2021,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         }
     }
     b.fine_key = fine;
+    b.dshift = c->bdshift;
     if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
         if (c->ring_used == kEventRing) {
             rc = resolve_events(c);
@@ -2949,6 +2958,56 @@ int pie_pack_results_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t idx_
     if (grid > (size_t)c->n_cus * 8) grid = (size_t)c->n_cus * 8;
     hipLaunchKernelGGL(k_pack_results, dim3((unsigned)grid), dim3(256), 0, c->stream, sl.offsets, c->n_users, (int)u_pad,
                        sl.sum, sl.out_idx, (long long)idx_cap, (int*)dst_i32);
+    PIE_HIP(c, hipGetLastError());
+    return PIE_OK;
+}
+
+int pie_batch_pack_union_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad union destination / u_pad < n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    const BatchSlot& b = *c->bres;
+    hipStream_t s = c->stream;
+    const size_t padded = (((size_t)c->cap_users + 1023) / 1024 + 1) * 1024, groups = padded / 1024 + 2;
+    if (c->union_users < c->cap_users || !c->d_union) {
+        if ((size_t)c->cap_users * kUnionMax * sizeof(UnionRow) > ((size_t)4 << 30)) return fail(c, PIE_E_NOMEM, "union scratch for %d users exceeds 4 GiB", c->cap_users);
+        PIE_HIP(c, hipStreamSynchronize(s));
+        dfree(c->d_union); dfree(c->d_union_cnt); dfree(c->d_union_local); dfree(c->d_union_off);
+        PIE_HIP(c, hipMalloc(&c->d_union, (size_t)c->cap_users * kUnionMax * sizeof(UnionRow)));
+        PIE_HIP(c, hipMalloc(&c->d_union_cnt, padded * 4));
+        PIE_HIP(c, hipMalloc(&c->d_union_local, padded * 4));
+        PIE_HIP(c, hipMalloc(&c->d_union_off, 2 * groups * 8 + 256 + 64));
+        PIE_HIP(c, hipMemsetAsync(c->d_union_cnt, 0, padded * 4, s)); // entries behind the users stay zero for good
+        c->union_users = c->cap_users;
+    }
+    long long* gsum = c->d_union_off;
+    long long* gbase = c->d_union_off + groups;
+    Summary* usum = reinterpret_cast<Summary*>(reinterpret_cast<char*>(c->d_union_off + 2 * groups));
+    int* over = reinterpret_cast<int*>(reinterpret_cast<char*>(usum) + 256);
+    PIE_HIP(c, hipMemsetAsync(over, 0, 4, s));
+    UnionLists lists{};
+    for (int q = 0; q < b.n_q; ++q) lists.idx[q] = b.idx_of[q];
+    const unsigned ublocks = (unsigned)((c->n_users + kUnionThreads - 1) / kUnionThreads);
+    bool from_buckets = !b.ordered && !b.unsupported && b.span && b.direct;
+    for (int q = 0; q < b.n_q; ++q) from_buckets = from_buckets && !b.fallback[q];
+    if (from_buckets) // the general batched pass: its union bucket slots ARE the union (a query that fell back is not in them)
+        hipLaunchKernelGGL(k_union_from_buckets, dim3(ublocks ? ublocks : 1u), dim3(kUnionThreads), 0, s, c->n_users,
+                           reinterpret_cast<const int*>(b.span), b.direct, b.dshift, c->d_union, c->d_union_cnt, over);
+    else
+        hipLaunchKernelGGL(k_union_collect, dim3(ublocks ? ublocks : 1u), dim3(kUnionThreads), 0, s, b.n_q, c->n_users, b.offsets, batch_users_stride(c),
+                           lists, c->d_start, c->d_union, c->d_union_cnt, over);
+    long long n_groups = ((long long)c->n_users + 1023) >> 10;
+    if (n_groups < 1) n_groups = 1;
+    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, c->d_union_cnt, (long long)c->n_users, c->d_union_local, gsum, gbase,
+                       (OrdCtl*)nullptr, usum, 0LL, 0LL, 0LL);
+    hipLaunchKernelGGL(k_ord_prefix_groups, dim3(1), dim3(256), 0, s, (long long)c->n_users, gsum, gbase, usum, 0LL, 0LL);
+    unsigned wblocks = (unsigned)((u_pad + 2 + 255) / 256);
+    if (wblocks > (unsigned)c->n_cus * 8) wblocks = (unsigned)c->n_cus * 8;
+    hipLaunchKernelGGL(k_union_write, dim3(wblocks), dim3(256), 0, s, c->n_users, (int)u_pad, c->d_union_local, gbase, c->d_union_cnt, c->d_union, over,
+                       (long long)cap, (int*)dst_i32);
     PIE_HIP(c, hipGetLastError());
     return PIE_OK;
 }

@@ -76,6 +76,10 @@ class HipShardBackend:
         """-> ([M per query], ready)"""
         return self.ctx.scan_batch_finish(packed=True)
 
+    def batch_pack_union(self, dst, u_pad, cap):
+        """Enqueue (on result_stream) the UNION message of the last finished batch into dst: u_pad + 2 + 2 * cap int32 words."""
+        self.ctx.batch_pack_union_device(dst.data_ptr(), u_pad, cap)
+
 
 N_SETS = 4
 
@@ -396,6 +400,17 @@ def _run_steps_batched(self, k, now, cutoff):
 ShardedFeeds._run_steps_batched = _run_steps_batched
 
 
+class UnionOverflow(RuntimeError):
+    """A shard's union message is unusable (a user's union of row lists exceeds 32 rows): exchange the per-query lists."""
+
+
+def union_feed(res, r, q, u):
+    """Feed of user u (local index on shard r) for query q out of a union-mode result of BatchedFeeds.run_steps."""
+    a, b = int(res["u_offsets"][r, u]), int(res["u_offsets"][r, u + 1])
+    rows, masks = res["rows"][r, a:b], res["masks"][r, a:b]
+    return rows[((masks >> q) & 1) == 1]
+
+
 class BatchedFeeds:
     """Per-rank driver of the BATCHED exchange: every step is one batched scan of Q queries over the local shard (one table
     pass, pie_scan_batch_*), whose offsets kernel writes the Q result messages back to back, and ONE all-gather moves them
@@ -403,10 +418,18 @@ class BatchedFeeds:
     ShardedFeeds.run_steps: begin(i+1) | gather(i-1) issued on the side stream | gather(i-2) collected | finish(i); four
     rotating buffer sets.
 
-    backend.batch_begin(queries[, dst, stride, u_pad, cap]) / backend.batch_finish() -> ([M], ready)."""
+    backend.batch_begin(queries[, dst, stride, u_pad, cap]) / backend.batch_finish() -> ([M], ready).
 
-    def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False):
+    union=True: ONE message per step instead of Q — per user the union of the Q row lists in (start, row) order with a query
+    mask per row (pie_batch_pack_union_device; backend.batch_pack_union(dst, u_pad, cap)).  The queries of a batch are
+    requests of the same few seconds and select almost the same rows, so the union is little longer than one list: an eighth
+    of the bytes cross the links for Q = 16.  run_steps then returns u_offsets [world, U_pad+1], lengths [world], rows
+    [world, cap], masks [world, cap]; Feed(r, q, u) = rows[r, a:b][(masks[r, a:b] >> q) & 1 == 1], a, b = u_offsets[r, u : u+2].
+    A shard whose users hold more than 32 union rows (skewed users) reports length -1: UnionOverflow, use the lists."""
+
+    def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False, union=False):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self.union = bool(union)
         self.q_max = int(q_max)
         self.collective = world > 1 or always_collective
         self.device = torch.device(getattr(backend, "device", "cpu"))
@@ -427,8 +450,8 @@ class BatchedFeeds:
 
     def _sets(self):
         if self.sets is None or self.sets["cap"] != self.cap:
-            L = self.u_pad + 2 + self.cap
-            Q, W = self.q_max, self.world
+            L = self.u_pad + 2 + (2 if self.union else 1) * self.cap
+            Q, W = (1 if self.union else self.q_max), self.world
             self.sets = {
                 "cap": self.cap, "L": L,
                 "msg": [torch.zeros(Q * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
@@ -446,6 +469,18 @@ class BatchedFeeds:
         """First use: one batch without messages learns the largest row list; every rank agrees on the capacity."""
         self.backend.batch_begin(queries)
         ms, _ = self.backend.batch_finish()
+        if self.union:   # the union's length: a message with no room for rows still carries it
+            head = torch.zeros(self.u_pad + 2, dtype=torch.int32, device=self.device)
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()
+            self.backend.batch_pack_union(head, self.u_pad, 0)
+            if self.cuda:
+                self.rs.synchronize()
+            mu = int(head[self.u_pad + 1])
+            if self._all_max(1 if mu < 0 else 0):
+                raise UnionOverflow("a user's union of row lists exceeds 32 rows on some shard")
+            self.cap = ShardedFeeds._grow(self._all_max(mu))
+            return
         self.cap = ShardedFeeds._grow(self._all_max(max(ms) if ms else 0))
 
     def _issue(self, st, p, ready):
@@ -475,6 +510,18 @@ class BatchedFeeds:
             if self.cuda:
                 torch.cuda.current_stream(self.device).synchronize()
             st["len_host"][p].copy_(st["len_dev"][p])
+        if self.union:
+            lens = st["len_host"][p][:, 0]
+            if int(lens.min()) < 0:
+                raise UnionOverflow("a user's union of row lists exceeds 32 rows on some shard")
+            need = int(lens.max())
+            if need > st["cap"]:
+                self.cap = max(self.cap, ShardedFeeds._grow(need))
+                return None
+            g = st["out"][p].view(self.world, st["L"])
+            cap = st["cap"]
+            return {"u_offsets": g[:, : self.u_pad + 1], "lengths": lens.clone(), "rows": g[:, self.u_pad + 2: self.u_pad + 2 + cap],
+                    "masks": g[:, self.u_pad + 2 + cap:]}
         need = int(st["len_host"][p][:, :nq].max())
         if need > st["cap"]:
             self.cap = max(self.cap, ShardedFeeds._grow(need))
@@ -499,7 +546,10 @@ class BatchedFeeds:
         finished, flying = None, None   # (set, ready)
 
         def begin(i):
-            self.backend.batch_begin(queries, st["msg"][i % N_SETS], L, self.u_pad, cap)
+            if self.union:
+                self.backend.batch_begin(queries)
+            else:
+                self.backend.batch_begin(queries, st["msg"][i % N_SETS], L, self.u_pad, cap)
 
         begin(0)
         for i in range(k):
@@ -514,6 +564,9 @@ class BatchedFeeds:
             flying, finished = finished, None
             _, ready = self.backend.batch_finish()
             p = i % N_SETS
+            if self.union:   # the union message is packed from the finished lists, on the result stream
+                self.backend.batch_pack_union(st["msg"][p], self.u_pad, cap)
+                ready = False
             if self.cuda and not ready:
                 st["ev_packed"][p].record(self.rs)
             finished = (p, ready)

@@ -294,8 +294,71 @@ def test_exchange_over_rccl_one_rank(pie, oracle):
                     assert int(res["lengths"][0, q]) == m
                     assert np.array_equal(res["offsets"][0, q].cpu().numpy(), w[1].astype(np.int32))
                     assert np.array_equal(res["rows"][0, q].cpu().numpy()[:m], w[2])
+            # the union form of the exchange: ONE message per step (per user the union of the Q lists + a query mask per row)
+            from sph_pie_amd.shard import union_feed
+            near = [(oracle.T0_MS - 6 * HOUR - 977 * q, oracle.T0_MS - (61 + q % 2) * DAY, (0x5555555555555555, ALL)[q % 2]) for q in range(8)]
+            wants = oracle_answers(oracle, cols, U, D, near)
+            uf = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True, union=True)
+            for k in (1, 4):
+                res = uf.run_steps(k, near)
+                assert res is not None
+                uo = res["u_offsets"][0].cpu().numpy()
+                assert uo[0] == 0 and uo[U] == int(res["lengths"][0]) and np.all(np.diff(uo[: U + 1]) >= 0)
+                union_len = int(res["lengths"][0])
+                assert union_len < sum(w[2].size for w in wants) // 4          # that is the point: far fewer rows cross the links
+                rows_all, masks_all = res["rows"][0].cpu().numpy(), res["masks"][0].cpu().numpy()
+                for q, w in enumerate(wants):
+                    sel = ((masks_all[:union_len] >> q) & 1) == 1
+                    assert np.array_equal(rows_all[:union_len][sel], w[2]), q       # every query's whole list, in order
+                    for u in (0, 17, U - 1):
+                        assert np.array_equal(union_feed(res, 0, q, u).cpu().numpy(), w[2][w[1][u]:w[1][u + 1]])
     finally:
         dist.destroy_process_group()
+
+
+def test_union_message_layout_capacity_and_overflow(pie, oracle):
+    """pie_batch_pack_union_device: offsets padded with Mu up to u_pad, rows beyond cap dropped (Mu still says how many), a
+    user whose union exceeds 32 rows makes the message say -1; the same words as a numpy restatement."""
+    import torch
+    n, U, D = 300000, 900, 16
+    cols = oracle.gen(SEED + 5, n, 0, n, U, D, 0)
+    s = cols[0]
+    lim = (1 << D) - 1
+    queries = [(oracle.T0_MS - 6 * HOUR - 500 * q, oracle.T0_MS - 61 * DAY, (0xFFFF, 0x0F0F, 0x00FF)[q % 3]) for q in range(5)]
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_disciplines(ALL, D)
+        ctx.scan_batch(queries)
+        per_user = [dict() for _ in range(U)]
+        for k, (now, cutoff, mask) in enumerate(queries):
+            c, off, idx = oracle.scan(*cols, U, now, cutoff, mask & lim)
+            for u in range(U):
+                for r in idx[off[u]:off[u + 1]]:
+                    per_user[u][int(r)] = per_user[u].get(int(r), 0) | (1 << k)
+        rows, masks, uoff = [], [], [0]
+        for u in range(U):
+            items = sorted(per_user[u].items(), key=lambda it: (int(s[it[0]]), it[0]))
+            rows += [r for r, _ in items]
+            masks += [m for _, m in items]
+            uoff.append(len(rows))
+        mu = len(rows)
+        for u_pad, cap in [(U, mu), (U + 77, mu + 9), (U + 1, mu // 2)]:
+            msg = torch.full((u_pad + 2 + 2 * cap,), -7, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.batch_pack_union_device(msg.data_ptr(), u_pad, cap)
+            ctx.synchronize()
+            a = msg.cpu().numpy()
+            k = min(mu, cap)
+            assert np.array_equal(a[: U + 1], np.array(uoff, np.int32)) and np.all(a[U + 1: u_pad + 2] == mu)
+            assert np.array_equal(a[u_pad + 2: u_pad + 2 + k], np.array(rows[:k], np.int32)) and np.all(a[u_pad + 2 + k: u_pad + 2 + cap] == -7)
+            assert np.array_equal(a[u_pad + 2 + cap: u_pad + 2 + cap + k], np.array(masks[:k], np.int32))
+        # dense queries: hundreds of rows per user
+        ctx.scan_batch([(oracle.T0_MS - 100 * DAY, INT64_MIN, ALL), (oracle.T0_MS - 90 * DAY, INT64_MIN, ALL)])
+        msg = torch.zeros(U + 2, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.batch_pack_union_device(msg.data_ptr(), U, 0)
+        ctx.synchronize()
+        assert int(msg[U + 1]) == -1
 
 
 def test_communicator_behind_the_c_abi(pie, oracle):

@@ -82,7 +82,34 @@ class OracleBatchBackend:
                 m[: off.size] = torch.from_numpy(off.astype(np.int32))
                 m[off.size:u_pad + 2] = int(idx.size)
                 m[u_pad + 2:u_pad + 2 + kk] = torch.from_numpy(idx[:kk])
+        self.last = queries
         return ms, True
+
+    def batch_pack_union(self, dst, u_pad, cap):
+        """numpy restatement of pie_batch_pack_union_device over the last finished batch"""
+        sh, U = self.sh, self.sh["n_users"]
+        per_user = [dict() for _ in range(U)]
+        for k, (now, cutoff, mask) in enumerate(self.last):
+            c, off, idx = self.o.scan(sh["start"], sh["end"], sh["user"], sh["disc"], U, now, cutoff, mask & self.lim)
+            for u in range(U):
+                for r in idx[off[u]:off[u + 1]]:
+                    per_user[u][int(r)] = per_user[u].get(int(r), 0) | (1 << k)
+        rows, masks, uoff = [], [], [0]
+        over = False
+        for u in range(U):
+            items = sorted(per_user[u].items(), key=lambda it: (int(sh["start"][it[0]]), it[0]))
+            over = over or len(items) > 32
+            rows += [r for r, _ in items]
+            masks += [m for _, m in items]
+            uoff.append(len(rows))
+        mu = len(rows)
+        dst[: U + 1] = torch.tensor(uoff, dtype=torch.int32)
+        dst[U + 1:u_pad + 1] = mu
+        dst[u_pad + 1] = -1 if over else mu
+        kk = min(mu, cap)
+        if kk:
+            dst[u_pad + 2:u_pad + 2 + kk] = torch.tensor(rows[:kk], dtype=torch.int32)
+            dst[u_pad + 2 + cap:u_pad + 2 + cap + kk] = torch.tensor(masks[:kk], dtype=torch.int32)
 
 
 def _batch_worker(rank, world, port, tmp, n, U):
@@ -126,6 +153,32 @@ def _batch_worker(rank, world, port, tmp, n, U):
         assert feeds.run_steps(2, dense) is None     # outgrew the negotiated capacity on every rank: raised, call again
         check(feeds.run_steps(2, dense), dense)
         check(feeds.run_steps(4, sparse), sparse)
+        # the union form of the exchange: one message per step, every query's feed a filter of it
+        from sph_pie_amd.shard import UnionOverflow, union_feed
+        ufeeds = BatchedFeeds(OracleBatchBackend(oracle_py, sh, D), rank, world, sh["n_users"], q_max=6, union=True)
+
+        def check_union(out, queries):
+            assert out is not None
+            for q, (now, cutoff, mask) in enumerate(queries):
+                wc, wo, wi = oracle_py.scan(*cols, U, now, cutoff, mask)
+                total = 0
+                for r in range(world):
+                    assert int(out["u_offsets"][r, 0]) == 0 and int(out["u_offsets"][r, -1]) == int(out["lengths"][r])
+                    for lu, gu in enumerate(shards[r]["users"]):
+                        rows = union_feed(out, r, q, lu).numpy()
+                        total += rows.size
+                        assert np.array_equal(shards[r]["rows"][rows], wi[wo[gu]:wo[gu + 1]]), (rank, q, gu)
+                assert total == wi.size
+
+        check_union(ufeeds.run_steps(1, sparse), sparse)
+        check_union(ufeeds.run_steps(5, sparse), sparse)
+        check_union(ufeeds.run_steps(3, sparse[:2]), sparse[:2])
+        try:   # dense queries: hundreds of rows per user — the union form declines, the caller uses the lists
+            ufeeds.run_steps(1, dense)
+            raised = False
+        except UnionOverflow:
+            raised = True
+        assert raised
         open(os.path.join(tmp, "bok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
