@@ -288,8 +288,8 @@ def main():
     # the batch: Q requests that arrived within a few seconds of each other — each samples its own clock (sessionStore.js:67),
     # same day's cutoff, same role mask; query 0 is the single-query workload
     batch_queries = [(now - 977 * q, cutoff, mask) for q in range(Q)]
-    bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=args.exchange == "union") \
-        if gather and Q > 1 else None
+    bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=args.exchange == "union",
+                          steps_per_gather=args.gather_batch) if gather and Q > 1 else None
     exchange_state = {"format": args.exchange if bfeeds is not None else None, "fallback": None}
 
     def exchange_steps(k):
@@ -306,7 +306,7 @@ def main():
             while ctx._batches:   # nothing of the declined run stays in flight
                 ctx.scan_batch_finish()
             exchange_state["format"], exchange_state["fallback"] = "lists", str(ex)
-            bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=False)
+            bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=False, steps_per_gather=args.gather_batch)
             return exchange_steps(k)
 
     def run_steps(k):
@@ -534,6 +534,7 @@ def main():
             "exchange": None if bfeeds is None else {
                 "format": exchange_state["format"], "fallback": exchange_state["fallback"],
                 "bytes_per_rank_per_step": int(bfeeds.sets["L"]) * 4 * (1 if bfeeds.union else Q) if bfeeds.sets else None,
+                "steps_per_gather": bfeeds.steps_per_gather,
                 "note": "what every rank contributes to a step's all-gather (and receives from every other rank): union = per user "
                         "the union of the Q row lists in (start, row) order + a query mask per row; lists = Q messages of offsets + rows"},
             "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,

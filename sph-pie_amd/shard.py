@@ -427,9 +427,11 @@ class BatchedFeeds:
     [world, cap], masks [world, cap]; Feed(r, q, u) = rows[r, a:b][(masks[r, a:b] >> q) & 1 == 1], a, b = u_offsets[r, u : u+2].
     A shard whose users hold more than 32 union rows (skewed users) reports length -1: UnionOverflow, use the lists."""
 
-    def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False, union=False):
+    def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False, union=False,
+                 steps_per_gather=1):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
         self.union = bool(union)
+        self.steps_per_gather = max(1, int(steps_per_gather))
         self.q_max = int(q_max)
         self.collective = world > 1 or always_collective
         self.device = torch.device(getattr(backend, "device", "cpu"))
@@ -451,14 +453,15 @@ class BatchedFeeds:
     def _sets(self):
         if self.sets is None or self.sets["cap"] != self.cap:
             L = self.u_pad + 2 + (2 if self.union else 1) * self.cap
-            Q, W = (1 if self.union else self.q_max), self.world
+            # messages of one step: one (union) or q_max (lists); G steps share an all-gather
+            Qm, W, G = (1 if self.union else self.q_max), self.world, self.steps_per_gather
             self.sets = {
-                "cap": self.cap, "L": L,
-                "msg": [torch.zeros(Q * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
-                "out": [torch.zeros(W * Q * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
-                "len_host": [torch.zeros(W, Q, dtype=torch.int32, pin_memory=self.cuda) for _ in range(N_SETS)],
+                "cap": self.cap, "L": L, "Qm": Qm,
+                "msg": [torch.zeros(G * Qm * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
+                "out": [torch.zeros(W * G * Qm * L, dtype=torch.int32, device=self.device) for _ in range(N_SETS)],
+                "len_host": [torch.zeros(W, G * Qm, dtype=torch.int32, pin_memory=self.cuda) for _ in range(N_SETS)],
             }
-            self.sets["len_dev"] = [o.view(W, Q, L)[:, :, self.u_pad + 1] for o in self.sets["out"]]
+            self.sets["len_dev"] = [o.view(W, G * Qm, L)[:, :, self.u_pad + 1] for o in self.sets["out"]]
             if self.cuda:
                 self.sets["ev_packed"] = [torch.cuda.Event() for _ in range(N_SETS)]
                 self.sets["ev_done"] = [torch.cuda.Event() for _ in range(N_SETS)]
@@ -503,36 +506,41 @@ class BatchedFeeds:
         else:
             dist.all_gather_into_tensor(st["out"][p], st["msg"][p], group=self.group)
 
-    def _collect(self, st, p, nq):
+    def _collect(self, st, p, nq, n_slots):
+        """Wait for the all-gather of set p (n_slots steps' messages) -> the LAST of those steps as a result dict, or None
+        when a message of the group outgrew the capacity (raised)."""
         if self.cuda and self.collective:
             st["ev_done"][p].synchronize()
         else:
             if self.cuda:
                 torch.cuda.current_stream(self.device).synchronize()
             st["len_host"][p].copy_(st["len_dev"][p])
+        Qm, G, L, cap = st["Qm"], self.steps_per_gather, st["L"], st["cap"]
+        lens_all = st["len_host"][p].view(self.world, G, Qm)[:, :n_slots]
         if self.union:
-            lens = st["len_host"][p][:, 0]
-            if int(lens.min()) < 0:
+            if int(lens_all.min()) < 0:
                 raise UnionOverflow("a user's union of row lists exceeds 32 rows on some shard")
-            need = int(lens.max())
-            if need > st["cap"]:
-                self.cap = max(self.cap, ShardedFeeds._grow(need))
-                return None
-            g = st["out"][p].view(self.world, st["L"])
-            cap = st["cap"]
-            return {"u_offsets": g[:, : self.u_pad + 1], "lengths": lens.clone(), "rows": g[:, self.u_pad + 2: self.u_pad + 2 + cap],
-                    "masks": g[:, self.u_pad + 2 + cap:]}
-        need = int(st["len_host"][p][:, :nq].max())
-        if need > st["cap"]:
+            need = int(lens_all.max())
+        else:
+            need = int(lens_all[:, :, :nq].max())
+        if need > cap:
             self.cap = max(self.cap, ShardedFeeds._grow(need))
             return None
-        g = st["out"][p].view(self.world, self.q_max, st["L"])
-        return {"offsets": g[:, :nq, : self.u_pad + 1], "lengths": st["len_host"][p][:, :nq].clone(), "rows": g[:, :nq, self.u_pad + 2:]}
+        last = n_slots - 1
+        g = st["out"][p].view(self.world, G, Qm, L)[:, last]
+        lens = lens_all[:, last]
+        if self.union:
+            g = g[:, 0]
+            return {"u_offsets": g[:, : self.u_pad + 1], "lengths": lens[:, 0].clone(), "rows": g[:, self.u_pad + 2: self.u_pad + 2 + cap],
+                    "masks": g[:, self.u_pad + 2 + cap:]}
+        return {"offsets": g[:, :nq, : self.u_pad + 1], "lengths": lens[:, :nq].clone(), "rows": g[:, :nq, self.u_pad + 2:]}
 
     def run_steps(self, k, queries):
-        """k steps of the same batch of queries, software-pipelined.  -> last collected result: offsets [world, Q, U_pad+1],
-        lengths [world, Q], rows [world, Q, cap]; Feed(r, q, u) = rows[r, q, offsets[r,q,u] : offsets[r,q,u+1]].  None when a
-        row list outgrew the capacity (raised: call again)."""
+        """k steps of the same batch of queries, software-pipelined; the messages of steps_per_gather consecutive steps
+        travel in ONE all-gather (a collective costs tens of microseconds of host and link latency whatever it carries).
+        -> the last step's result.  lists: offsets [world, Q, U_pad+1], lengths [world, Q], rows [world, Q, cap];
+        Feed(r, q, u) = rows[r, q, offsets[r,q,u] : offsets[r,q,u+1]].  union: see the class docstring.  None when a message
+        outgrew the capacity (raised: call again)."""
         if k <= 0:
             return None
         nq = len(queries)
@@ -541,42 +549,53 @@ class BatchedFeeds:
         if self.cap is None:
             self._negotiate(queries)
         st = self._sets()
-        L, cap = st["L"], st["cap"]
+        L, cap, Qm, G = st["L"], st["cap"], st["Qm"], self.steps_per_gather
         overflow, last = False, None
-        finished, flying = None, None   # (set, ready)
+        pending, flying = None, None   # a complete group whose gather is not issued yet / issued and not collected: (set, ready, steps)
+
+        def slot_of(i):
+            return st["msg"][(i // G) % N_SETS][(i % G) * Qm * L: (i % G + 1) * Qm * L]
 
         def begin(i):
             if self.union:
                 self.backend.batch_begin(queries)
             else:
-                self.backend.batch_begin(queries, st["msg"][i % N_SETS], L, self.u_pad, cap)
+                self.backend.batch_begin(queries, slot_of(i), L, self.u_pad, cap)
+
+        def collect(t):
+            nonlocal overflow, last
+            res = self._collect(st, t[0], nq, t[2])
+            overflow = overflow or res is None
+            last = res if res is not None else last
 
         begin(0)
+        group_ready = True
         for i in range(k):
             if i + 1 < k:
                 begin(i + 1)
-            if finished is not None:
-                self._issue(st, *finished)
-            if flying is not None:
-                res = self._collect(st, flying[0], nq)
-                overflow = overflow or res is None
-                last = res if res is not None else last
-            flying, finished = finished, None
+            if pending is not None:   # the gather of the group before runs beside this group's scans
+                self._issue(st, pending[0], pending[1])
+                if flying is not None:
+                    collect(flying)
+                flying, pending = pending, None
             _, ready = self.backend.batch_finish()
-            p = i % N_SETS
+            p = (i // G) % N_SETS
             if self.union:   # the union message is packed from the finished lists, on the result stream
-                self.backend.batch_pack_union(st["msg"][p], self.u_pad, cap)
+                self.backend.batch_pack_union(slot_of(i), self.u_pad, cap)
                 ready = False
-            if self.cuda and not ready:
-                st["ev_packed"][p].record(self.rs)
-            finished = (p, ready)
-        if finished is not None:
-            self._issue(st, *finished)
-        for t in (flying, finished):
-            if t is not None:
-                res = self._collect(st, t[0], nq)
-                overflow = overflow or res is None
-                last = res if res is not None else last
+            group_ready = group_ready and ready
+            if i % G == G - 1 or i == k - 1:
+                if self.cuda and not group_ready:
+                    st["ev_packed"][p].record(self.rs)
+                pending = (p, group_ready, i % G + 1)
+                group_ready = True
+        if pending is not None:
+            self._issue(st, pending[0], pending[1])
+            if flying is not None:
+                collect(flying)
+            flying, pending = pending, None
+        if flying is not None:
+            collect(flying)
         return None if overflow else last
 
 

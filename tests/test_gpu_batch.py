@@ -285,9 +285,10 @@ def test_exchange_over_rccl_one_rank(pie, oracle):
                 assert np.array_equal(res["rows"][0].cpu().numpy()[: want[2].size], want[2])
             queries = mixed_queries(oracle, 7)
             bf = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True)
+            bf4 = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True, steps_per_gather=4)
             wants = oracle_answers(oracle, cols, U, D, queries)
-            for k in (1, 5):
-                res = bf.run_steps(k, queries)
+            for feeds_k, k in ((bf, 1), (bf, 5), (bf4, 9), (bf4, 3)):
+                res = feeds_k.run_steps(k, queries)
                 assert res is not None
                 for q, w in enumerate(wants):
                     m = w[2].size
@@ -299,8 +300,9 @@ def test_exchange_over_rccl_one_rank(pie, oracle):
             near = [(oracle.T0_MS - 6 * HOUR - 977 * q, oracle.T0_MS - (61 + q % 2) * DAY, (0x5555555555555555, ALL)[q % 2]) for q in range(8)]
             wants = oracle_answers(oracle, cols, U, D, near)
             uf = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True, union=True)
-            for k in (1, 4):
-                res = uf.run_steps(k, near)
+            uf3 = BatchedFeeds(backend, 0, 1, U, q_max=8, always_collective=True, union=True, steps_per_gather=3)   # three steps per all-gather
+            for feeds_k, k in ((uf, 1), (uf, 4), (uf3, 7), (uf3, 2)):
+                res = feeds_k.run_steps(k, near)
                 assert res is not None
                 uo = res["u_offsets"][0].cpu().numpy()
                 assert uo[0] == 0 and uo[U] == int(res["lengths"][0]) and np.all(np.diff(uo[: U + 1]) >= 0)

@@ -172,6 +172,14 @@ def _batch_worker(rank, world, port, tmp, n, U):
 
         check_union(ufeeds.run_steps(1, sparse), sparse)
         check_union(ufeeds.run_steps(5, sparse), sparse)
+        # several steps per all-gather (the collective's fixed cost is shared), for group sizes that do and do not divide k
+        for g, k in ((3, 7), (4, 4), (2, 1), (8, 5)):
+            gf = BatchedFeeds(OracleBatchBackend(oracle_py, sh, D), rank, world, sh["n_users"], q_max=6, union=True, steps_per_gather=g)
+            check_union(gf.run_steps(k, sparse), sparse)
+            gl = BatchedFeeds(OracleBatchBackend(oracle_py, sh, D), rank, world, sh["n_users"], q_max=6, steps_per_gather=g)
+            check(gl.run_steps(k, sparse), sparse)
+            assert gl.run_steps(g + 1, dense) is None   # a group that outgrows the capacity: raised for all of it, call again
+            check(gl.run_steps(g + 1, dense), dense)
         check_union(ufeeds.run_steps(3, sparse[:2]), sparse[:2])
         try:   # dense queries: hundreds of rows per user — the union form declines, the caller uses the lists
             ufeeds.run_steps(1, dense)
