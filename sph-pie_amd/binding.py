@@ -381,11 +381,19 @@ class PieScan:
         return m
 
     # ---- batched scan: Q queries (now, cutoff, mask), one table pass
+    _q_cache = None
+
     @staticmethod
     def _queries(queries):
+        # the same list of queries, batch after batch, is the common case (a pipelined loop): marshal it once
+        key = tuple(queries)
+        hit = PieScan._q_cache
+        if hit is not None and hit[0] == key:
+            return hit[1]
         arr = (PieQuery * len(queries))()
         for k, (now, cutoff, mask) in enumerate(queries):
             arr[k].now, arr[k].cutoff, arr[k].mask = int(now), int(cutoff), int(mask) & (2 ** 64 - 1)
+        PieScan._q_cache = (key, arr)
         return arr
 
     def scan_batch_begin(self, queries):
