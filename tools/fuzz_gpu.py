@@ -147,6 +147,26 @@ while time.time() < t_end:
                                 raise AssertionError(what + " batch %d query %d: M differs" % (k, qi))
                             same(ctx.batch_read_results(qi), w, what + " batch %d query %d now %d cutoff %d mask %x" % (k, qi, nw, ct, mk))
                             scans += 1
+                        if rng.random() < 0.4:   # the union exchange message of this batch: every query's list is a filter of it, in order
+                            wants = [oracle.scan(s, e, u, d, U, nw, ct, mk & lim) for nw, ct, mk in batches[k]]
+                            per_user_max = max(int(np.max(sum((w[0] for w in wants), np.zeros(U, np.int64)))), 0)
+                            u_pad, cap = U + int(rng.integers(0, 3)), int(sum(w[2].size for w in wants)) + 5
+                            msg = torch.full((u_pad + 2 + 2 * cap,), -7, dtype=torch.int32, device=dev)
+                            torch.cuda.synchronize()
+                            ctx.batch_pack_union_device(msg.data_ptr(), u_pad, cap)
+                            ctx.synchronize()
+                            a = msg.cpu().numpy()
+                            mu = int(a[u_pad + 1])
+                            if mu < 0:
+                                if per_user_max <= 32:   # the sum over the queries bounds a user's union from above
+                                    raise AssertionError(what + " batch %d: union message declined although no user has more than 32 rows" % k)
+                            else:
+                                uoff, rows_u, masks_u = a[: U + 1].astype(np.int64), a[u_pad + 2: u_pad + 2 + mu], a[u_pad + 2 + cap: u_pad + 2 + cap + mu]
+                                for qi, w in enumerate(wants):
+                                    sel = ((masks_u >> qi) & 1) == 1
+                                    csum = np.concatenate([[0], np.cumsum(sel)])
+                                    if not (np.array_equal(rows_u[sel], w[2]) and np.array_equal(csum[uoff], w[1])):
+                                        raise AssertionError(what + " batch %d query %d: union message differs" % (k, qi))
                     ctx.set_disciplines(mask, D)
                 if rng.random() < 0.3:
                     prev = int(now - rng.integers(0, 3 * DAY)) if now > INT64_MIN + 4 * DAY else INT64_MIN
