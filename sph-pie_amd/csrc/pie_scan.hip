@@ -2980,12 +2980,14 @@ int pie_batch_pack_union_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t 
         PIE_HIP(c, hipMalloc(&c->d_union_local, padded * 4));
         PIE_HIP(c, hipMalloc(&c->d_union_off, 2 * groups * 8 + 256 + 64));
         PIE_HIP(c, hipMemsetAsync(c->d_union_cnt, 0, padded * 4, s)); // entries behind the users stay zero for good
+        PIE_HIP(c, hipMemsetAsync(c->d_union_off, 0, 2 * groups * 8 + 256 + 64, s)); // incl. the prefix kernel's block counter
         c->union_users = c->cap_users;
     }
     long long* gsum = c->d_union_off;
     long long* gbase = c->d_union_off + groups;
     Summary* usum = reinterpret_cast<Summary*>(reinterpret_cast<char*>(c->d_union_off + 2 * groups));
     int* over = reinterpret_cast<int*>(reinterpret_cast<char*>(usum) + 256);
+    OrdCtl* uctl = reinterpret_cast<OrdCtl*>(reinterpret_cast<char*>(usum) + 256 + 16); // its counter returns to 0 by itself
     PIE_HIP(c, hipMemsetAsync(over, 0, 4, s));
     UnionLists lists{};
     for (int q = 0; q < b.n_q; ++q) lists.idx[q] = b.idx_of[q];
@@ -3001,9 +3003,9 @@ int pie_batch_pack_union_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t 
     long long n_groups = ((long long)c->n_users + 1023) >> 10;
     if (n_groups < 1) n_groups = 1;
     const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
+    // a hundred groups at most: the one-launch form (the block that finishes last scans the group sums)
     hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, c->d_union_cnt, (long long)c->n_users, c->d_union_local, gsum, gbase,
-                       (OrdCtl*)nullptr, usum, 0LL, 0LL, 0LL);
-    hipLaunchKernelGGL(k_ord_prefix_groups, dim3(1), dim3(256), 0, s, (long long)c->n_users, gsum, gbase, usum, 0LL, 0LL);
+                       uctl, usum, 0LL, 0LL, 0LL);
     unsigned wblocks = (unsigned)((u_pad + 2 + 255) / 256);
     if (wblocks > (unsigned)c->n_cus * 8) wblocks = (unsigned)c->n_cus * 8;
     hipLaunchKernelGGL(k_union_write, dim3(wblocks), dim3(256), 0, s, c->n_users, (int)u_pad, c->d_union_local, gbase, c->d_union_cnt, c->d_union, over,
