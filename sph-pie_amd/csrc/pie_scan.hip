@@ -974,6 +974,10 @@ int ord_alloc(pie_ctx* c)
     // positions: every row of capacity, a sixteenth more and four per user as spare slots; then whole chunks of zero keys
     const size_t positions = (size_t)c->cap_rows + (size_t)c->cap_rows / 16 + (size_t)ord_spare(c) * (size_t)c->cap_users + 64;
     const size_t padded = ((positions + 1023) / 1024) * 1024 + 1024;
+    if (padded + kOrdTile >= ((size_t)1 << 31)) { // positions are 31-bit (ring entries, staging records, pos[])
+        o.no_room = true;
+        return PIE_OK;
+    }
     // a scan stages one 4-byte entry per position in the slot's record staging (sel): a table with far more users than rows
     // (four spare slots each) does not fit there, and has no use for the run anyway
     if ((padded + kOrdTile) * 4 > (size_t)c->sel_cap * sizeof(SelRec)) {
