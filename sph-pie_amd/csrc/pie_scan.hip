@@ -131,6 +131,7 @@ struct BatchSlot {
 
 // the ordered run of the resident table (pie_ordered.h)
 struct OrderedRun {
+    int grid_mult = 12;      // PIE_ORD_GRID: blocks per CU of the key-stream kernels on the 1-byte key
     int mode = 1;            // PIE_ORDERED: 0 = never, 1 = when the general path is weak (dense / skewed queries), 2 = always
     bool valid = false;
     long long n = 0;         // positions (= rows the all-selecting scan returned)
@@ -1261,14 +1262,9 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
     const long long units_stride = o.units_cap, group_stride = o.units_cap / 1024 + 2, sum_stride = (long long)ord_sum_bytes();
     Summary* sum0 = reinterpret_cast<Summary*>(sums);
     if (fine) {
-        const int gm = getenv("PIE_ORD_GRID") ? atoi(getenv("PIE_ORD_GRID")) : 12;
+        const int gm = o.grid_mult;
         long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * gm ? (n_chunks + 3) / 4 : (long long)c->n_cus * gm;
         if (grid < 1) grid = 1;
-        if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 8)
-            hipLaunchKernelGGL((k_ord_batch_scan<fkey_t, 8>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
-        else if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 2)
-            hipLaunchKernelGGL((k_ord_batch_scan<fkey_t, 2>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
-        else
         hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
     } else {
         long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
@@ -1340,16 +1336,9 @@ void launch_ordered(pie_ctx* c, Slot& sl, hipStream_t s, long long now, long lon
     } else if (fine) {
         unit_shift = 9;
         n_units = (o.n + 511) >> 9;
-        const int gm = getenv("PIE_ORD_GRID") ? atoi(getenv("PIE_ORD_GRID")) : 12; // blocks per CU (profiles/r02_ze_ord_keyed_grid_unroll_sweep.txt)
+        const int gm = o.grid_mult; // blocks per CU (profiles/r02_ze_ord_keyed_grid_unroll_sweep.txt: 12 beats 4 .. 10; the unroll does not matter)
         long long grid = (n_units + 3) / 4 < (long long)c->n_cus * gm ? (n_units + 3) / 4 : (long long)c->n_cus * gm;
         if (grid < 1) grid = 1;
-        if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 8)
-            hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t, 8>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
-                               host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
-        else if (getenv("PIE_ORD_UNROLL") && atoi(getenv("PIE_ORD_UNROLL")) == 2)
-            hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t, 2>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
-                               host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
-        else
         hipLaunchKernelGGL((k_ord_scan_keyed<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_units, now,
                            host_fine_key_of(c, now), cutoff, mask, stage, uc, sum);
         sl.variant = 0x2C00;
@@ -2339,6 +2328,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_RUN_SHIFT")) { const int r = atoi(v); if (r >= 0 && r <= 3) { c->run_shift = r; c->run_shift_pinned = true; } }
     if (const char* v = getenv("PIE_ORDERED")) { const int m = atoi(v); if (m >= 0 && m <= 2) c->ord.mode = m; }
+    if (const char* v = getenv("PIE_ORD_GRID")) { const int g = atoi(v); if (g >= 1 && g <= 64) c->ord.grid_mult = g; }
     if (const char* v = getenv("PIE_WAIT_DEADLINE_MS")) { const double d = atof(v); if (d > 0) c->wait_deadline_ms = d; }
     if (const char* v = getenv("PIE_K1_KEYED")) {
         const int k = (int)strtol(v, nullptr, 0);
