@@ -87,9 +87,13 @@ __global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx,
 // order — behind every row whose start is not above its own: the new row has the largest row id.  A session store creates
 // sessions now, so that place is almost always the end of the segment (one compare); a row that arrives a little late
 // (clock jitter between front-ends, a batch that is not sorted, a corpus whose last sessions lie "after now") shifts the
-// few rows behind it by one slot.  All rows of one user in a batch are handled by ONE thread — the one whose row is the
-// user's first in the batch — in batch order, so rows of the same user never race; different users are different threads.
-// O(batch) + the shifts per row of the batch, nothing per row of the table.
+// few rows behind it by one slot.  All rows of one user in a batch are handled by ONE thread, so rows of the same user never
+// race; different users are different threads.  k_ord_append_mark threads the batch's rows of each user on a chain (one
+// atomicExch per row: bhead[u] = the row that came last, bnext[row] = the one before it); the thread of the chain's head walks
+// it.  The chain's order is whatever order the exchanges took, so a row's place is found on (start, row), not on start alone:
+// the rows of one user then end up in order however the chain runs.
+// O(batch) + the shifts per row of the batch, nothing per row of the table — and nothing per row of the batch either: a thread
+// that searched the batch for its user's later rows made the kernel as slow as its longest search (80 us per 1 000 rows).
 //   placed[t] = pass   the row went into the run in this pass
 //   stale[0]++         the row would have to move more than kOrdShiftMax rows (a back-fill, not a session store's append):
 //                      the host drops the run
@@ -98,56 +102,61 @@ __global__ __launch_bounds__(256) void k_ord_gather(const int* __restrict__ idx,
 // stale[] is mapped host memory, read by the host after the append's one synchronisation.
 constexpr int kOrdShiftMax = 256;
 
+// first pass of an append: the chains (bhead[] rests at -1 between appends: the thread that walks a chain puts it back)
+__global__ __launch_bounds__(256) void k_ord_append_mark(const int* __restrict__ st_user, int k, int n_users, const int* __restrict__ placed_in,
+                                                         int pass, int* __restrict__ bhead, int* __restrict__ bnext)
+{
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= k) return;
+    const int u = st_user[t];
+    if ((unsigned)u >= (unsigned)n_users || (pass > 1 && placed_in[t] != 0)) return;
+    bnext[t] = atomicExch(&bhead[u], t);
+}
+
 __global__ __launch_bounds__(256) void k_ord_append(const long long* __restrict__ st_start, const long long* __restrict__ st_end,
                                                     const int* __restrict__ st_user, const int* __restrict__ st_disc, int k,
                                                     long long row0, int n_users, long long key_base, int key_shift, long long fkey_base,
                                                     int fkey_shift, const long long* __restrict__ uoff, int* __restrict__ ufill,
                                                     OrdRec* __restrict__ o_pay, long long* __restrict__ o_end, lkey_t* __restrict__ o_key,
                                                     fkey_t* __restrict__ o_fkey, int* __restrict__ pos, unsigned int* __restrict__ stale,
-                                                    const int* __restrict__ placed_in, int* __restrict__ placed, int* __restrict__ pend, int pass)
+                                                    const int* __restrict__ placed_in, int* __restrict__ placed, int* __restrict__ pend, int pass,
+                                                    int* __restrict__ bhead, const int* __restrict__ bnext)
 {
-    // the users of the batch's rows, in LDS (pass 2: a row that pass 1 placed is in its segment already: entry -1)
-    __shared__ __attribute__((aligned(16))) int lu[4096];
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    for (int e = threadIdx.x; e < ((k + 3) & ~3); e += blockDim.x) lu[e] = (e < k && (pass == 1 || placed_in[e] == 0)) ? st_user[e] : -1;
-    __syncthreads();
     if (t >= k) return;
-    const int u = lu[t];
-    if ((unsigned)u >= (unsigned)n_users) { // pass 1: the whole append is rejected by the caller; pass 2: nothing left to do for this row
+    const int u = st_user[t];
+    if ((unsigned)u >= (unsigned)n_users) { // pass 1: the whole append is rejected by the caller
         if (pass == 1) placed[t] = 0;
         return;
     }
-    // rows of my user before / behind mine in the batch: counted four at a time without an early exit (a loop that may leave
-    // at every entry waits for every LDS read in turn: 90 us for a batch of 1 000)
-    int before = 0, later = 0;
-    const int k4 = (k + 3) & ~3; // lu[] entries in [k, k4) are never equal to a valid user: set below
-    for (int e0 = 0; e0 < k4; e0 += 4) {
-        const int4 v = *reinterpret_cast<const int4*>(&lu[e0]);
-        const int m0 = v.x == u, m1 = v.y == u, m2 = v.z == u, m3 = v.w == u;
-        before += (m0 & (e0 < t)) + (m1 & (e0 + 1 < t)) + (m2 & (e0 + 2 < t)) + (m3 & (e0 + 3 < t));
-        later += (m0 & (e0 > t)) + (m1 & (e0 + 1 > t)) + (m2 & (e0 + 2 > t)) + (m3 & (e0 + 3 > t));
-    }
-    if (before) return; // an earlier row of the batch has my user: its thread places mine too
+    if (pass > 1 && placed_in[t] != 0) return; // pass 2: only what pass 1 left over
+    if (bhead[u] != t) return;                 // another row of the batch heads my user's chain: its thread places mine too
+    bhead[u] = -1;                             // back to rest for the next append (only this thread touches user u now)
     int fill = ufill[u];
     const long long seg = uoff[u];
     const long long cap = uoff[u + 1] - seg;
     auto place = [&](int e) { // insert row e of the batch into my user's segment
         const long long sv = st_start[e];
-        int at = fill; // behind every row whose start is <= sv: usually the end of the segment
-        if (fill > 0 && o_pay[seg + fill - 1].start > sv) {
-            int lo = 0, hi = fill - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (o_pay[seg + mid].start <= sv) lo = mid + 1;
-                else hi = mid;
-            }
-            at = lo;
-        }
+        const int row = (int)(row0 + e);
         if (fill >= cap) {
             placed[e] = 0;
             if (pend) pend[u] += 1;
             __hip_atomic_fetch_add(&stale[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
+        }
+        int at = fill; // behind every row that is before it in (start, row): usually the end of the segment
+        if (fill > 0) {
+            const OrdRec last = o_pay[seg + fill - 1];
+            if (!key_less(last.start, last.row, sv, row)) {
+                int lo = 0, hi = fill - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const OrdRec m = o_pay[seg + mid];
+                    if (key_less(m.start, m.row, sv, row)) lo = mid + 1;
+                    else hi = mid;
+                }
+                at = lo;
+            }
         }
         if (fill - at > kOrdShiftMax) {
             placed[e] = 0;
@@ -165,27 +174,59 @@ __global__ __launch_bounds__(256) void k_ord_append(const long long* __restrict_
         const long long ev = st_end[e];
         OrdRec o;
         o.start = sv;
-        o.row = (int)(row0 + e);
+        o.row = row;
         o.disc = st_disc[e];
         o_pay[seg + at] = o;
         o_end[seg + at] = ev;
         o_key[seg + at] = (lkey_t)key_of(ev, key_base, key_shift);
         o_fkey[seg + at] = (fkey_t)key_of(ev, fkey_base, fkey_shift, kFineKeyMax);
-        pos[row0 + e] = (int)(seg + at);
+        pos[row] = (int)(seg + at);
         placed[e] = pass;
         ++fill;
     };
-    if (later == 0) place(t); // the usual case: one row of this user in the batch — no second look at the batch
-    else {
-        int todo = later + 1; // my row and the later ones of my user, in batch order
-        for (int e0 = t & ~3; e0 < k4 && todo > 0; e0 += 4) {
-            const int4 v = *reinterpret_cast<const int4*>(&lu[e0]);
-            if (!((v.x == u) | (v.y == u) | (v.z == u) | (v.w == u))) continue;
-            for (int e = e0 < t ? t : e0; e < e0 + 4; ++e)
-                if (lu[e] == u) {
-                    --todo;
-                    place(e);
-                }
+    // the chain in batch order (then a row's place is the end of the segment and nothing shifts).  One row, nearly always; up to
+    // four are sorted in registers; a longer chain (one user, five sessions in one batch) is read off the batch itself.
+    int c0 = t, c1 = bnext[t], c2 = -1, c3 = -1, more = -1;
+    if (c1 >= 0) {
+        c2 = bnext[c1];
+        if (c2 >= 0) {
+            c3 = bnext[c2];
+            if (c3 >= 0) more = bnext[c3];
+        }
+    }
+    if (c1 < 0) place(c0);
+    else if (more < 0) {
+        constexpr int kNone = 0x7FFFFFFF;
+        if (c2 < 0) c2 = kNone;
+        if (c3 < 0) c3 = kNone;
+        auto order = [](int& a, int& b) {
+            const int lo = min(a, b), hi = max(a, b);
+            a = lo;
+            b = hi;
+        };
+        order(c0, c1);
+        order(c2, c3);
+        order(c0, c2);
+        order(c1, c3);
+        order(c1, c2);
+        place(c0);
+        place(c1);
+        if (c2 != kNone) place(c2);
+        if (c3 != kNone) place(c3);
+    } else {
+        for (int b = 0; b < k; b += 64) { // 64 users of the batch per step (the reads past k stay inside the staging block)
+            const int4* v = reinterpret_cast<const int4*>(st_user + b);
+            unsigned long long hit = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int4 x = v[j];
+                hit |= (unsigned long long)((x.x == u) | ((x.y == u) << 1) | ((x.z == u) << 2) | ((x.w == u) << 3)) << (4 * j);
+            }
+            while (hit) {
+                const int e = b + __builtin_ctzll(hit);
+                hit &= hit - 1;
+                if (e < k && (pass == 1 || placed_in[e] == 0)) place(e);
+            }
         }
     }
     ufill[u] = fill;

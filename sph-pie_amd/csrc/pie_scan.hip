@@ -130,6 +130,8 @@ struct BatchSlot {
 };
 
 // the ordered run of the resident table (pie_ordered.h)
+constexpr int kOrdAppendMax = 4096; // rows of one append the run takes in place (a larger append drops the run)
+
 struct OrderedRun {
     int grid_mult = 12;      // PIE_ORD_GRID: blocks per CU of the key-stream kernels on the 1-byte key
     int mode = 1;            // PIE_ORDERED: 0 = never, 1 = when the general path is weak (dense / skewed queries), 2 = always
@@ -147,6 +149,8 @@ struct OrderedRun {
     long long* uoff = nullptr;               // [users + 1] first position of every user's segment (rows, then spare slots)
     int* ufill = nullptr;                    // [users] rows in the segment
     int* pend = nullptr;                     // [users] rows of an append that found their segment full (re-spread)
+    int* bhead = nullptr;                    // [users] head of the user's chain of rows in the append in progress (-1 between appends)
+    int* bnext = nullptr;                    // [kOrdAppendMax] the chains: the row of the same user that came before this one, or -1
     int* placed = nullptr;                   // [2][4096] outcome per row of the append in progress (+ the copy pass 2 reads)
     OrdRec* alt_pay = nullptr;               // the arrays a re-spread moves the run into (allocated at the first one), then swapped
     long long* alt_end = nullptr;
@@ -375,7 +379,7 @@ void free_batch(pie_ctx* c)
 void ord_free(pie_ctx* c)
 {
     OrderedRun& o = c->ord;
-    dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed);
+    dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed); dfree(o.bhead); dfree(o.bnext);
     dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
     dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
     dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
@@ -992,7 +996,8 @@ int ord_alloc(pie_ctx* c)
                     hipMalloc(&o.pos, (size_t)c->cap_rows * 4 + 64) == hipSuccess &&
                     hipMalloc(&o.uoff, ((size_t)c->cap_users + 1) * 8) == hipSuccess &&
                     hipMalloc(&o.ufill, ((size_t)c->cap_users + 1) * 4) == hipSuccess &&
-                    hipMalloc(&o.pend, ((size_t)c->cap_users + 1) * 4) == hipSuccess && hipMalloc(&o.placed, 2 * 4096 * 4) == hipSuccess &&
+                    hipMalloc(&o.pend, ((size_t)c->cap_users + 1) * 4) == hipSuccess && hipMalloc(&o.placed, 2 * (size_t)kOrdAppendMax * 4) == hipSuccess &&
+                    hipMalloc(&o.bhead, ((size_t)c->cap_users + 1) * 4) == hipSuccess && hipMalloc(&o.bnext, (size_t)kOrdAppendMax * 4) == hipSuccess &&
                     hipMalloc(&o.unit_count[0], units * 4) == hipSuccess && hipMalloc(&o.unit_count[1], units * 4) == hipSuccess &&
                     hipMalloc(&o.unit_local, units * 4) == hipSuccess && hipMalloc(&o.group_sum, (units / 1024 + 2) * 8) == hipSuccess &&
                     hipMalloc(&o.group_base, (units / 1024 + 2) * 8) == hipSuccess &&
@@ -1083,6 +1088,7 @@ int build_ordered(pie_ctx* c)
     PIE_HIP(c, hipMemcpyAsync(o.uoff, seg.data(), ((size_t)seg_users + 1) * 8, hipMemcpyHostToDevice, s));
     PIE_HIP(c, hipMemcpyAsync(o.ufill, cnt.data(), ((size_t)seg_users + 1) * 4, hipMemcpyHostToDevice, s));
     PIE_HIP(c, hipMemsetAsync(o.pend, 0, ((size_t)seg_users + 1) * 4, s));
+    PIE_HIP(c, hipMemsetAsync(o.bhead, 0xFF, ((size_t)seg_users + 1) * 4, s));
     PIE_HIP(c, hipMemsetAsync(o.pos, 0xFF, (size_t)o.cap * 4, s));
     PIE_HIP(c, hipMemsetAsync(o.pay, 0xFF, padded * sizeof(OrdRec), s)); // filler: discipline -1, never selected
     PIE_HIP(c, hipMemsetAsync(o.end, 0, padded * 8, s));
@@ -1119,18 +1125,17 @@ int build_ordered(pie_ctx* c)
     return PIE_OK;
 }
 
-constexpr int kOrdAppendMax = 4096; // rows of one append the run takes (each row looks at the batch's earlier rows)
-
 void launch_ord_append(pie_ctx* c, hipStream_t s, size_t k, long long row0, int n_users, int pass)
 {
     OrderedRun& o = c->ord;
     const unsigned grid = (unsigned)((k + 255) / 256);
     const int* st_user = reinterpret_cast<const int*>(c->d_stage + k * 16);
     if (pass == 2) (void)hipMemcpyAsync(o.placed + kOrdAppendMax, o.placed, k * 4, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_ord_append_mark, dim3(grid), dim3(256), 0, s, st_user, (int)k, n_users, o.placed + kOrdAppendMax, pass, o.bhead, o.bnext);
     hipLaunchKernelGGL(k_ord_append, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(c->d_stage),
                        reinterpret_cast<const long long*>(c->d_stage + k * 8), st_user, reinterpret_cast<const int*>(c->d_stage + k * 20), (int)k,
                        row0, n_users, c->key_base, c->key_shift, c->fkey_base, c->fkey_shift, o.uoff, o.ufill, o.pay, o.end, o.key, o.fkey,
-                       o.pos, o.stale, o.placed + kOrdAppendMax, o.placed, pass == 1 ? o.pend : (int*)nullptr, pass);
+                       o.pos, o.stale, o.placed + kOrdAppendMax, o.placed, pass == 1 ? o.pend : (int*)nullptr, pass, o.bhead, o.bnext);
 }
 
 // Segments are full: give every user fresh spare slots (its rows, the rows of this append still waiting, a sixteenth more,
