@@ -86,7 +86,8 @@ struct HostSummary {
 struct alignas(128) StatSlot {
     unsigned long long live, amb, cand;
     unsigned long long chunk_max; // max over the blocks of this slot
-    unsigned long long pad[12];
+    unsigned long long max_count; // largest per-user count the blocks of this slot saw (k_ord_batch_emit; k_ord_publish folds it in)
+    unsigned long long pad[11];
 };
 constexpr int kStatSlots = 64;
 constexpr int kSummaryBytes = 128; // Summary, padded: the slots start here

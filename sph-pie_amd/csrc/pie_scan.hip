@@ -164,6 +164,7 @@ struct OrderedRun {
     long long* bq_gsum = nullptr;
     long long* bq_gbase = nullptr;
     OrdCtl* bq_ctl = nullptr;
+    int* bq_runflag = nullptr;               // [units / 32] the run of 32 chunks holds too many records for one wave (k_ord_batch_count -> k_ord_batch_emit)
     char* bq_sum[2] = {nullptr, nullptr};
     int users = 0;                           // users that have a segment (>= n_users: room for users yet to come)
     long long pos_cap = 0;                   // positions the arrays hold
@@ -381,7 +382,7 @@ void ord_free(pie_ctx* c)
     OrderedRun& o = c->ord;
     dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed); dfree(o.bhead); dfree(o.bnext);
     dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
-    dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
+    dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
     dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
     dfree(o.sum[0]); dfree(o.sum[1]);
     o.valid = false;
@@ -1214,12 +1215,12 @@ int ord_batch_alloc(pie_ctx* c)
                     hipMalloc(&o.bq_local, (size_t)kBatchMax * units * 4) == hipSuccess &&
                     hipMalloc(&o.bq_gsum, (size_t)kBatchMax * groups * 8) == hipSuccess &&
                     hipMalloc(&o.bq_gbase, (size_t)kBatchMax * groups * 8) == hipSuccess &&
-                    hipMalloc(&o.bq_ctl, (size_t)kBatchMax * sizeof(OrdCtl)) == hipSuccess &&
+                    hipMalloc(&o.bq_ctl, (size_t)kBatchMax * sizeof(OrdCtl)) == hipSuccess && hipMalloc(&o.bq_runflag, (units / 32 + 2) * 4) == hipSuccess &&
                     hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess &&
                     hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
-        dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
+        dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
         return PIE_E_NOMEM;
     }
     PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kBatchMax * sizeof(OrdCtl), c->stream));
@@ -1277,7 +1278,7 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
         hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
     }
     if (b.ev_index >= 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
-    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, b.n_q, o.bq_count, units_stride);
+    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, b.n_q, o.bq_count, units_stride, o.bq_runflag);
     long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
     if (n_groups < 1) n_groups = 1;
     const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
@@ -1288,7 +1289,7 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
     const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
     hipLaunchKernelGGL(k_ord_batch_emit, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks,
                        b.n_q, ustage, uc, o.bq_local, o.bq_gbase, units_stride, group_stride, o.pay, b.out_idx, batch_out_stride(c), b.offsets,
-                       b.counts_ord, batch_users_stride(c), copy_blocks, sum0, sum_stride, uc_other, o.units_cap);
+                       b.counts_ord, batch_users_stride(c), copy_blocks, sum0, sum_stride, uc_other, o.units_cap, o.bq_runflag, o.bq_count);
     hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)b.n_q), dim3(64), 0, s, sum0, b.h_sum_dev, b.seq, sum_stride);
 }
 
