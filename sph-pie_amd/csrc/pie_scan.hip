@@ -1105,7 +1105,7 @@ int build_ordered(pie_ctx* c)
         PIE_HIP(c, hipGetLastError());
     }
     PIE_HIP(c, hipStreamSynchronize(s));
-    *o.h_stale = 0;
+    o.h_stale[0] = o.h_stale[1] = 0;
     // the build's scan is not a result: the caller's last one (in the other slot) stays readable, and the next scan takes
     // the slot it would have taken
     built->have_result = false;
@@ -2450,7 +2450,10 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
         PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
         PIE_HIP(c, hipStreamSynchronize(s));
         if (c->h_summary->bad_rows) { // the rows were written beyond n: the table itself is unchanged
-            if (ord_kept) ord_invalidate(c); // ... but some of them may sit in the run's spare slots
+            if (ord_kept) { // ... but some of them may sit in the run's spare slots
+                ord_invalidate(c);
+                c->ord.h_stale[0] = c->ord.h_stale[1] = 0;
+            }
             return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", c->h_summary->bad_rows, n_users);
         }
         c->n = old_n + (long long)k;

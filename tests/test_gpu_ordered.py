@@ -238,6 +238,48 @@ def test_ordered_run_takes_appends_in_time_order(pie, oracle):
         assert ctx.table_info()["ordered_rows"] == 0
         all_queries("back-fill", n_users)
 
+def test_ordered_run_rejected_append_and_chains_of_one_user(pie, oracle):
+    """an append that carries a user id outside the table is rejected as a whole: the table is unchanged, the run (some of the
+    rows may already sit in its spare slots) is dropped and rebuilt by the next scan; batches with 2, 3, 4 and 5+ rows of one user
+    with equal starts (the chain of a user's rows is put in batch order: in registers up to four, off the batch beyond) keep
+    (start, row) order"""
+    n, U, D = 100000, 400, 8
+    t0 = oracle.T0_MS
+    s, e, u, d = [c.copy() for c in oracle.gen(SEED + 21, n, 0, n, U, D, 0)]
+    qs = [(t0 + HOUR, t0 - 61 * DAY, ALL), (INT64_MIN, INT64_MIN, ALL)]
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(s, e, u, d, U)
+        ctx.set_ordered_run(2)
+        now = t0 + HOUR
+        ctx.append_rows(np.array([now], np.int64), np.array([now + HOUR], np.int64), np.array([0], np.int32), np.array([0], np.int32), U)  # capacity growth
+        s, e, u, d = np.append(s, now), np.append(e, now + HOUR), np.append(u, 0).astype(np.int32), np.append(d, 0).astype(np.int32)
+        for k, q in enumerate(qs):
+            check(ctx, oracle, (s, e, u, d), U, D, q, f"grown q{k}")
+        builds = ctx.table_info()["ordered_builds"]
+        bad_u = np.array([3, 3, U + 5, 9], np.int32)
+        with pytest.raises(Exception):
+            ctx.append_rows(np.full(4, now + 1, np.int64), np.full(4, now + HOUR, np.int64), bad_u, np.zeros(4, np.int32), U)
+        assert ctx.table_info()["ordered_rows"] == 0
+        for k, q in enumerate(qs):
+            check(ctx, oracle, (s, e, u, d), U, D, q, f"after the rejected append q{k}")
+        assert ctx.table_info()["ordered_builds"] == builds + 1
+        respreads = ctx.table_info()["ordered_respreads"]
+        for step, users in enumerate(([5, 5], [6, 1, 6, 6], [7, 7, 2, 7, 7], [8] * 5 + [1], [9, 3] * 6, list(range(20)) + [4] * 7)):
+            u2 = np.array(users, np.int32)
+            k = u2.size
+            s2 = np.full(k, now + 10 * (step + 1), np.int64)                      # equal starts: order is by row
+            if step % 2:
+                s2[::2] += 1                                                      # and not in time order inside the batch
+            e2 = s2 + HOUR + np.arange(k)
+            d2 = (np.arange(k) % D).astype(np.int32)
+            ctx.append_rows(s2, e2, u2, d2, U)
+            s, e, u, d = np.concatenate([s, s2]), np.concatenate([e, e2]), np.concatenate([u, u2]).astype(np.int32), np.concatenate([d, d2]).astype(np.int32)
+            info = ctx.table_info()
+            assert info["ordered_rows"] == s.size and info["ordered_builds"] == builds + 1 and info["ordered_respreads"] == respreads, (step, info)
+            for k2, q in enumerate(qs):
+                check(ctx, oracle, (s, e, u, d), U, D, (q[0] if q[0] == INT64_MIN else now + 20 * HOUR, q[1], q[2]), f"chains step {step} q{k2}")
+
+
 def test_ordered_run_is_built_when_the_general_path_is_weak(pie, oracle):
     """mode 1 (the default): sparse queries on evenly spread users never build it; the second dense query in a row does,
     and from then on dense queries use it while sparse ones stay on the keyed general path; skewed users call for it too."""
