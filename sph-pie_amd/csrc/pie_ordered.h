@@ -795,12 +795,12 @@ __global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summar
 // its batches used to run as Q single scans, each streaming the key column again.  On the run a batch is ONE pass: the
 // candidates are the positions whose key reaches the smallest key(now) of the batch, every candidate is evaluated against
 // all queries (one 16-byte gather, `end` only where some query's key cannot decide), and a position that any query selects
-// is staged once, in position order, as {position, query mask}.
+// is staged once, in position order, as {row id, query mask + position inside the chunk}.
 //   k_ord_batch_scan    key stream -> union staging records + per-chunk union counts
 //   k_ord_batch_count   per chunk and query: how many of the chunk's records carry the query's bit (a lane per chunk; heavy
 //                       chunks by whole waves); which runs of 32 chunks are too heavy for one wave
 //   k_ord_prefix        (gridDim.y = Q) per-query exclusive prefix of those counts
-//   k_ord_batch_emit    per run of 32 chunks (heavy runs: per chunk): every query's row list (the record's row id is fetched once, then compacted per query
+//   k_ord_batch_emit    per run of 32 chunks (heavy runs: per chunk): every query's row list (the row id comes with the record, compacted per query
 //                       by ballot); per user: every query's offset and count
 //   k_ord_publish       (gridDim.x = Q) summaries
 struct OrdBatchQuery {
@@ -814,10 +814,15 @@ struct OrdBatchArgs {
     unsigned min_key;
     OrdBatchQuery q[kBatchMax];
 };
+// A union staging record lives in its chunk's 512 slots, so its position is the chunk + 9 bits; with the 16 query bits that
+// leaves a whole word for the row id: the emit kernel reads the row where it reads the mask, not through a second, dependent
+// gather at the position (the copy role's 33 us were two such round trips per record).
 struct alignas(8) OrdUnion {
-    unsigned pos;
-    unsigned qmask;
+    int row;
+    unsigned qsub; // bits 0..15: the queries that select the row; bits 16..24: its position inside the chunk
 };
+static_assert(kBatchMax <= 16, "OrdUnion keeps the query mask in 16 bits");
+constexpr unsigned kOrdSubMask = 511u; // k_ord_batch_scan's chunk: 512 positions for both key widths
 
 // A chunk is 512 positions for both key widths: 8 one-byte keys (one 8-byte load) or 8 two-byte keys (one 16-byte load) per
 // lane.  The candidate ring then takes 5 / 6 KiB per wave instead of 10, and two to three times as many waves fit a CU —
@@ -887,8 +892,8 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
         const int new_cnt = __shfl(rank, last, kWave) + 1;
         if (sel) {
             OrdUnion r;
-            r.pos = (unsigned)a_pos;
-            r.qmask = qmask;
+            r.row = a_pay.row;
+            r.qsub = qmask | (((unsigned)a_pos & kOrdSubMask) << 16);
             ustage[((long long)ch << kChunkShift) + rank] = r;
             if (last_of_seg && ch != new_chunk) ucount[ch] = rank + 1;
         }
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_count(const OrdUnion* __restr
         if (cnt <= kOrdChunkHeavy) {
             const OrdUnion* rec = ustage + (ch << chunk_shift);
             for (int j = 0; j < cnt; ++j) {
-                const unsigned qm = rec[j].qmask;
+                const unsigned qm = rec[j].qsub;
 #pragma unroll
                 for (int q = 0; q < kBatchMax; ++q) tot[q] += (qm >> q) & 1u;
             }
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_count(const OrdUnion* __restr
             const OrdUnion* lrec = ustage + (lch << chunk_shift);
             int tot = 0; // lane q < n_q ends up with query q's count
             for (int j0 = 0; j0 < lcnt; j0 += 64) {
-                const unsigned qm = j0 + lane < lcnt ? lrec[j0 + lane].qmask : 0u;
+                const unsigned qm = j0 + lane < lcnt ? lrec[j0 + lane].qsub : 0u;
                 for (int q = 0; q < n_q; ++q) {
                     const int c = __popcll(__ballot((qm >> q) & 1u));
                     if (lane == q) tot += c;
@@ -1097,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
 #pragma unroll
             for (int q = 0; q < kBatchMax; ++q) {
                 if (q >= n_q) break; // wave-uniform
-                const bool sel = (r.qmask >> q) & 1u;
+                const bool sel = (r.qsub >> q) & 1u;
                 const unsigned long long b = __ballot(sel);
                 if (b == 0) continue;
                 const long long base_q = __shfl(next, q, kWave);
@@ -1121,8 +1126,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
             __builtin_amdgcn_wave_barrier();
             for (int j0 = 0; j0 < total; j0 += 64) {
                 OrdUnion r;
-                r.pos = 0; r.qmask = 0;
-                int row = 0;
+                r.row = 0; r.qsub = 0;
                 const int j = j0 + lane;
                 if (j < total) {
                     int lo = 0, hi = kOrdRun - 1; // the first chunk whose inclusive prefix is above j
@@ -1133,9 +1137,8 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
                     }
                     const int before = lo ? incl_s[lo - 1] : 0;
                     r = ustage[((ch0 + lo) << chunk_shift) + (j - before)];
-                    row = pay[r.pos].row;
                 }
-                put(r, row, next);
+                put(r, r.row, next);
             }
         }
         // Pass 2: the chunks of the heavy runs, chunk ch by wave ch mod n_waves (neighbouring chunks go to different waves)
@@ -1151,13 +1154,9 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
                 if (lane < n_q) next = group_base[(long long)lane * group_stride + (lch >> kOrdGroupShift)] + unit_local[(long long)lane * unit_stride + lch];
                 for (int j0 = 0; j0 < lcnt; j0 += 64) {
                     OrdUnion r;
-                    r.pos = 0; r.qmask = 0;
-                    int row = 0;
-                    if (j0 + lane < lcnt) {
-                        r = ustage[(lch << chunk_shift) + j0 + lane];
-                        row = pay[r.pos].row;
-                    }
-                    put(r, row, next);
+                    r.row = 0; r.qsub = 0;
+                    if (j0 + lane < lcnt) r = ustage[(lch << chunk_shift) + j0 + lane];
+                    put(r, r.row, next);
                 }
                 todo &= todo - 1;
             }
@@ -1183,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
             int lo = 0, hi = cnt;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (rec[mid].pos < (unsigned)qpos) lo = mid + 1;
+                if ((rec[mid].qsub >> 16) < ((unsigned)qpos & kOrdSubMask)) lo = mid + 1; // same chunk: compare inside it
                 else hi = mid;
             }
             jb = lo;
@@ -1200,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
     if (!heavy && j_hi > j_lo) {
         const OrdUnion* rec = ustage + (ch << chunk_shift);
         for (int j = j_lo; j < j_hi; ++j) {
-            const unsigned qm = rec[j].qmask;
+            const unsigned qm = rec[j].qsub;
 #pragma unroll
             for (int q = 0; q < kBatchMax; ++q) below[q] += (qm >> q) & 1u;
         }
@@ -1215,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
 #pragma unroll
         for (int q = 0; q < kBatchMax; ++q) tot[q] = 0;
         for (int j0 = l_lo; j0 < l_hi; j0 += 64) {
-            const unsigned qm = j0 + lane < l_hi ? lrec[j0 + lane].qmask : 0u;
+            const unsigned qm = j0 + lane < l_hi ? lrec[j0 + lane].qsub : 0u;
 #pragma unroll
             for (int q = 0; q < kBatchMax; ++q) {
                 if (q >= n_q) break;
