@@ -191,6 +191,10 @@ def main():
     ap.add_argument("--exchange", choices=["union", "lists"], default="union",
                     help="multi-GPU, batched scans: what a step's all-gather moves — union: per user the union of the Q row lists "
                          "+ a query mask per row (an eighth of the bytes; falls back to lists on skewed users); lists: Q messages")
+    ap.add_argument("--transport", choices=["nccl", "gloo"], default=os.environ.get("PIE_BENCH_TRANSPORT", "nccl"),
+                    help="multi-GPU: nccl = RCCL over xGMI (the product path); gloo = the ranks' messages staged through pinned host "
+                         "memory and exchanged between CPU tensors — the rehearsal transport (several ranks on one GPU with "
+                         "PIE_BENCH_DEVICE=0, where RCCL refuses to form a group); everything else is the code the RCCL run executes")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="every n-th timed step carries HIP events around the scan kernels (each pair drains the stream for a "
                          "few microseconds); 0 = min(16, steps // 3), i.e. at least three samples")
@@ -240,7 +244,12 @@ def main():
     if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.transport == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if args.transport == "nccl" else torch.device("cpu")   # where the small control collectives run
+    transport = "device" if args.transport == "nccl" else "host"
 
     flags = (pie.PIE_GEN_INTERVAL if args.variant == "interval" else 0) | (pie.PIE_GEN_CLUSTERED if args.order == "clustered" else 0) | \
         (pie.PIE_GEN_TIME_ORDERED if args.order == "time" else 0)
@@ -281,7 +290,7 @@ def main():
     backend = HipShardBackend(ctx, dev) if gather else None
     # --gather-batch scans per all-gather: the collective is latency-bound at this size, so the same lists travel in
     # fewer, larger messages
-    feeds = ShardedFeeds(backend, rank, world, u_local, always_collective=gather, batch=args.gather_batch) if gather else None
+    feeds = ShardedFeeds(backend, rank, world, u_local, always_collective=gather, batch=args.gather_batch, transport=transport) if gather else None
 
     expired_window = (T0_MS - 30 * DAY, T0_MS - 29 * DAY)   # one day of expiries: ~0.83 % of the rows queue up
     Q = max(1, min(args.queries_per_launch, pie.PIE_BATCH_MAX))
@@ -289,7 +298,7 @@ def main():
     # same day's cutoff, same role mask; query 0 is the single-query workload
     batch_queries = [(now - 977 * q, cutoff, mask) for q in range(Q)]
     bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=args.exchange == "union",
-                          steps_per_gather=args.gather_batch) if gather and Q > 1 else None
+                          steps_per_gather=args.gather_batch, transport=transport) if gather and Q > 1 else None
     exchange_state = {"format": args.exchange if bfeeds is not None else None, "fallback": None}
 
     def exchange_steps(k):
@@ -306,7 +315,8 @@ def main():
             while ctx._batches:   # nothing of the declined run stays in flight
                 ctx.scan_batch_finish()
             exchange_state["format"], exchange_state["fallback"] = "lists", str(ex)
-            bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=False, steps_per_gather=args.gather_batch)
+            bfeeds = BatchedFeeds(backend, rank, world, u_local, q_max=Q, always_collective=gather, union=False, steps_per_gather=args.gather_batch,
+                                  transport=transport)
             return exchange_steps(k)
 
     def run_steps(k):
@@ -376,7 +386,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if gather:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -450,7 +460,7 @@ def main():
             ok = int(last["lengths"][rank]) == own_idx.size and \
                 np.array_equal(last["offsets"][rank].cpu().numpy()[: u_local + 1], own_off.astype(np.int32)) and \
                 np.array_equal(last["rows"][rank].cpu().numpy()[: own_idx.size], own_idx)
-        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         gather_ok = bool(int(t_ok.item()))
         if not gather_ok:
@@ -464,7 +474,7 @@ def main():
     # totals over the ranks (strong scaling: every rank holds a different number of rows / users)
     tot_rows, tot_users = n_local, u_local
     if gather:
-        t = torch.tensor([n_local, u_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_local, u_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         tot_rows, tot_users = int(t[0]), int(t[1])
 

@@ -84,15 +84,34 @@ class HipShardBackend:
 N_SETS = 4
 
 
+def _staged_all_gather(out_dev, msg_dev, h_out, h_msg, group, wait_event, device):
+    """transport="host": the ranks' messages live on their GPUs but the collective runs between CPU tensors (gloo, or any
+    backend without a device transport): D2H into pinned memory, all-gather on the host, H2D into the gather buffer.
+    Synchronous — the rehearsal / fallback transport (two ranks on ONE GPU, where RCCL refuses to form a group; a node
+    without xGMI), not the fast path; everything around it (sharding, batched scans, message formats, capacity
+    negotiation, buffer rotation) is the code the RCCL run executes."""
+    cur = torch.cuda.current_stream(device)
+    if wait_event is not None:
+        cur.wait_event(wait_event)
+    h_msg.copy_(msg_dev, non_blocking=True)
+    cur.synchronize()
+    dist.all_gather_into_tensor(h_out, h_msg, group=group)
+    out_dev.copy_(h_out, non_blocking=True)
+    cur.synchronize()
+
+
 class _Buffers:
     """Four message / gather buffer sets of one capacity; scan i of a pipelined run uses set i % 4 (one being written by
     the scan just begun, one by the scan in flight, one being gathered, one being collected)."""
 
-    def __init__(self, world, u_pad, cap, device, cuda):
+    def __init__(self, world, u_pad, cap, device, cuda, staged=False):
         self.cap, self.u_pad = cap, u_pad
         L = self.L = u_pad + 2 + cap
         self.msg = [torch.zeros(L, dtype=torch.int32, device=device) for _ in range(N_SETS)]
         self.out = [torch.zeros(world * L, dtype=torch.int32, device=device) for _ in range(N_SETS)]
+        if staged:   # transport="host": pinned staging of one message / one gather
+            self.h_msg = torch.zeros(L, dtype=torch.int32, pin_memory=True)
+            self.h_out = torch.zeros(world * L, dtype=torch.int32, pin_memory=True)
         self.len_host = [torch.zeros(world, dtype=torch.int32, pin_memory=cuda) for _ in range(N_SETS)]
         # strided view of the M word of every rank's message, made once
         self.len_dev = [o.view(world, L)[:, u_pad + 1] for o in self.out]
@@ -115,11 +134,14 @@ class _BatchBuffers:
     carry the same lists for a fraction of the fixed cost; the price is that a step's gathered lists arrive up to
     `batch` steps later."""
 
-    def __init__(self, world, u_pad, cap, batch, device, cuda):
+    def __init__(self, world, u_pad, cap, batch, device, cuda, staged=False):
         self.cap, self.u_pad, self.batch, self.world = cap, u_pad, batch, world
         L = self.L = u_pad + 2 + cap
         self.msg = [torch.zeros(batch * L, dtype=torch.int32, device=device) for _ in range(3)]
         self.out = [torch.zeros(world * batch * L, dtype=torch.int32, device=device) for _ in range(3)]
+        if staged:
+            self.h_msg = torch.zeros(batch * L, dtype=torch.int32, pin_memory=True)
+            self.h_out = torch.zeros(world * batch * L, dtype=torch.int32, pin_memory=True)
         self.len_host = [torch.zeros(world, batch, dtype=torch.int32, pin_memory=cuda) for _ in range(3)]
         self.len_dev = [o.view(world, batch, L)[:, :, u_pad + 1] for o in self.out]
         if cuda:
@@ -143,7 +165,8 @@ class ShardedFeeds:
     run_steps() keeps two scans queued on the GPU while the host issues and collects gathers, so neither the host work
     nor the gather sits between two table passes.  Four message / result buffer sets rotate."""
 
-    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False, batch=1):
+    def __init__(self, backend, rank, world, n_users_local, group=None, cap=None, always_collective=False, batch=1,
+                 transport="device"):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
         self.batch = max(1, int(batch))   # run_steps: scans per all-gather (see _BatchBuffers)
         self.bbufs = None
@@ -151,6 +174,9 @@ class ShardedFeeds:
         self.n_users_local = int(n_users_local)
         self.device = torch.device(getattr(backend, "device", "cpu"))
         self.cuda = self.device.type == "cuda"
+        # "device": the collective moves the GPU tensors (nccl = RCCL over xGMI; gloo when they are CPU tensors);
+        # "host": GPU messages staged through pinned host memory, collective between CPU tensors (see _staged_all_gather)
+        self.staged = transport == "host" and self.cuda
         self.direct = bool(getattr(backend, "direct_message", False))
         # offsets are padded to the largest shard's user count so the gather has one fixed size
         self.u_pad = self._all_max(self.n_users_local)
@@ -164,7 +190,7 @@ class ShardedFeeds:
 
     # ---- helpers
     def _all_max(self, value):
-        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.staged else self.device)
         if self.collective:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
@@ -178,7 +204,7 @@ class ShardedFeeds:
     def _buffers(self):
         if self.bufs is None or self.bufs.cap != self.cap:
             # scans begun earlier keep their own (old) set alive through their tickets
-            self.bufs = _Buffers(self.world, self.u_pad, self.cap, self.device, self.cuda)
+            self.bufs = _Buffers(self.world, self.u_pad, self.cap, self.device, self.cuda, self.staged)
         return self.bufs
 
     # ---- pipeline stages
@@ -229,6 +255,10 @@ class ShardedFeeds:
                 torch.cuda.current_stream(self.device).wait_event(b.ev_packed[p])
             b.out[p].copy_(b.msg[p])
             return
+        if self.staged:
+            _staged_all_gather(b.out[p], b.msg[p], b.h_out, b.h_msg, self.group, None if t.ready else b.ev_packed[p], self.device)
+            b.len_host[p].copy_(b.h_out.view(self.world, b.L)[:, b.u_pad + 1])
+            return
         if self.cuda:
             prev = torch.cuda.current_stream(self.device)
             torch.cuda.set_stream(self.comm_stream)
@@ -248,7 +278,9 @@ class ShardedFeeds:
         list outgrew the message capacity (every rank sees the same lengths, so every rank gets None, the capacity has
         been raised, and the caller resubmits).  Feed(r, u) = rows[r, offsets[r,u] : offsets[r,u+1]]."""
         b, p = t.bufs, t.parity
-        if self.cuda and self.collective:
+        if self.staged and self.collective:
+            pass                         # the staged exchange is synchronous: lengths are already on the host
+        elif self.cuda and self.collective:
             b.ev_done[p].synchronize()   # waits for the side stream only, never for the scan stream
         else:
             if self.cuda:
@@ -321,7 +353,7 @@ def _run_steps_batched(self, k, now, cutoff):
     (while the offsets kernel of the scan in flight rides in the next table pass) and collected one batch later."""
     B = self.batch
     if self.bbufs is None or self.bbufs.cap != self.cap or self.bbufs.batch != B:
-        self.bbufs = _BatchBuffers(self.world, self.u_pad, self.cap, B, self.device, self.cuda)
+        self.bbufs = _BatchBuffers(self.world, self.u_pad, self.cap, B, self.device, self.cuda, self.staged)
     bb = self.bbufs
     L = bb.L
     overflow = False
@@ -336,6 +368,10 @@ def _run_steps_batched(self, k, now, cutoff):
             if self.cuda and not all_ready:
                 torch.cuda.current_stream(self.device).wait_event(bb.ev_packed[s_])
             bb.out[s_].copy_(bb.msg[s_])
+            return
+        if self.staged:
+            _staged_all_gather(bb.out[s_], bb.msg[s_], bb.h_out, bb.h_msg, self.group, None if all_ready else bb.ev_packed[s_], self.device)
+            bb.len_host[s_].copy_(bb.h_out.view(self.world, B, L)[:, :, bb.u_pad + 1])
             return
         if self.cuda:
             prev = torch.cuda.current_stream(self.device)
@@ -353,7 +389,9 @@ def _run_steps_batched(self, k, now, cutoff):
 
     def collect(s_, filled):
         nonlocal overflow, last
-        if self.cuda and self.collective:
+        if self.staged and self.collective:
+            pass
+        elif self.cuda and self.collective:
             bb.ev_done[s_].synchronize()
         else:
             if self.cuda:
@@ -428,8 +466,9 @@ class BatchedFeeds:
     A shard whose users hold more than 32 union rows (skewed users) reports length -1: UnionOverflow, use the lists."""
 
     def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False, union=False,
-                 steps_per_gather=1):
+                 steps_per_gather=1, transport="device"):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self.staged = transport == "host" and torch.device(getattr(backend, "device", "cpu")).type == "cuda"   # see ShardedFeeds
         self.union = bool(union)
         self.steps_per_gather = max(1, int(steps_per_gather))
         self.q_max = int(q_max)
@@ -445,7 +484,7 @@ class BatchedFeeds:
             self.rs = getattr(backend, "result_stream", None) or torch.cuda.current_stream(self.device)
 
     def _all_max(self, value):
-        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.staged else self.device)
         if self.collective:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
@@ -462,6 +501,9 @@ class BatchedFeeds:
                 "len_host": [torch.zeros(W, G * Qm, dtype=torch.int32, pin_memory=self.cuda) for _ in range(N_SETS)],
             }
             self.sets["len_dev"] = [o.view(W, G * Qm, L)[:, :, self.u_pad + 1] for o in self.sets["out"]]
+            if self.staged:
+                self.sets["h_msg"] = torch.zeros(G * Qm * L, dtype=torch.int32, pin_memory=True)
+                self.sets["h_out"] = torch.zeros(W * G * Qm * L, dtype=torch.int32, pin_memory=True)
             if self.cuda:
                 self.sets["ev_packed"] = [torch.cuda.Event() for _ in range(N_SETS)]
                 self.sets["ev_done"] = [torch.cuda.Event() for _ in range(N_SETS)]
@@ -492,6 +534,10 @@ class BatchedFeeds:
                 torch.cuda.current_stream(self.device).wait_event(st["ev_packed"][p])
             st["out"][p].copy_(st["msg"][p])
             return
+        if self.staged:
+            _staged_all_gather(st["out"][p], st["msg"][p], st["h_out"], st["h_msg"], self.group, None if ready else st["ev_packed"][p], self.device)
+            st["len_host"][p].copy_(st["h_out"].view(self.world, self.steps_per_gather * st["Qm"], st["L"])[:, :, self.u_pad + 1])
+            return
         if self.cuda:
             prev = torch.cuda.current_stream(self.device)
             torch.cuda.set_stream(self.comm_stream)
@@ -509,7 +555,9 @@ class BatchedFeeds:
     def _collect(self, st, p, nq, n_slots):
         """Wait for the all-gather of set p (n_slots steps' messages) -> the LAST of those steps as a result dict, or None
         when a message of the group outgrew the capacity (raised)."""
-        if self.cuda and self.collective:
+        if self.staged and self.collective:
+            pass   # synchronous exchange: lengths are on the host already
+        elif self.cuda and self.collective:
             st["ev_done"][p].synchronize()
         else:
             if self.cuda:
