@@ -72,14 +72,29 @@ def kernel_name(variant, rides, mode):
     return "k_scan_compact<%d, %s, %s, false, false>" % (un, "true" if variant & 1 else "false", "true" if variant & 2 else "false")
 
 
+def lib_srchash():
+    """Digest of the sources the loaded libpie_hip.so was built from (written beside it by sph-pie_amd/build.py)."""
+    try:
+        import sph_pie_amd
+        with open(sph_pie_amd.build.HIP_LIB + ".srchash") as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
 def pmc_traffic(kname, default_workload, fname="traffic.json"):
     """HBM bytes per launch of `kname` from the committed rocprofv3 PMC summary of this command (profiles/traffic.json, or
     traffic_wide.json / traffic_zipf.json for those two secondary workloads; written by tools/pmc_traffic.py), or None.
-    Only quoted for the workload it was measured on."""
+    Only quoted for the workload it was measured on AND for the binary it was measured with: the file records the source
+    digest of the library that ran under the profiler; when the loaded library differs (a kernel changed since the PMC
+    passes) the figure is stale, and the byte model from this run's own counters is used instead."""
     path = os.path.join(REPO, "profiles", fname)
     if not default_workload or not os.path.exists(path):
         return None, None
     doc = json.load(open(path))
+    if not doc.get("lib_srchash") or doc.get("lib_srchash") != lib_srchash():
+        return None, "profiles/%s was measured with another build of the library (srchash %s..., loaded %s...): byte model used" % (
+            fname, str(doc.get("lib_srchash"))[:12], str(lib_srchash())[:12])
     for k, v in doc.get("kernels", {}).items():
         if kname in k:
             return v, doc.get("source")
@@ -94,7 +109,7 @@ def start_js_baseline(args, U, D):
         node = shutil.which("node")
         js = os.path.join(REPO, "oracle", "ref_faithful.js")
         if node and os.path.exists(js) and args.js_rows > 0:
-            return subprocess.Popen([node, "--max-old-space-size=12288", js, "--bench", str(args.js_rows), str(max(U // 100, 10)), str(D)],
+            return subprocess.Popen([node, "--max-old-space-size=12288", js, "--bench", str(args.js_rows), str(max(int(args.js_rows * U // max(args.rows, 1)), 10)), str(D)],
                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     except Exception as ex:  # the JS leg is optional context, never fatal
         log("js baseline skipped:", ex)
@@ -185,6 +200,9 @@ def main():
     ap.add_argument("--js-timeout", type=float, default=240.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the full-read / D2H legs (secondary workloads, sweeps)")
+    ap.add_argument("--no-mixed-leg", action="store_true",
+                    help="skip the heterogeneous 64-query leg (tools/run_pmc.sh: its launches carry the headline kernel's name and would "
+                         "be averaged into the headline's PMC figures)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE corpus of --rows sharded by user hash (BASELINE configs[3]); weak = --rows per rank")
     ap.add_argument("--gather-batch", type=int, default=8, help="multi-GPU: scans per all-gather (1 = one gather per scan)")
@@ -206,7 +224,7 @@ def main():
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic); mixed: every step "
                          "creates --mixed-rows sessions (append) and touches as many (set_end) before its scan: the upkeep of the "
                          "derived key columns inside the timed region")
-    ap.add_argument("--queries-per-launch", type=int, default=16,
+    ap.add_argument("--queries-per-launch", type=int, default=64,
                     help="every step is ONE batched scan of Q queries (Q feed requests, each with its own `now`, answered by one table "
                          "pass: pie_scan_batch_*); value counts Q x U feeds per step; 1 = one query per step (single_query reports that "
                          "form in every run)")
@@ -417,13 +435,23 @@ def main():
     ctx.set_profiling(0)
     st = ctx.stats()
     batch_ms = None
+    def union_masks64(res, r, mu):
+        """the 64-bit query mask of every union row of rank r in a gathered union result"""
+        mk = res["masks"][r][:mu].cpu().numpy().astype(np.uint32).astype(np.uint64)
+        if "masks_hi" in res:
+            mk |= res["masks_hi"][r][:mu].cpu().numpy().astype(np.uint32).astype(np.uint64) << np.uint64(32)
+        return mk
+
+    union_rows = None
     if Q > 1 and not gather and args.mode == "scan":
         batch_ms = list(last)
         last = batch_ms[0]
+        union_rows = ctx.batch_union_device_ptrs()[4] or None
     elif Q > 1 and gather and args.mode == "scan":
         if "u_offsets" in last:   # union exchange: a query's rows are the union rows that carry its bit
-            mk = last["masks"][rank][: int(last["lengths"][rank])]
-            batch_ms = [int(((mk >> q) & 1).sum()) for q in range(Q)]
+            union_rows = int(last["lengths"][rank])
+            mk = union_masks64(last, rank, union_rows)
+            batch_ms = [int(((mk >> np.uint64(q)) & np.uint64(1)).sum()) for q in range(Q)]
         else:
             batch_ms = [int(x) for x in last["lengths"][rank]]
     m = batch_ms[0] if (batch_ms is not None and gather) else (last if not gather else int(last["lengths"][rank]))
@@ -439,14 +467,14 @@ def main():
             union = "u_offsets" in last
             if union:   # every query's list is a filter of the union rows (in order); the offsets follow from the masks
                 mu = int(last["lengths"][rank])
-                u_rows, u_masks = last["rows"][rank].cpu().numpy()[:mu], last["masks"][rank].cpu().numpy()[:mu]
+                u_rows, u_masks = last["rows"][rank].cpu().numpy()[:mu], union_masks64(last, rank, mu)
                 u_off = last["u_offsets"][rank].cpu().numpy()[: u_local + 1].astype(np.int64)
             for q, (qn, qc, qm) in enumerate(batch_queries):
                 ctx.set_disciplines(qm, D)
                 ctx.scan_device(qn, qc)
                 _, own_off, own_idx = ctx.read_results()
                 if union:
-                    sel = ((u_masks >> q) & 1) == 1
+                    sel = ((u_masks >> np.uint64(q)) & np.uint64(1)) == 1
                     csum = np.concatenate([[0], np.cumsum(sel)])
                     ok = ok and np.array_equal(u_rows[sel], own_idx) and np.array_equal(csum[u_off], own_off)
                     continue
@@ -485,13 +513,13 @@ def main():
         rides = (args.depth == 2 or gather) and os.environ.get("PIE_K2_RIDE") != "0" and (variant & ~0x840) == 0x485
         kname = kernel_name(variant, rides, args.mode)
         if batch_ms is not None:
-            kname = "k_scan_batch_with_tail<8, true, %s, %d>" % ("unsigned char" if variant & 0x800 else "unsigned short", 4 if Q <= 4 else 8)
+            kname = "k_scan_batch_with_tail<8, true, %s, %s>" % ("unsigned char" if variant & 0x800 else "unsigned short", "true" if Q > 32 else "false")
             if variant & 0x2000:
                 kname = "k_ord_batch_scan<%s, 4>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local
-        traffic_doc, traffic_src = pmc_traffic(kname, default_workload and (batch_ms is None or Q == 16))
+        traffic_doc, traffic_src = pmc_traffic(kname, default_workload and (batch_ms is None or Q == 64))
         # the two secondary workloads of the ordered run that have PMC passes of their own
         base_shape = (N, U, D, args.order, args.variant, args.mode, world) == (10 ** 8, 10 ** 5, 32, "random", "auth", "scan", 1)
         if base_shape and batch_ms is None and args.query == "wide" and args.users_dist == "uniform":
@@ -516,8 +544,11 @@ def main():
                 model = pos_n * kb + st["candidates"] * 64 + int(m) * 4
         elif batch_ms is not None:
             kb = 1 if variant & 0x800 else 2
-            # one union bucket store per selected row (whatever Q), Q sets of counts / offsets / row lists
-            model = n_local * kb + st["candidates"] * 128 + max(batch_ms) * 64 + sum(batch_ms) * 4 + Q * u_local * 12
+            # per launch: the key stream; one 128-B sector per candidate payload record; one 64-B sector per union bucket store
+            # (whatever Q); the tail of the batch before: histogram + bucket records read (4 B per user, a sector per bucket),
+            # the union written (uoff 8 B per user, 8 or 12 B per union row), the next span zeroed
+            mu_rows = union_rows if union_rows else max(batch_ms)
+            model = n_local * kb + st["candidates"] * 128 + mu_rows * 64 + u_local * (4 + 64 + 8) + mu_rows * (12 if Q > 32 else 8) + u_local * 4
         elif args.mode == "scan" and variant & 0x400:
             kb = 1 if variant & 0x800 else 2
             model = n_local * kb + st["candidates"] * 128 + st["key_ambiguous"] * 128 + int(m) * 64 + u_local * 12 + int(m) * 4
@@ -532,8 +563,14 @@ def main():
                       "expired-queue pass (SURVEY 8f-1): sessions scanned/sec; value counts table rows, not feeds",
             "value": per_step_units / (ms_per_step * 1e-3),
             "unit": "feeds/s" if args.mode in ("scan", "mixed") else "sessions/s",
-            "sessions_per_sec": tot_rows * (Q if batch_ms is not None else 1) / (ms_per_step * 1e-3),
+            ("logical_sessions_per_sec" if (batch_ms is not None or variant & 0x400) else "sessions_per_sec"):
+                tot_rows * (Q if batch_ms is not None else 1) / (ms_per_step * 1e-3),
+            "logical_sessions_note": "rows of the table x queries answered per second: what the answers cover, NOT bytes scanned — the keyed "
+                                     "pass reads a 1-byte liveness key per row and one 16-byte record per candidate row (physical_bytes_per_step); "
+                                     "sessions really scanned at 24 B each per second is roofline.full_read.sessions_per_sec",
+            "physical_bytes_per_step": basis,
             "queries_per_launch": Q if batch_ms is not None else 1,
+            "union_rows_rank0": union_rows,
             "table_passes_per_sec": 1.0 / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "timing": {"timed_regions": len(region_ms), "steps_per_region": args.steps, "ms_per_step": spread(region_ms),
@@ -542,7 +579,7 @@ def main():
                                "value and ms_per_step are the median region"},
             "scan_only_ms_per_step": scan_only_ms, "gather_verified": gather_ok,
             "exchange": None if bfeeds is None else {
-                "format": exchange_state["format"], "fallback": exchange_state["fallback"],
+                "format": exchange_state["format"], "fallback": exchange_state["fallback"], "transport": args.transport,
                 "bytes_per_rank_per_step": int(bfeeds.sets["L"]) * 4 * (1 if bfeeds.union else Q) if bfeeds.sets else None,
                 "steps_per_gather": bfeeds.steps_per_gather,
                 "note": "what every rank contributes to a step's all-gather (and receives from every other rank): union = per user "
@@ -564,7 +601,7 @@ def main():
                 "bound": "hbm", "kernel": kname, "kernel_variant": hex(variant),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "lib_srchash": lib_srchash(),
                 "traffic_model": model,
                 "traffic_model_note": "bytes from this run's own counters: key stream N x key bytes + 128 B per candidate payload record + 128 B "
                                       "per ambiguous `end` + 64 B per selected row stored + K2 outputs; `achieved` uses the PMC traffic when the "
@@ -638,6 +675,34 @@ def main():
             "note": "one query per scan, two scans in flight (the r01 headline form); the timed launch is the keyed table pass plus, in its "
                     "first blocks, the offsets + order kernel of the scan before it",
         }
+    if world == 1 and args.mode == "scan" and not gather and not args.no_extra and Q > 1:
+        # ---- other batches through the same pass, same table, same run (each: warm-up, then --repeat regions of --steps steps)
+        def batch_leg(queries, note):
+            ctx.scan_batch_pipelined(max(args.warmup, 1), queries)
+            regs = []
+            ms_l = None
+            for _ in range(max(args.repeat, 1)):
+                dt, ms_l = timed_region(lambda k: ctx.scan_batch_pipelined(k, queries), args.steps)
+                regs.append(dt * 1e3 / args.steps)
+            stb = ctx.stats()
+            med = statistics.median(regs)
+            return {"queries": len(queries), "ms_per_step": med, "ms_per_step_spread": spread(regs), "value": U * len(queries) / (med * 1e-3),
+                    "unit": "feeds/s", "us_per_query": med * 1e3 / len(queries), "union_rows": ctx.batch_union_device_ptrs()[4] or None,
+                    "selected_rows_per_query": {"min": int(min(ms_l)), "max": int(max(ms_l)), "distinct": len(set(int(x) for x in ms_l))},
+                    "distinct_now_cutoff_mask": [len(set(q[k] for q in queries)) for k in range(3)],
+                    "candidates": stb["candidates"], "kernel_variant": hex(stb["k1_variant"]), "note": note}
+
+        lim = (1 << D) - 1 if D < 64 else 2 ** 64 - 1
+        role_masks = [mask, 0xAAAAAAAAAAAAAAAA & lim, lim, 0x0F0F0F0F0F0F0F0F & lim]
+        line["batch_q16"] = batch_leg(batch_queries[:16], "the round-2 headline batch: 16 requests 977 ms apart, same cutoff, same discipline mask")
+        if not args.no_mixed_leg:
+            line["batch_mixed"] = batch_leg(
+                [(now - 977 * q, cutoff - (q % 3) * DAY, role_masks[q % 4]) for q in range(Q)],
+                "a heterogeneous batch: every request its own clock, three different cutoffs (requests either side of a day change), four "
+                "role masks (16 of 32 disciplines, the other 16, all 32, nibbles): the union is the rows ANY of them selects")
+        line["batch_mixed_q16"] = batch_leg(
+            [(now - 977 * q, cutoff - (q % 3) * DAY, (mask, 0xAAAAAAAAAAAAAAAA & lim, lim)[q % 3]) for q in range(16)],
+            "the 16 heterogeneous queries of tests/test_gpu_parity.py::test_full_size_properties_1e8 (three cutoffs, three masks), timed")
     if world == 1 and args.mode == "scan" and not gather and not args.no_extra:
         # ---- the every-byte form of the same query, same table, same run (SURVEY.md 8d's 24 B/row really read)
         ctx.set_scan_form(0x01)
@@ -714,6 +779,17 @@ def main():
             ctx.read_results_into(None, None, h_idx.data_ptr(), h_idx.numel())
         line["value_with_d2h"]["idx_to_host_ms"] = (time.perf_counter() - t1) * 1e3 / 20
         line["value_with_d2h"]["idx_bytes"] = int(m) * 4
+        # the figure SURVEY.md 8(d) defines, inside `roofline` (the record's first place to look): algorithmic 24 B x N over the
+        # every-byte kernel's time and over t_scan
+        fr = line["roofline_full_read"]
+        line["roofline"]["full_read"] = {
+            "kernel": fr["kernel"], "alg_bytes_per_scan": fr["alg_bytes_per_scan"], "kernel_ms": fr["kernel_ms"], "t_scan_ms": fr["t_scan_ms"],
+            "frac_kernel": fr["kernel_frac"], "frac_t_scan": fr["frac"], "ms_per_step": fr["ms_per_step"], "frac_step": fr["step_frac"],
+            "sessions_per_sec": N / (fr["t_scan_ms"] * 1e-3), "feeds_per_sec": U / (fr["t_scan_ms"] * 1e-3), "traffic": fr["traffic"],
+            "note": "the same query on the same table with the table pass pinned to the form that reads every byte of the four columns "
+                    "(24 B/row = SURVEY 8d's algorithmic bytes; PMC traffic = algorithmic): frac_* = 24 B x N / time / 8 TB/s; t_scan = first "
+                    "kernel start -> last kernel end of ONE scan; sessions_per_sec = rows really read per second",
+        }
         for sx in sets:
             ctx.host_free(sx[2])
             ctx.host_free(sx[5])

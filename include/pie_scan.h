@@ -61,7 +61,8 @@ typedef struct pie_stats {
     uint32_t k1_blocks;    /* grid of the scan kernel */
     uint32_t k1_variant;   /* form of the scan kernel used by the last scan (bit0 nt loads, bit1 late user, bit2 liveness-first,
                               0x400 keyed: streams the 2-byte liveness key instead of the `end` column, 0x800 the 1-byte key,
-                              0x1000 batched: the last finished call was a batch, `selected` sums its queries,
+                              0x1000 batched: the last finished call was a batch, `selected` sums its queries, `max_bucket` is the
+                              largest UNION bucket,
                               0x2000 ordered run: 0x2003 dense form, 0x2400 / 0x2C00 keyed form on the 2- / 1-byte key,
                               0x3400 / 0x3C00 a batch on the ordered run) */
     uint32_t key_ambiguous; /* keyed form: rows of the last scan whose key equalled the query's and needed the full compare (saturating) */
@@ -168,11 +169,21 @@ int pie_host_free(pie_ctx *ctx, void *host_ptr);
 /* ---- batched scan: many feed requests, one table pass (SURVEY.md section 7 "batch many queries per launch"; the
  * north_star's "calendarFeed per-request loop -> batched GPU scan").  Every query has its own `now` (the request's clock,
  * server/sessionStore.js:67 samples one per scan), `cutoff` (server/calendarFeed.js:33-38) and discipline mask
- * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Results are bit for bit those of
- * n_q separate pie_scan calls.  Up to two batches may be in flight (begin(i+1) before finish(i)), like two scans; single
- * scans and batches do not mix in flight.  A query the batched pass cannot finish (a dense query, a bucket of more than
- * 16 rows) is rerun inside pie_scan_batch_finish on the general path. */
-#define PIE_BATCH_MAX 16
+ * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Up to two batches may be in flight
+ * (begin(i+1) before finish(i)), like two scans; single scans and batches do not mix in flight.
+ *
+ * The PRIMARY result of a batch is the UNION of its queries' selections: per user the rows that ANY query selected, in
+ * (start, row) order, with a query mask per row —
+ *     uoff[U+1] (int64) | rows[Mu] (int32) | mask[Mu] (bit q = query q selected the row)
+ *     Feed(q, u) = the rows of rows[uoff[u] : uoff[u+1]] whose mask has bit q, in that order
+ * (requests that arrive together select almost the same rows: the union is little longer than one query's list, whatever Q).
+ * pie_scan_batch_finish reports every query's M; pie_batch_read_user_feed answers a request straight from the union.  The
+ * per-query form of a result — counts[U], offsets[U+1], idx[M], bit for bit those of n_q separate pie_scan calls — is
+ * materialised from the union only when asked for (pie_batch_read_results, pie_batch_result_device_ptrs, the per-query
+ * messages).  A query the batched pass cannot hold (a dense query, a user with more than 64 union rows) is rerun inside
+ * pie_scan_batch_finish on the general path; such a batch has per-query results only (no union: pie_batch_union_device_ptrs
+ * returns NULL pointers). */
+#define PIE_BATCH_MAX 64
 typedef struct pie_query {
     int64_t now, cutoff;
     uint64_t mask;
@@ -182,26 +193,38 @@ int pie_scan_batch_begin(pie_ctx *ctx, const pie_query *queries, int n_q);
 int pie_scan_batch_finish(pie_ctx *ctx, size_t *m_out);
 /* begin + finish */
 int pie_scan_batch(pie_ctx *ctx, const pie_query *queries, int n_q, size_t *m_out);
-/* The same with one result message per query (layout of pie_pack_results_device) written to msg_i32 + q * msg_stride_words
- * and, optionally, counts[U] to counts_i32 + q * counts_stride_words; both device-visible (device or mapped host memory).
- * *ready_out = 1: every message was complete when the call returned; 0: order the consumer behind the context's stream. */
+/* The union of the last finished batch: device pointers (valid until the batch after the next begins; NULL when the batch has
+ * no union, see above), or host copies (masks_out: one 64-bit mask per union row; PIE_E_CAPACITY if cap < Mu, PIE_E_STATE if
+ * the batch has no union). */
+int pie_batch_union_device_ptrs(pie_ctx *ctx, void **uoff_dev /* int64[U+1] */, void **rows_dev /* int32[Mu] */,
+                                void **mask_lo_dev /* uint32[Mu]: queries 0..31 */, void **mask_hi_dev /* uint32[Mu]: 32..63, NULL for n_q <= 32 */,
+                                size_t *mu_out);
+int pie_batch_read_union(pie_ctx *ctx, int64_t *uoff_out, int32_t *rows_out, uint64_t *masks_out, size_t cap, size_t *mu_out);
+/* A batch that also writes the multi-GPU exchange message as it goes — ONE union message for the whole batch:
+ *   msg (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | mask_lo[0..cap) | mask_hi[0..cap) (only when n_q > 32) ]
+ * u_pad + 2 + 2 * cap words (3 * cap for n_q > 32); uoff[u] = Mu for u >= users; rows beyond cap are dropped (Mu says how many
+ * there are).  msg is device-visible memory (device or mapped host) that stays valid until the matching finish.
+ * pie_scan_batch_finish_packed: *ready_out = 1 when the message was complete when the call returned (the batch's own kernels
+ * wrote it); 0 when it was packed afterwards on the context's stream (order the consumer behind pie_ctx_aux_stream) — then
+ * Mu = -1 means a user's merged union exceeds 32 rows or the batch holds more than 32 queries: use the per-query messages. */
+int pie_scan_batch_begin_union(pie_ctx *ctx, const pie_query *queries, int n_q, void *msg_i32, size_t u_pad, size_t cap);
+/* The per-query form of the exchange: one result message per query (layout of pie_pack_results_device) written to
+ * msg_i32 + q * msg_stride_words and, optionally, counts[U] to counts_i32 + q * counts_stride_words; both device-visible.
+ * The lists are materialised from the union and packed at finish (*ready_out = 0: order the consumer behind the context's
+ * stream). */
 int pie_scan_batch_begin_packed(pie_ctx *ctx, const pie_query *queries, int n_q, void *msg_i32, size_t msg_stride_words,
                                 size_t u_pad, size_t idx_cap, void *counts_i32, size_t counts_stride_words);
 int pie_scan_batch_finish_packed(pie_ctx *ctx, size_t *m_out, int *ready_out);
-/* Results of query `qi` of the last finished batch (as pie_read_results / pie_result_device_ptrs). */
+/* Results of query `qi` of the last finished batch (as pie_read_results / pie_result_device_ptrs): materialised on first use. */
 int pie_batch_read_results(pie_ctx *ctx, int qi, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                            size_t *m_out);
 int pie_batch_result_device_ptrs(pie_ctx *ctx, int qi, void **counts_dev, void **offsets_dev, void **idx_dev);
-/* The UNION message of the last finished batch, for the multi-GPU exchange.  The queries of a batch are
- * requests of the same few seconds and select almost the same rows; per user the union of their row lists in (start, row)
- * order with a query mask per row carries every query's feed in 8 B per union row instead of 4 B per row per query:
- *   dst (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | masks[0..cap) ],   u_pad + 2 + 2 * cap words
- * Feed(q, u) = the rows of rows[uoff[u] : uoff[u+1]] whose mask has bit q, in that order (uoff[u] = Mu for u >= users).
- * Rows beyond cap are dropped (Mu says how many there are); Mu = -1: a user's union exceeds 32 rows (skewed users) — use the
- * per-query messages.  Enqueued on the context's stream (pie_ctx_aux_stream); dst is device-visible memory. */
+/* The union message (layout above) of the last finished batch into caller memory, whatever path the batch took; enqueued on
+ * the context's stream (pie_ctx_aux_stream). */
 int pie_batch_pack_union_device(pie_ctx *ctx, void *dst_i32, size_t u_pad, size_t cap);
 /* One user's feed of query `qi` of the last finished batch (as pie_read_user_feed): the per-request read of a server that
- * answers the requests of one event-loop turn with one batch. */
+ * answers the requests of one event-loop turn with one batch (/root/reference/server/index.js:293-302).  Read from the union
+ * (two small copies + a filter on the host); no per-query list is built for it. */
 int pie_batch_read_user_feed(pie_ctx *ctx, int qi, int32_t user, int32_t *idx_out, size_t idx_cap, size_t *k_out);
 
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */

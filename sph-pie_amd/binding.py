@@ -38,7 +38,7 @@ class PieQuery(C.Structure):
     _fields_ = [("now", C.c_int64), ("cutoff", C.c_int64), ("mask", C.c_uint64)]
 
 
-PIE_BATCH_MAX = 16
+PIE_BATCH_MAX = 64
 
 
 class PieStats(C.Structure):
@@ -88,6 +88,9 @@ _SIGS = [
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
     ("pie_scan_batch_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
     ("pie_scan_batch", C.c_int, [_P, C.POINTER(PieQuery), C.c_int, C.POINTER(C.c_size_t)]),
+    ("pie_scan_batch_begin_union", C.c_int, [_P, C.POINTER(PieQuery), C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]),
+    ("pie_batch_union_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("pie_batch_read_union", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_scan_batch_begin_packed", C.c_int, [_P, C.POINTER(PieQuery), C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]),
     ("pie_scan_batch_finish_packed", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     ("pie_batch_read_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -168,6 +171,7 @@ class PieScan:
         self.n = 0
         self.n_users = 0
         self._begun = []   # scans begun and not finished, oldest first: True = begun with scan_begin_packed
+        self._m_buf, self._ready_buf = (C.c_size_t * PIE_BATCH_MAX)(), C.c_int(0)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -386,14 +390,16 @@ class PieScan:
     @staticmethod
     def _queries(queries):
         # the same list of queries, batch after batch, is the common case (a pipelined loop): marshal it once
-        key = tuple(queries)
         hit = PieScan._q_cache
+        if hit is not None and hit[2] is queries and len(queries) == len(hit[0]):
+            return hit[1]            # the very same list object again (a caller that changes it in place passes a new list)
+        key = tuple(queries)
         if hit is not None and hit[0] == key:
             return hit[1]
         arr = (PieQuery * len(queries))()
         for k, (now, cutoff, mask) in enumerate(queries):
             arr[k].now, arr[k].cutoff, arr[k].mask = int(now), int(cutoff), int(mask) & (2 ** 64 - 1)
-        PieScan._q_cache = (key, arr)
+        PieScan._q_cache = (key, arr, queries)
         return arr
 
     def scan_batch_begin(self, queries):
@@ -410,16 +416,43 @@ class PieScan:
         self._batches = getattr(self, "_batches", [])
         self._batches.append(len(queries))
 
+    def scan_batch_begin_union(self, queries, msg_ptr, u_pad, cap):
+        """A batch whose own kernels write the UNION exchange message [uoff[0..u_pad] | Mu | rows[cap) | mask_lo[cap) | mask_hi[cap)
+        if more than 32 queries] into msg_ptr (device-visible int32 memory)."""
+        arr = self._queries(queries)
+        self._check(self._lib.pie_scan_batch_begin_union(self._ctx, arr, len(queries), msg_ptr, int(u_pad), int(cap)))
+        self._batches = getattr(self, "_batches", [])
+        self._batches.append(len(queries))
+
+    def batch_read_union(self):
+        """The primary result of the last finished batch: (uoff[U+1] int64, rows[Mu] int32, masks[Mu] uint64);
+        Feed(q, u) = rows[uoff[u]:uoff[u+1]][(masks[uoff[u]:uoff[u+1]] >> q) & 1 == 1].  None when the batch has no union
+        (queries fell back to the general path, or it ran on the ordered run)."""
+        a, b, lo, hi, mu = _P(), _P(), _P(), _P(), C.c_size_t(0)
+        self._check(self._lib.pie_batch_union_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(lo), C.byref(hi), C.byref(mu)))
+        if not a.value:
+            return None
+        uoff = np.empty(self.n_users + 1, np.int64)
+        rows, masks = np.empty(max(mu.value, 1), np.int32), np.empty(max(mu.value, 1), np.uint64)
+        self._check(self._lib.pie_batch_read_union(self._ctx, _ptr(uoff), _ptr(rows), _ptr(masks), mu.value, C.byref(mu)))
+        return uoff, rows[: mu.value], masks[: mu.value]
+
+    def batch_union_device_ptrs(self):
+        """-> (uoff, rows, mask_lo, mask_hi device addresses or None, Mu)"""
+        a, b, lo, hi, mu = _P(), _P(), _P(), _P(), C.c_size_t(0)
+        self._check(self._lib.pie_batch_union_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(lo), C.byref(hi), C.byref(mu)))
+        return a.value, b.value, lo.value, hi.value, int(mu.value)
+
     def scan_batch_finish(self, packed=False):
         """-> list of M per query of the oldest batch in flight (packed: (list, ready))."""
         nq = self._batches[0] if getattr(self, "_batches", None) else PIE_BATCH_MAX
-        m = (C.c_size_t * PIE_BATCH_MAX)()
-        ready = C.c_int(0)
+        m = self._m_buf
+        ready = self._ready_buf
         rc = self._lib.pie_scan_batch_finish_packed(self._ctx, m, C.byref(ready))
         if getattr(self, "_batches", None) and rc != -6:
             self._batches.pop(0)
         self._check(rc)
-        ms = [int(m[k]) for k in range(nq)]
+        ms = m[:nq]
         return (ms, bool(ready.value)) if packed else ms
 
     def batch_pack_union_device(self, dst_ptr, u_pad, cap):
@@ -606,6 +639,7 @@ class PieComm:
             raise PieError(-1, "rank %d is not local to this communicator" % rank)
         p = PieScan.__new__(PieScan)
         p._lib, p._ctx, p._begun = self._lib, _P(h), []
+        p._m_buf, p._ready_buf = (C.c_size_t * PIE_BATCH_MAX)(), C.c_int(0)
         st = PieStats()
         st.struct_size = C.sizeof(PieStats)
         p._check(self._lib.pie_stats_get(p._ctx, C.byref(st)))

@@ -1835,15 +1835,24 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
 // returning atomics, ~10 us at the chip's scattered-atomic rate, plus its own offsets kernel — profiles/r02_b_*.)
 // There is no staged route here: a user whose union bucket outgrows its slots is reported (Summary::n_over) and the host
 // reruns the batch's queries on the general path, bit for bit the same result; the slot capacity then grows (up to 64).
-constexpr int kBatchMax = 16;
+constexpr int kBatchMax = 64;
 constexpr int kUnionShiftMax = 6; // union bucket slots per user: 16 .. 64 (one wave orders a bucket by ranking)
 
-struct BatchQueryScalars {
-    long long now, cutoff;
-    unsigned long long mask;
-    unsigned now_key;
-    unsigned pad;
+// The Q predicates of a candidate row in O(log Q): `end > now_q` and `start >= cutoff_q` are monotone in the query's scalar,
+// so with the batch's `now` values and cutoffs sorted, the queries a row is live for / in the window of are a PREFIX of the
+// sorted order — two binary searches and two prefix-mask lookups — and the discipline conjunct is one lookup in a table
+// "which queries accept discipline d".  qmask = live[rank(end)] & win[rank(start)] & disc[d].  (Round 2 looped over the
+// queries: 64 of them cost 0.101 ms per pass against 0.064 for 16.)  Built on the host, shipped in the kernel arguments,
+// copied to LDS by every block.  Queries that fall back are simply not in the tables.
+struct BatchTables {
+    long long now[kBatchMax];               // ascending; unused entries INT64_MAX
+    long long cutoff[kBatchMax];            // ascending; unused entries INT64_MAX
+    unsigned long long live[kBatchMax + 1]; // live[r]: the queries with the r smallest `now`
+    unsigned long long win[kBatchMax + 1];  // win[r]: the queries with the r smallest cutoff
+    unsigned long long disc[64];            // disc[d]: the queries whose mask has bit d
+    unsigned nk[kBatchMax];                 // key(now) in the order of now[] (monotone, so ascending too); unused entries ~0
 };
+static_assert(sizeof(BatchTables) % 4 == 0, "copied to LDS word by word");
 
 template <class KT>
 struct BatchScanArgs {
@@ -1856,11 +1865,27 @@ struct BatchScanArgs {
     unsigned min_key;          // smallest now_key of the batch: a row below it is dead for every query
     int dshift;                // log2 of the union bucket's slot capacity
     int* counts;               // union histogram (transposed user order, hist_index)
-    Summary* summary;          // query 0's summary: bad rows and the row statistics of the pass
-    BktRec* direct;            // union bucket slots, (1 << dshift) per user; BktRec::pad = the queries that selected the row
+    Summary* summary;          // the batch's summary: bad rows and the row statistics of the pass
+    BktRec* direct;            // union bucket slots, (1 << dshift) per user; BktRec::pad = the queries (0..31) that selected the row
+    unsigned* direct_hi;       // queries 32..63 of every slot (written when n_q > 32)
     int run_shift;             // see KeyedArgs
-    BatchQueryScalars q[kBatchMax];
+    BatchTables tab;
 };
+
+// entries of an ascending 64-entry table that are < x (LT) or <= x (!LT): branchless, seven probes
+template <bool LT, class T>
+__device__ __forceinline__ int rank_in_64(const T* tab, T x)
+{
+    int r = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const T v = tab[r + s - 1];
+        r += (LT ? (v < x) : (v <= x)) ? s : 0;
+    }
+    const T v = tab[r];
+    r += (LT ? (v < x) : (v <= x)) ? 1 : 0;
+    return r;
+}
 
 template <int UNROLL, bool NT, class KT>
 __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int bid, int n_scan_blocks)
@@ -1869,6 +1894,7 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     __shared__ int ring_key[kK1Waves][kLiveRing];
     __shared__ int blk_cand;
     __shared__ int blk_chunk_max;
+    __shared__ BatchTables tab;
     constexpr int kLogUnroll = UNROLL >= 8 ? 3 : UNROLL >= 4 ? 2 : UNROLL >= 2 ? 1 : 0;
     const int run_shift = a.run_shift < kLogUnroll ? (a.run_shift < 0 ? 0 : a.run_shift) : kLogUnroll;
     int pushed = 0, chunk_max = 0, chunk_mark = 0;
@@ -1877,6 +1903,11 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { blk_cand = 0; blk_chunk_max = 0; }
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&a.tab);
+        unsigned* dst = reinterpret_cast<unsigned*>(&tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(BatchTables) / 4); i += kK1Threads) dst[i] = src[i];
+    }
     __syncthreads();
     int* rrow = ring_row[wave];
     int* rkey = ring_key[wave];
@@ -1897,18 +1928,14 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
             key = (unsigned)rkey[slot];
             pr = a.pay[row]; // ONE gather per candidate, shared by all queries
         }
-        bool amb_any = false;
-        for (int q = 0; q < nq; ++q) amb_any |= key == a.q[q].now_key;
-        long long ev = 0;
-        if (valid && amb_any) ev = a.end[row]; // the 8-byte `end` only where some query's key cannot decide
-        const bool disc_ok = (unsigned)pr.disc < 64u;
-        unsigned qmask = 0;
-        for (int q = 0; q < nq; ++q) { // wave-uniform loop over the queries' scalars (SGPRs)
-            const BatchQueryScalars& Q = a.q[q];
-            const bool live = key > Q.now_key || (key == Q.now_key && ev > Q.now);
-            const bool p = valid & live & (pr.start >= Q.cutoff) & disc_ok & (((Q.mask >> (pr.disc & 63)) & 1ull) != 0);
-            qmask |= (p ? 1u : 0u) << q;
-        }
+        // liveness: the queries whose key(now) lies below the row's key form a prefix of the sorted order; a row whose key
+        // EQUALS some query's is ranked by its 8-byte `end` instead (key() is monotone, so that is exact for every query)
+        int r = rank_in_64<true>(tab.nk, key);
+        const bool amb = valid && r < kBatchMax && tab.nk[r < kBatchMax ? r : 0] == key;
+        if (amb) r = rank_in_64<true>(tab.now, a.end[row]);
+        const int w = rank_in_64<false>(tab.cutoff, pr.start);
+        unsigned long long qmask = 0;
+        if (valid && (unsigned)pr.disc < 64u) qmask = tab.live[r] & tab.win[w] & tab.disc[pr.disc & 63];
         if (qmask && (unsigned)pr.user >= (unsigned)a.n_users) {
             atomicAdd(&a.summary->bad_rows, 1u);
             qmask = 0;
@@ -1919,8 +1946,9 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
                 BktRec rec;
                 rec.start = pr.start;
                 rec.idx = row;
-                rec.pad = (int)qmask;
+                rec.pad = (int)(unsigned)qmask;
                 a.direct[((long long)pr.user << a.dshift) + rank] = rec;
+                if (nq > 32) a.direct_hi[((long long)pr.user << a.dshift) + rank] = (unsigned)(qmask >> 32);
             }
         }
         ncand += cnt;
@@ -2010,35 +2038,42 @@ __device__ __forceinline__ void scan_batch_body(const BatchScanArgs<KT>& a, int 
     if (threadIdx.x == 0) add_row_stats(a.summary, 0, 0, bid, blk_cand, blk_chunk_max);
 }
 
-// offsets + order kernel of a batch: blocks of 256 users; see the section header
-struct BatchTailArgs {
+// offsets + order kernel of a batch: blocks of 256 users.  The batch's PRIMARY result is the union: per user the rows that any
+// query selected, in (start, row) order, with a query mask per row —
+//     uoff[U+1] | urows[Mu] | umask_lo[Mu] (| umask_hi[Mu] when the batch holds more than 32 queries)
+// Feed(q, u) = the rows of urows[uoff[u] : uoff[u+1]] whose mask has bit q, in that order.  ONE prefix scan (the union counts),
+// one ordered copy of every bucket, whatever Q; per-query counts / offsets / row lists are materialised from it only on request
+// (k_mat_*), and the multi-GPU exchange message is the same arrays as int32 words, written here when the caller asked for it.
+// (Round 2 wrote Q full sets of counts / offsets / row lists in this kernel: 47 MB per 16-query batch at cfg3, 0.19 of peak.)
+constexpr int kMqSlots = 64; // per-query selected-row totals: blocks add to slot (tile mod 64), the last block sums the slots
+
+struct BatchHost {           // mapped pinned host memory, one per batch slot: written by the tail's last block, seq last
+    Summary s;               // m = Mu (union rows), max_count = largest union bucket
+    unsigned long long mq[kBatchMax]; // selected rows per query
+    unsigned long long seq;
+};
+
+struct UnionTailArgs {
     int n_q;
     int n_users;
-    int tiles;                 // blocks (256 users each) per query group; a batch of more than 8 queries runs as two groups
-                               // of <= 8 (queries 0..7 and 8..), each a complete offsets kernel of its own over the same union
-                               // buckets: 16 queries' worth of per-thread state would halve the occupancy of the launch per query group; a batch of more than 8 queries runs as two groups
-                               // of <= 8 (queries 0..7 and 8..), each a complete offsets kernel of its own over the same union
-                               // buckets: 16 queries' worth of per-thread state would halve the occupancy of the launch
+    int tiles;                 // blocks (256 users each)
     int dshift;
-    char* span;                // the batch's span set: span 0 holds the union histogram and the ticket / done words,
-                               // span q (at q * span_stride) query q's tile granules and Summary
-    long long span_stride, tiles_off, ctl_off, summary_off; // byte offsets inside a span
-    char* zero_span;           // the span SET the batch after the next will use: zeroed here, all kBatchMax spans of it
-    long long zero_total16;    // 16-byte vectors of a set
-    int* counts_ord;           // + q * users_stride
-    long long* offsets;        // + q * users_stride
-    long long users_stride;    // elements (>= n_users + 1)
-    const BktRec* direct;      // union bucket slots
-    int* out_idx;              // + q * out_stride
-    long long out_stride;      // capacity of a query's row list
-    HostSummary* host;         // [n_q], mapped host memory
+    char* span;                // the batch's span: union histogram | tile granules | .. | ScanCtl | Summary + row statistics | mq slots
+    long long tiles_off, ctl_off, summary_off, mq_off; // byte offsets inside a span
+    char* zero_span;           // the span the batch after the next will use: zeroed here
+    long long zero_total16;    // 16-byte vectors of a span
+    const BktRec* direct;      // union bucket slots (BktRec::pad = query bits 0..31)
+    const unsigned* direct_hi; // query bits 32..63 of every slot (batches of more than 32 queries)
+    long long* uoff;           // [n_users + 1]
+    int* urows;                // [n_users << dshift]
+    unsigned* umlo;
+    unsigned* umhi;
+    BatchHost* host;
     unsigned long long seq;
-    int* msg;                  // optional per-query result messages: msg + q * msg_stride
-    long long msg_stride;
+    int* msg;                  // optional union message (device-visible): [uoff[0..u_pad] | Mu | rows[cap) | mask_lo[cap) | mask_hi[cap) if n_q > 32]
     int u_pad;
     long long msg_cap;
-    int* msg_counts;           // optional per-query counts copies: msg_counts + q * msg_counts_stride
-    long long msg_counts_stride;
+    int dbg;                   // PIE_TAIL_DBG: timing experiments only (skips parts of the kernel; results are then wrong)
 };
 
 __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane)
@@ -2051,60 +2086,62 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane)
     return v;
 }
 
-// QT = compile-time bound on the queries of one group (4 / 8): per-query state lives in registers
-template <int QT>
-__device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int gbid)
+// HI = the batch holds more than 32 queries (a second mask word per row)
+template <bool HI>
+__device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid)
 {
     constexpr int BLOCK = kK1Threads;
     constexpr int kWaves = kK1Waves;
-    __shared__ long long s_sum[QT][kWaves];
-    __shared__ unsigned int s_max[QT][kWaves];
-    __shared__ long long s_part[QT][kWaves];
-    __shared__ unsigned int s_pmax[QT][kWaves];
-    __shared__ long long s_total[QT];
+    __shared__ long long s_sum[kWaves];
+    __shared__ unsigned int s_max[kWaves];
+    __shared__ long long s_part[kWaves];
+    __shared__ unsigned int s_pmax[kWaves];
+    __shared__ unsigned int s_mq[kWaves][kBatchMax];
+    __shared__ long long s_total;
     __shared__ unsigned int tile_s;
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nblk = t.tiles, U = t.n_users;
-    const int grp = gbid / nblk, n_grp = t.n_q > 8 ? 2 : 1;
-    const int q_lo = grp * 8;
-    const int nq = (t.n_q - q_lo) < QT ? (t.n_q - q_lo) : QT;   // queries of this group
-    if (t.zero_span) {
+    const int nblk = t.tiles, U = t.n_users, nq = t.n_q;
+    if (t.zero_span && !(t.dbg & 16)) {
         const int4 z = make_int4(0, 0, 0, 0);
         int4* zs = reinterpret_cast<int4*>(t.zero_span);
-        for (long long i = (long long)gbid * BLOCK + threadIdx.x; i < t.zero_total16; i += (long long)nblk * n_grp * BLOCK) zs[i] = z;
+        for (long long i = (long long)gbid * BLOCK + threadIdx.x; i < t.zero_total16; i += (long long)nblk * BLOCK) zs[i] = z;
     }
-    // the group's ticket / done words and its overflow count live in the span of its first query; the table pass's
-    // statistics (bad rows, candidates) in span 0
-    char* gspan = t.span + (long long)q_lo * t.span_stride;
-    ScanCtl* ctl = reinterpret_cast<ScanCtl*>(gspan + t.ctl_off);
-    Summary* sumg = reinterpret_cast<Summary*>(gspan + t.summary_off);
-    Summary* sum0 = reinterpret_cast<Summary*>(t.span + t.summary_off);
+    ScanCtl* ctl = reinterpret_cast<ScanCtl*>(t.span + t.ctl_off);
+    Summary* sum = reinterpret_cast<Summary*>(t.span + t.summary_off);
+    unsigned int* mq_slots = reinterpret_cast<unsigned int*>(t.span + t.mq_off);
     if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
     const int tile = (int)tile_s;
+    if ((t.dbg >> 8) == 1) return;
     const int u = tile * BLOCK + (int)threadIdx.x;
     const bool in_u = u < U;
     const int* counts = reinterpret_cast<const int*>(t.span);
     const int cap = 1 << t.dshift;
     const int n_raw = in_u ? counts[hist_index(u, U)] : 0;
     const int nn = n_raw < cap ? n_raw : cap;
-    const BktRec* src = t.direct + ((long long)(in_u ? u : 0) << t.dshift);
+    const long long slot0 = (long long)(in_u ? u : 0) << t.dshift;
+    const BktRec* src = t.direct + slot0;
 
     // the user's union bucket: up to 8 rows ordered in this thread's registers; 9 .. 64 rows by the whole wave (below)
     long long ks[8];
     int ki[8];
-    unsigned km[8];
+    unsigned km[8], kh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         BktRec r;
         r.start = INT64_MAX;
         r.idx = INT32_MAX;
         r.pad = 0;
-        if (nn <= 8 && k < nn) r = src[k];
+        unsigned h = 0;
+        if (nn <= 8 && k < nn && !(t.dbg & 2)) {
+            r = src[k];
+            if constexpr (HI) h = t.direct_hi[slot0 + k];
+        }
         ks[k] = r.start;
         ki[k] = r.idx;
-        km[k] = (unsigned)r.pad >> q_lo; // this group's queries at bits 0 ..
+        km[k] = (unsigned)r.pad;
+        kh[k] = h;
     }
     if (nn >= 2 && nn <= 8) {
 #pragma unroll
@@ -2122,129 +2159,144 @@ __device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int g
                         const int i0 = sw ? ki[l] : ki[i], i1 = sw ? ki[i] : ki[l];
                         const unsigned m0 = sw ? km[l] : km[i], m1 = sw ? km[i] : km[l];
                         ks[i] = s0; ks[l] = s1; ki[i] = i0; ki[l] = i1; km[i] = m0; km[l] = m1;
+                        if constexpr (HI) {
+                            const unsigned h0 = sw ? kh[l] : kh[i], h1 = sw ? kh[i] : kh[l];
+                            kh[i] = h0; kh[l] = h1;
+                        }
                     }
                 }
             }
         }
     }
-    int cq[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) cq[q] = 0;
-    if (nn <= 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < nn) {
-#pragma unroll
-                for (int q = 0; q < QT; ++q) cq[q] += (int)((km[k] >> q) & 1u);
-            }
-    }
-    // larger buckets, phase A: per-query row counts (the prefix scans need them before anything can be placed)
-    const bool mid = nn > 8;
+    if ((t.dbg >> 8) == 2) { if (ks[0] == 12345 && ki[7] == 3) t.uoff[0] = km[3]; return; }
+    // ONE prefix scan: the union counts
+    const int incl = wave_incl_scan_i32(nn, lane);
     {
-        unsigned long long todo = __ballot(mid);
-        while (todo) {
-            const int src_lane = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int nb = __shfl(nn, src_lane, kWave);
-            const int ub = __shfl(u, src_lane, kWave);
-            unsigned qm = 0;
-            if (lane < nb) qm = (unsigned)(t.direct + ((long long)ub << t.dshift))[lane].pad >> q_lo;
-#pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const int cnt = __popcll(__ballot((qm >> q) & 1u));
-                if (lane == src_lane) cq[q] = cnt;
-            }
-        }
-    }
-    // Q prefix scans side by side
-    int incl[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-        incl[q] = wave_incl_scan_i32(cq[q], lane);
-        unsigned mx = (unsigned)cq[q];
+        unsigned mx = (unsigned)nn;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, kWave));
-        if (lane == 63) s_sum[q][wave] = incl[q];
-        if (lane == 0) s_max[q][wave] = mx;
+        if (lane == 63) s_sum[wave] = incl;
+        if (lane == 0) s_max[wave] = mx;
     }
     __syncthreads();
-    if ((int)threadIdx.x < nq) { // one granule per query: its tile sum (bits 0..30) and largest bucket (bits 31..61)
-        const int q = (int)threadIdx.x;
+    if (threadIdx.x == 0) { // the tile's granule: its sum (bits 0..30) and largest bucket (bits 31..61)
         long long tot = 0;
         unsigned mx = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) { tot += s_sum[q][w]; mx = max(mx, s_max[q][w]); }
-        unsigned long long* pub = reinterpret_cast<unsigned long long*>(t.span + (long long)(q_lo + q) * t.span_stride + t.tiles_off);
+        for (int w = 0; w < kWaves; ++w) { tot += s_sum[w]; mx = max(mx, s_max[w]); }
+        unsigned long long* pub = reinterpret_cast<unsigned long long*>(t.span + t.tiles_off);
         __hip_atomic_store(&pub[tile], kTileReady | ((unsigned long long)mx << 31) | (unsigned long long)tot, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    // base of every query = sum of its granules of the tiles in front of this one
-    long long part[QT];
-    unsigned pmax[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) { part[q] = 0; pmax[q] = 0; }
-    for (int tt = threadIdx.x; tt < tile; tt += BLOCK) {
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            if (q < nq) {
-                const unsigned long long* pub = reinterpret_cast<const unsigned long long*>(t.span + (long long)(q_lo + q) * t.span_stride + t.tiles_off);
-                unsigned long long v;
-                do {
-                    v = __hip_atomic_load(&pub[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(v & kTileReady)) __builtin_amdgcn_s_sleep(1);
-                } while (!(v & kTileReady));
-                part[q] += (long long)(v & 0x7FFFFFFFull);
-                pmax[q] = max(pmax[q], (unsigned)((v >> 31) & 0x7FFFFFFFull));
+    // while the predecessors' granules arrive: selected rows per query (what pie_scan_batch_finish reports).  Per lane the
+    // (<= 8) masks of its bucket are added up bit-sliced — planes b0..b3: bit q of plane i = bit i of "how many of my rows
+    // query q selected" — by a carry-save adder tree, no loop over queries; then lane q of the wave collects query q's total
+    // from four ballots per query.  No branch inside the loop: the chains of consecutive queries interleave (a first version
+    // with one ballot per bucket slot and query, each behind a wave-uniform branch, cost 20 of the kernel's 50 us at Q = 64).
+    const bool mid = nn > 8 && !(t.dbg & 32);
+    unsigned acc = 0;
+    if (!(t.dbg & 1)) {
+        auto fa = [](unsigned a, unsigned b, unsigned c, unsigned& carry) { const unsigned x = a ^ b; carry = (a & b) | (c & x); return x ^ c; };
+        unsigned pl[4], ph[4];
+        {
+            unsigned c1, c2, c3, c4, c5, c6;
+            const unsigned s1 = fa(km[0], km[1], km[2], c1), s2 = fa(km[3], km[4], km[5], c2);
+            const unsigned s3 = km[6] ^ km[7];
+            c3 = km[6] & km[7];
+            pl[0] = fa(s1, s2, s3, c4);
+            const unsigned tw = fa(c1, c2, c3, c5);
+            pl[1] = tw ^ c4;
+            c6 = tw & c4;
+            pl[2] = c5 ^ c6;
+            pl[3] = c5 & c6;
+        }
+        if constexpr (HI) {
+            unsigned c1, c2, c3, c4, c5, c6;
+            const unsigned s1 = fa(kh[0], kh[1], kh[2], c1), s2 = fa(kh[3], kh[4], kh[5], c2);
+            const unsigned s3 = kh[6] ^ kh[7];
+            c3 = kh[6] & kh[7];
+            ph[0] = fa(s1, s2, s3, c4);
+            const unsigned tw = fa(c1, c2, c3, c5);
+            ph[1] = tw ^ c4;
+            c6 = tw & c4;
+            ph[2] = c5 ^ c6;
+            ph[3] = c5 & c6;
+        } else {
+            ph[0] = ph[1] = ph[2] = ph[3] = 0;
+        }
+        const int nq_lo = nq < 32 ? nq : 32;
+#pragma unroll 4
+        for (int q = 0; q < nq_lo; ++q) {
+            const unsigned c = (unsigned)__popcll(__ballot((pl[0] >> q) & 1u)) + 2u * (unsigned)__popcll(__ballot((pl[1] >> q) & 1u)) +
+                               4u * (unsigned)__popcll(__ballot((pl[2] >> q) & 1u)) + 8u * (unsigned)__popcll(__ballot((pl[3] >> q) & 1u));
+            if (lane == q) acc = c;
+        }
+        if constexpr (HI) {
+#pragma unroll 4
+            for (int q = 32; q < nq; ++q) {
+                const unsigned c = (unsigned)__popcll(__ballot((ph[0] >> (q - 32)) & 1u)) + 2u * (unsigned)__popcll(__ballot((ph[1] >> (q - 32)) & 1u)) +
+                                   4u * (unsigned)__popcll(__ballot((ph[2] >> (q - 32)) & 1u)) + 8u * (unsigned)__popcll(__ballot((ph[3] >> (q - 32)) & 1u));
+                if (lane == q) acc = c;
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            part[q] += __shfl_xor(part[q], o, kWave);
-            pmax[q] = max(pmax[q], (unsigned)__shfl_xor((int)pmax[q], o, kWave));
+    if ((t.dbg >> 8) == 3) return;
+    // base = sum of the granules of the tiles in front of this one
+    long long part = 0;
+    unsigned pmax = 0;
+    {
+        const unsigned long long* pub = reinterpret_cast<const unsigned long long*>(t.span + t.tiles_off);
+        for (int tt = threadIdx.x; tt < ((t.dbg & 4) ? 0 : tile); tt += BLOCK) {
+            unsigned long long v;
+            do {
+                v = __hip_atomic_load(&pub[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(v & kTileReady)) __builtin_amdgcn_s_sleep(1);
+            } while (!(v & kTileReady));
+            part += (long long)(v & 0x7FFFFFFFull);
+            pmax = max(pmax, (unsigned)((v >> 31) & 0x7FFFFFFFull));
         }
-        if (lane == 0) { s_part[q][wave] = part[q]; s_pmax[q][wave] = pmax[q]; }
     }
-    __syncthreads();
-    long long run[QT];
 #pragma unroll
-    for (int q = 0; q < QT; ++q) {
+    for (int o = 32; o > 0; o >>= 1) {
+        part += __shfl_xor(part, o, kWave);
+        pmax = max(pmax, (unsigned)__shfl_xor((int)pmax, o, kWave));
+    }
+    if (lane == 0) { s_part[wave] = part; s_pmax[wave] = pmax; }
+    __syncthreads();
+    long long run = incl - nn;
+    {
         long long base = 0;
         unsigned pm = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) { base += s_part[q][w]; pm = max(pm, s_pmax[q][w]); }
-        pmax[q] = pm;
-        run[q] = base + incl[q] - cq[q];
-        for (int w = 0; w < wave; ++w) run[q] += s_sum[q][w];
+        for (int w = 0; w < kWaves; ++w) { base += s_part[w]; pm = max(pm, s_pmax[w]); }
+        pmax = pm;
+        run += base;
+        for (int w = 0; w < wave; ++w) run += s_sum[w];
     }
-    const long long us = t.users_stride;
+    if ((t.dbg >> 8) == 4) { if (run == 12345) t.uoff[0] = run; return; }
+    int* msg_rows = t.msg ? t.msg + t.u_pad + 2 : nullptr;
+    int* msg_lo = t.msg ? msg_rows + t.msg_cap : nullptr;
+    int* msg_hi = t.msg ? msg_lo + t.msg_cap : nullptr;
     if (in_u) {
+        t.uoff[u] = run;
+        if (t.msg) msg_store(t.msg + u, (int)run);
+        if (nn >= 1 && nn <= 8 && !(t.dbg & 8)) {
 #pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            if (q < nq) {
-                t.counts_ord[(long long)(q_lo + q) * us + u] = cq[q];
-                t.offsets[(long long)(q_lo + q) * us + u] = run[q];
-                if (t.msg_counts) msg_store(t.msg_counts + (long long)(q_lo + q) * t.msg_counts_stride + u, cq[q]);
-                int* msg = t.msg ? t.msg + (long long)(q_lo + q) * t.msg_stride : nullptr;
-                if (msg) msg_store(msg + u, (int)run[q]);
-                // this query's rows of a small bucket, in bucket order
-                if (nn >= 1 && nn <= 8 && cq[q] > 0 && run[q] + cq[q] <= t.out_stride) {
-                    int* out = t.out_idx + (long long)(q_lo + q) * t.out_stride;
-                    long long pos = run[q];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k < nn && ((km[k] >> q) & 1u)) {
-                            out[pos] = ki[k];
-                            if (msg && pos < t.msg_cap) msg_store(msg + t.u_pad + 2 + pos, ki[k]);
-                            ++pos;
-                        }
+            for (int k = 0; k < 8; ++k)
+                if (k < nn) {
+                    const long long pos = run + k;
+                    t.urows[pos] = ki[k];
+                    t.umlo[pos] = km[k];
+                    if constexpr (HI) t.umhi[pos] = kh[k];
+                    if (t.msg && pos < t.msg_cap) {
+                        msg_store(msg_rows + pos, ki[k]);
+                        msg_store(msg_lo + pos, (int)km[k]);
+                        if constexpr (HI) msg_store(msg_hi + pos, (int)kh[k]);
+                    }
                 }
-            }
         }
     }
-    // larger buckets, phase B: lane i < n holds record i and counts, per query, the query's records that sort before it
+    // larger buckets: lane i < n holds record i and counts the records that sort before it
     {
         unsigned long long todo = __ballot(mid && in_u);
         while (todo) {
@@ -2252,97 +2304,122 @@ __device__ __forceinline__ void offsets_union_body(const BatchTailArgs& t, int g
             todo &= todo - 1;
             const int nb = __shfl(nn, src_lane, kWave);
             const int ub = __shfl(u, src_lane, kWave);
+            const long long rq = __shfl(run, src_lane, kWave);
             BktRec r;
             r.start = INT64_MAX;
             r.idx = INT32_MAX;
             r.pad = 0;
-            if (lane < nb) r = (t.direct + ((long long)ub << t.dshift))[lane];
-            // byte q of lo (q < 8) / hi (q >= 8) counts the records of query q that sort before this lane's record
-            unsigned long long lo = 0, hi = 0;
+            unsigned hi = 0;
+            if (lane < nb) {
+                r = (t.direct + ((long long)ub << t.dshift))[lane];
+                if constexpr (HI) hi = t.direct_hi[((long long)ub << t.dshift) + lane];
+            }
+            int rank = 0;
             for (int j = 0; j < nb; ++j) {
                 const long long sj = __shfl(r.start, j, kWave);
                 const int ij = __shfl(r.idx, j, kWave);
-                const unsigned mj = (unsigned)__shfl(r.pad, j, kWave) >> q_lo;
-                if (key_less(sj, ij, r.start, r.idx)) {
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-                        const unsigned long long one = (unsigned long long)((mj >> q) & 1u) << (8 * (q & 7));
-                        if (q < 8) lo += one; else hi += one;
-                    }
+                rank += key_less(sj, ij, r.start, r.idx) ? 1 : 0;
+                // lane q counts the rows of this bucket that query q selected (the per-query totals)
+                unsigned mj = (unsigned)__shfl(r.pad, j, kWave);
+                if constexpr (HI) {
+                    const unsigned hj = (unsigned)__shfl((int)hi, j, kWave);
+                    mj = lane >= 32 ? hj : mj;
                 }
+                acc += (mj >> (lane & 31)) & 1u;
             }
-#pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const long long rq = __shfl(run[q], src_lane, kWave);
-                const int cnt = __shfl(cq[q], src_lane, kWave);
-                if (q < nq && lane < nb && (((unsigned)r.pad >> (q_lo + q)) & 1u) && rq + cnt <= t.out_stride) {
-                    const long long pos = rq + (long long)(((q < 8 ? lo : hi) >> (8 * (q & 7))) & 0xFFull);
-                    t.out_idx[(long long)(q_lo + q) * t.out_stride + pos] = r.idx;
-                    int* msg = t.msg ? t.msg + (long long)(q_lo + q) * t.msg_stride : nullptr;
-                    if (msg && pos < t.msg_cap) msg_store(msg + t.u_pad + 2 + pos, r.idx);
+            if (lane < nb) {
+                const long long pos = rq + rank;
+                t.urows[pos] = r.idx;
+                t.umlo[pos] = (unsigned)r.pad;
+                if constexpr (HI) t.umhi[pos] = hi;
+                if (t.msg && pos < t.msg_cap) {
+                    msg_store(msg_rows + pos, r.idx);
+                    msg_store(msg_lo + pos, r.pad);
+                    if constexpr (HI) msg_store(msg_hi + pos, (int)hi);
                 }
             }
         }
     }
-    if (in_u && n_raw > cap) (void)wave_list_slot(&sumg->n_over); // a bucket outgrew its slots: the host reruns the queries
+    // the block's per-query totals -> the slot of this tile
+    s_mq[wave][lane] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < nq) {
+        unsigned tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tot += s_mq[w][threadIdx.x];
+        if (tot) atomicAdd(&mq_slots[(tile & (kMqSlots - 1)) * kBatchMax + (int)threadIdx.x], tot);
+    }
+    if (in_u && n_raw > cap) (void)wave_list_slot(&sum->n_over); // a bucket outgrew its slots: the host reruns the queries
     if (in_u && u == U - 1) { // the thread holding the last user sits in the last tile, which has seen every granule
+        unsigned tmax = 0;
 #pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            if (q < nq) {
-                unsigned tmax = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) tmax = max(tmax, s_max[q][w]);
-                const long long m_all = run[q] + cq[q];
-                t.offsets[(long long)(q_lo + q) * us + U] = m_all;
-                Summary* sq = reinterpret_cast<Summary*>(t.span + (long long)(q_lo + q) * t.span_stride + t.summary_off);
-                __hip_atomic_store(&sq->m, (unsigned long long)m_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&sq->max_count, max(pmax[q], tmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_total[q] = m_all;
-            }
-        }
+        for (int w = 0; w < kWaves; ++w) tmax = max(tmax, s_max[w]);
+        const long long m_all = run + nn;
+        t.uoff[U] = m_all;
+        __hip_atomic_store(&sum->m, (unsigned long long)m_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sum->max_count, max(pmax, tmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_total = m_all;
     }
-    if (t.msg && tile == nblk - 1) { // message tails: off[u] = M for the padding users, then the M word
+    if (t.msg && tile == nblk - 1) { // message tail: uoff[u] = Mu for the padding users, then the Mu word
         __syncthreads();
-        for (int q = 0; q < nq; ++q) {
-            int* msg = t.msg + (long long)(q_lo + q) * t.msg_stride;
-            const long long m_all = s_total[q];
-            for (int uu = U + threadIdx.x; uu <= t.u_pad + 1; uu += BLOCK) msg_store(msg + uu, (int)m_all);
-        }
+        const long long m_all = s_total;
+        for (int uu = U + threadIdx.x; uu <= t.u_pad + 1; uu += BLOCK) msg_store(t.msg + uu, (int)m_all);
     }
-    // completion: the last block hands every query's summary to the host (see offsets_body)
+    if ((t.dbg >> 8) == 5) return;
+    // completion: the last block hands the summary and the per-query totals to the host (see offsets_body)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) is_last = (atomicAdd(&ctl->done, 1u) == (unsigned)nblk - 1u && t.host) ? 1 : 0;
     __syncthreads();
-    if (is_last && threadIdx.x < 64) {
-        unsigned long long live = 0, amb = 0, cand = 0;
-        unsigned int chunk_max = 0;
-        sum_row_stats(sum0, (int)threadIdx.x, live, amb, &cand, &chunk_max);
-        if ((int)threadIdx.x < nq) {
-            const int q = (int)threadIdx.x;
-            Summary* sq = reinterpret_cast<Summary*>(t.span + (long long)(q_lo + q) * t.span_stride + t.summary_off);
-            Summary out;
-            out.m = __hip_atomic_load(&sq->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.n_seg = out.n_big = out.n_small = 0;
-            out.max_count = __hip_atomic_load(&sq->max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.bad_rows = __hip_atomic_load(&sum0->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.q = 0;
-            out.live = 0;
-            out.pad = 0;
-            out.amb = 0;
-            out.n_hot = 0;
-            out.n_over = __hip_atomic_load(&sumg->n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out.cand = cand;
-            out.chunk_max = chunk_max;
-            out.pad2 = 0;
-            t.host[q_lo + q].s = out;
-            __hip_atomic_store(&t.host[q_lo + q].seq, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (is_last) {
+        // per-query totals: 64 slots x n_q counters.  All 256 threads read (16 slots each, INDEPENDENT loads: summed straight
+        // into one register the compiler waits for each of them — 64 dependent L2 round trips were 14 of the kernel's 38 us)
+        {
+            const int q = (int)threadIdx.x & 63, g = (int)threadIdx.x >> 6;
+            unsigned v[kMqSlots / kWaves];
+#pragma unroll
+            for (int i = 0; i < kMqSlots / kWaves; ++i)
+                v[i] = q < nq ? __hip_atomic_load(&mq_slots[(g * (kMqSlots / kWaves) + i) * kBatchMax + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            unsigned tot = 0;
+#pragma unroll
+            for (int i = 0; i < kMqSlots / kWaves; ++i) tot += v[i];
+            s_mq[g][q] = tot;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            unsigned long long live = 0, amb = 0, cand = 0;
+            unsigned int chunk_max = 0;
+            sum_row_stats(sum, (int)threadIdx.x, live, amb, &cand, &chunk_max);
+            unsigned long long mq = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) mq += s_mq[w][threadIdx.x];
+            t.host->mq[threadIdx.x] = mq;
+            if (threadIdx.x == 0) {
+                Summary out;
+                out.m = __hip_atomic_load(&sum->m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.n_seg = out.n_big = out.n_small = 0;
+                out.max_count = __hip_atomic_load(&sum->max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.bad_rows = __hip_atomic_load(&sum->bad_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.q = 0;
+                out.live = 0;
+                out.pad = 0;
+                out.amb = 0;
+                out.n_hot = 0;
+                out.n_over = __hip_atomic_load(&sum->n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.cand = cand;
+                out.chunk_max = chunk_max;
+                out.pad2 = 0;
+                t.host->s = out;
+            }
+            // every lane's stores above precede this instruction in the wave's program order; the release waits for them all
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&t.host->seq, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-template <int QT>
-__global__ __launch_bounds__(kK1Threads) void k_offsets_batch(BatchTailArgs t) { offsets_union_body<QT>(t, (int)blockIdx.x); }
+template <bool HI>
+__global__ __launch_bounds__(kK1Threads) void k_union_tail(UnionTailArgs t) { union_tail_body<HI>(t, (int)blockIdx.x); }
 
 template <int UNROLL, bool NT, class KT>
 __global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
@@ -2350,13 +2427,143 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_batch(BatchScanArgs<KT> a)
     scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// table pass of batch i+1 with the offsets kernel of batch i in its first blocks (see k_scan_keyed_with_tail)
-template <int UNROLL, bool NT, class KT, int QT>
-__global__ __launch_bounds__(kK1Threads) void k_scan_batch_with_tail(BatchScanArgs<KT> a, BatchTailArgs t)
+// table pass of batch i+1 with the union tail of batch i in its first blocks (see k_scan_keyed_with_tail)
+template <int UNROLL, bool NT, class KT, bool HI>
+__global__ __launch_bounds__(kK1Threads) void k_scan_batch_with_tail(BatchScanArgs<KT> a, UnionTailArgs t)
 {
-    const int n_tail = t.tiles * (t.n_q > 8 ? 2 : 1);
-    if ((int)blockIdx.x < n_tail) offsets_union_body<QT>(t, (int)blockIdx.x);
+    const int n_tail = t.tiles;
+    if ((int)blockIdx.x < n_tail) union_tail_body<HI>(t, (int)blockIdx.x);
     else scan_batch_body<UNROLL, NT, KT>(a, (int)blockIdx.x - n_tail, (int)gridDim.x - n_tail);
+}
+
+// ---- per-query results of a batch, materialised from its union on request (pie_batch_read_results / _result_device_ptrs, the
+// per-query exchange messages): counts[U], offsets[U+1] and the row list of query q, bit for bit what a single scan of that
+// query gives.  Three small launches for any number of queries (blockIdx.y = index into the list of queries asked for): per-tile
+// counts, a one-block prefix of the tile sums per query, the write.  Off the hot path: no tickets, no spinning.
+struct MatArgs {
+    int n_users, tiles, n_list;
+    const long long* uoff;
+    const int* urows;
+    const unsigned* umlo;
+    const unsigned* umhi;      // nullptr for batches of <= 32 queries
+    int* counts;               // + q * users_stride
+    long long* offsets;        // + q * users_stride
+    long long users_stride;
+    int* out[kBatchMax];       // row list of the i-th query asked for
+    long long out_cap[kBatchMax];
+    long long* tile_sum;       // [n_list][tiles + 1] scratch: tile sums, then their exclusive prefix (entry `tiles` = M)
+    unsigned int* qmax;        // [n_list] largest per-user count
+    unsigned char q_of[kBatchMax]; // the queries asked for
+};
+
+__device__ __forceinline__ int mat_count_user(const MatArgs& a, int u, int q)
+{
+    const long long lo = a.uoff[u], hi = a.uoff[u + 1];
+    const unsigned* m = (q >= 32) ? a.umhi : a.umlo;
+    int c = 0;
+    for (long long j = lo; j < hi; ++j) c += (int)((m[j] >> (q & 31)) & 1u);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_mat_count(MatArgs a)
+{
+    __shared__ int s_w[4];
+    __shared__ unsigned s_m[4];
+    const int li = (int)blockIdx.y, q = a.q_of[li];
+    const int u = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = u < a.n_users ? mat_count_user(a, u, q) : 0;
+    if (u < a.n_users) a.counts[(long long)q * a.users_stride + u] = c;
+    int v = c;
+    unsigned mx = (unsigned)c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o, kWave);
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, o, kWave));
+    }
+    if (lane == 0) { s_w[wave] = v; s_m[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.tile_sum[(long long)li * (a.tiles + 1) + blockIdx.x] = (long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const unsigned m4 = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m4) atomicMax(&a.qmax[li], m4);
+    }
+}
+
+// one block per query: exclusive prefix of its tile sums in place; entry `tiles` receives M
+__global__ __launch_bounds__(1024) void k_mat_prefix(MatArgs a)
+{
+    __shared__ long long s_w[16];
+    __shared__ long long s_carry;
+    long long* ts = a.tile_sum + (long long)blockIdx.x * (a.tiles + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.tiles; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const long long v = i < a.tiles ? ts[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const long long tt = __shfl_up(inc, o, kWave);
+            if (lane >= o) inc += tt;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        long long before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_w[w];
+        if (i < a.tiles) ts[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ts[a.tiles] = s_carry;
+        a.offsets[(long long)a.q_of[blockIdx.x] * a.users_stride + a.n_users] = s_carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mat_write(MatArgs a)
+{
+    __shared__ int s_w[4];
+    const int li = (int)blockIdx.y, q = a.q_of[li];
+    const int u = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = u < a.n_users ? mat_count_user(a, u, q) : 0;
+    const int inc = wave_incl_scan_i32(c, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    long long at = a.tile_sum[(long long)li * (a.tiles + 1) + blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; ++w) at += s_w[w];
+    if (u >= a.n_users) return;
+    a.offsets[(long long)q * a.users_stride + u] = at;
+    if (c == 0 || at + c > a.out_cap[li]) return;
+    int* out = a.out[li];
+    const unsigned* m = (q >= 32) ? a.umhi : a.umlo;
+    const long long lo = a.uoff[u], hi = a.uoff[u + 1];
+    for (long long j = lo; j < hi; ++j)
+        if ((m[j] >> (q & 31)) & 1u) out[at++] = a.urows[j];
+}
+
+// the union arrays as one int32 message in caller-owned device-visible memory (layout: UnionTailArgs::msg)
+__global__ __launch_bounds__(256) void k_union_pack(int n_users, int u_pad, const long long* __restrict__ uoff, const int* __restrict__ urows,
+                                                    const unsigned* __restrict__ umlo, const unsigned* __restrict__ umhi, long long cap,
+                                                    int* __restrict__ dst)
+{
+    const long long mu = uoff[n_users];
+    const long long k = mu < cap ? mu : cap;
+    const long long head = (long long)u_pad + 2;
+    int* rows = dst + head;
+    int* lo = rows + cap;
+    int* hi = lo + cap;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < head; i += stride)
+        dst[i] = i <= n_users ? (int)uoff[i] : (int)mu;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += stride) {
+        rows[i] = urows[i];
+        lo[i] = (int)umlo[i];
+        if (umhi) hi[i] = (int)umhi[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K3 scatter
@@ -2763,6 +2970,22 @@ __global__ __launch_bounds__(256) void k_pack_results(const long long* __restric
     }
 }
 
+// the same message from lists whose M the host knows (a batch's per-query lists)
+__global__ __launch_bounds__(256) void k_pack_lists(const long long* __restrict__ offsets, int n_users, int u_pad, long long m,
+                                                    const int* __restrict__ out_idx, long long cap, int* __restrict__ dst)
+{
+    const long long k = m < cap ? m : cap;
+    const long long head = (long long)u_pad + 2;
+    const long long total = head + k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int v;
+        if (i <= n_users) v = (int)offsets[i];
+        else if (i < head) v = (int)m;
+        else v = out_idx[i - head];
+        dst[i] = v;
+    }
+}
+
 // The UNION message of a batch (multi-GPU exchange).  The Q queries of a batch are requests of the same few seconds: their
 // row lists are almost the same rows, Q times over.  Per user the union of the Q lists, in (start, row) order, with a query
 // mask per row, is what the exchange needs to move — 8 B per union row instead of 4 B per row per query:
@@ -2839,61 +3062,6 @@ __global__ __launch_bounds__(kUnionThreads) void k_union_collect(int n_q, int n_
     }
     ucnt[u] = n;
     if (overflow) atomicOr(over, 1);
-}
-
-// The general batched pass already holds the union: one bucket slot {start, row, query mask} per row that any query selected
-// (scan_batch_body), counted in the union histogram.  One thread per user orders its slots — a few contiguous 16-byte loads,
-// no chasing through Q row lists (the generic form above is latency-bound: three dependent loads per row and query).
-__global__ __launch_bounds__(kUnionThreads) void k_union_from_buckets(int n_users, const int* __restrict__ counts,
-                                                                      const BktRec* __restrict__ direct, int dshift,
-                                                                      UnionRow* __restrict__ scratch, int* __restrict__ ucnt,
-                                                                      int* __restrict__ over)
-{
-    __shared__ int l_row[kUnionMax][kUnionThreads];
-    __shared__ unsigned l_mask[kUnionMax][kUnionThreads];
-    __shared__ long long l_start[kUnionMax][kUnionThreads];
-    const int t = threadIdx.x;
-    const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (u >= n_users) return;
-    int n = counts[hist_index(u, n_users)];
-    if (n > (1 << dshift) || n > kUnionMax) { // cannot happen for a batch without overflow; never read beyond the slots
-        atomicOr(over, 1);
-        n = n > kUnionMax ? kUnionMax : n;
-        if (n > (1 << dshift)) n = 1 << dshift;
-    }
-    const BktRec* slots = direct + ((long long)u << dshift);
-    for (int i = 0; i < n; ++i) {
-        const BktRec r = slots[i];
-        l_row[i][t] = r.idx;
-        l_mask[i][t] = (unsigned)r.pad;
-        l_start[i][t] = r.start;
-    }
-    for (int i = 1; i < n; ++i) {
-        const int xr = l_row[i][t];
-        const unsigned xm = l_mask[i][t];
-        const long long xs = l_start[i][t];
-        int j = i - 1;
-        while (j >= 0) {
-            const long long ys = l_start[j][t];
-            const int yr = l_row[j][t];
-            if (ys < xs || (ys == xs && yr < xr)) break;
-            l_row[j + 1][t] = yr;
-            l_mask[j + 1][t] = l_mask[j][t];
-            l_start[j + 1][t] = ys;
-            --j;
-        }
-        l_row[j + 1][t] = xr;
-        l_mask[j + 1][t] = xm;
-        l_start[j + 1][t] = xs;
-    }
-    UnionRow* mine = scratch + (long long)u * kUnionMax;
-    for (int i = 0; i < n; ++i) {
-        UnionRow x;
-        x.row = l_row[i][t];
-        x.mask = l_mask[i][t];
-        mine[i] = x;
-    }
-    ucnt[u] = n;
 }
 
 // uoff[u] = group_base[u >> 10] + unit_local[u]: the two-level prefix of the union counts (k_ord_prefix + k_ord_prefix_groups,

@@ -803,6 +803,7 @@ __global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summar
 //   k_ord_batch_emit    per run of 32 chunks (heavy runs: per chunk): every query's row list (the row id comes with the record, compacted per query
 //                       by ballot); per user: every query's offset and count
 //   k_ord_publish       (gridDim.x = Q) summaries
+constexpr int kOrdBatchMax = 16; // queries per pass over the run (a larger batch runs as consecutive passes of 16)
 struct OrdBatchQuery {
     long long now, cutoff;
     unsigned long long mask;
@@ -812,7 +813,7 @@ struct OrdBatchQuery {
 struct OrdBatchArgs {
     int n_q;
     unsigned min_key;
-    OrdBatchQuery q[kBatchMax];
+    OrdBatchQuery q[kOrdBatchMax];
 };
 // A union staging record lives in its chunk's 512 slots, so its position is the chunk + 9 bits; with the 16 query bits that
 // leaves a whole word for the row id: the emit kernel reads the row where it reads the mask, not through a second, dependent
@@ -821,7 +822,7 @@ struct alignas(8) OrdUnion {
     int row;
     unsigned qsub; // bits 0..15: the queries that select the row; bits 16..24: its position inside the chunk
 };
-static_assert(kBatchMax <= 16, "OrdUnion keeps the query mask in 16 bits");
+static_assert(kOrdBatchMax <= 16, "OrdUnion keeps the query mask in 16 bits");
 constexpr unsigned kOrdSubMask = 511u; // k_ord_batch_scan's chunk: 512 positions for both key widths
 
 // A chunk is 512 positions for both key widths: 8 one-byte keys (one 8-byte load) or 8 two-byte keys (one 16-byte load) per
@@ -1024,18 +1025,18 @@ __global__ __launch_bounds__(256) void k_ord_batch_count(const OrdUnion* __restr
     for (long long base = wv << 6; base < padded; base += n_waves << 6) {
         const long long ch = base + lane; // < padded: a multiple of 64
         const int cnt = ch < n_chunks ? ucount[ch] : 0;
-        int tot[kBatchMax];
+        int tot[kOrdBatchMax];
 #pragma unroll
-        for (int q = 0; q < kBatchMax; ++q) tot[q] = 0;
+        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
         if (cnt <= kOrdChunkHeavy) {
             const OrdUnion* rec = ustage + (ch << chunk_shift);
             for (int j = 0; j < cnt; ++j) {
                 const unsigned qm = rec[j].qsub;
 #pragma unroll
-                for (int q = 0; q < kBatchMax; ++q) tot[q] += (qm >> q) & 1u;
+                for (int q = 0; q < kOrdBatchMax; ++q) tot[q] += (qm >> q) & 1u;
             }
 #pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) {
+            for (int q = 0; q < kOrdBatchMax; ++q) {
                 if (q >= n_q) break;
                 cq[(long long)q * unit_stride + ch] = tot[q];
             }
@@ -1084,9 +1085,9 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
                                                         const int* __restrict__ run_flag, const int* __restrict__ cq)
 {
     const int user_blocks = (int)gridDim.x - copy_blocks;
-    __shared__ int soff[kBatchMax][256];
+    __shared__ int soff[kOrdBatchMax][256];
     __shared__ int sincl[4][kWave];
-    __shared__ int wmax[kBatchMax][4];
+    __shared__ int wmax[kOrdBatchMax][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
         const long long n_runs = (n_chunks + kOrdRun - 1) >> kOrdRunShift;
         auto put = [&](const OrdUnion& r, int row, long long& next) { // one round of up to 64 records: each query's rows, compacted by ballot
 #pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) {
+            for (int q = 0; q < kOrdBatchMax; ++q) {
                 if (q >= n_q) break; // wave-uniform
                 const bool sel = (r.qsub >> q) & 1u;
                 const unsigned long long b = __ballot(sel);
@@ -1164,9 +1165,9 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
         return;
     }
     const long long u = (long long)blockIdx.x * 255 + threadIdx.x;
-    int below[kBatchMax]; // records of my chunk before my segment start, per query
+    int below[kOrdBatchMax]; // records of my chunk before my segment start, per query
 #pragma unroll
-    for (int q = 0; q < kBatchMax; ++q) below[q] = 0;
+    for (int q = 0; q < kOrdBatchMax; ++q) below[q] = 0;
     long long ch = -1;
     bool at_end = true;
     int jb = 0; // records of my chunk that lie before my segment start (staged in position order: a binary search)
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
         for (int j = j_lo; j < j_hi; ++j) {
             const unsigned qm = rec[j].qsub;
 #pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) below[q] += (qm >> q) & 1u;
+            for (int q = 0; q < kOrdBatchMax; ++q) below[q] += (qm >> q) & 1u;
         }
     }
     unsigned long long todo = __ballot(heavy);
@@ -1210,32 +1211,32 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
         const long long lch = __shfl(ch, leader, kWave);
         const int l_lo = __shfl(j_lo, leader, kWave), l_hi = __shfl(j_hi, leader, kWave);
         const OrdUnion* lrec = ustage + (lch << chunk_shift);
-        int tot[kBatchMax];
+        int tot[kOrdBatchMax];
 #pragma unroll
-        for (int q = 0; q < kBatchMax; ++q) tot[q] = 0;
+        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
         for (int j0 = l_lo; j0 < l_hi; j0 += 64) {
             const unsigned qm = j0 + lane < l_hi ? lrec[j0 + lane].qsub : 0u;
 #pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) {
+            for (int q = 0; q < kOrdBatchMax; ++q) {
                 if (q >= n_q) break;
                 tot[q] += __popcll(__ballot((qm >> q) & 1u));
             }
         }
         if (lane == leader) {
 #pragma unroll
-            for (int q = 0; q < kBatchMax; ++q) below[q] = tot[q];
+            for (int q = 0; q < kOrdBatchMax; ++q) below[q] = tot[q];
         }
         todo &= todo - 1;
     }
     if (from_end) {
 #pragma unroll
-        for (int q = 0; q < kBatchMax; ++q) {
+        for (int q = 0; q < kOrdBatchMax; ++q) {
             if (q >= n_q) break;
             below[q] = cq[(long long)q * unit_stride + ch] - below[q];
         }
     }
 #pragma unroll
-    for (int q = 0; q < kBatchMax; ++q) {
+    for (int q = 0; q < kOrdBatchMax; ++q) {
         if (q >= n_q) break;
         long long my = 0;
         if (u <= n_users) {

@@ -97,30 +97,45 @@ struct Slot {
     int ev_index = -1; // index into the event ring, -1 = not profiled
 };
 
-// everything one batch of queries owns (see pie_kernels.h "batched scan"); per-query arrays have a fixed stride
+// everything one batch of queries owns (see pie_kernels.h "batched scan").  The primary result of a batch on the general pass
+// is the UNION (uoff / urows / umlo / umhi); per-query lists are materialised from it on request, or produced directly by the
+// paths that work per query (fallback scans on the general path, a batch on the ordered run).
 struct BatchSlot {
     int n_q = 0;
     bool in_flight = false, k2_pending = false, have_result = false;
     int dshift = 4;                    // union bucket capacity (log2) the batch ran with
-    bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no K2, nothing rides
+    bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no tail, nothing rides
     bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
     bool fine_key = false;
     unsigned long long seq = 0;
-    char* span = nullptr;              // this batch's span set
-    char* zero_span = nullptr;         // the set its K2 zeroes
-    int* counts_ord = nullptr;         // [kBatchMax][users_stride]
-    long long* offsets = nullptr;      // [kBatchMax][users_stride]
-    BktRec* direct = nullptr;          // union bucket slots: [cap_users << bdshift]; BktRec::pad = the queries that selected the row
-    int* out_idx = nullptr;            // [kBatchMax][out_stride]
-    HostSummary* h_sum = nullptr;      // [kBatchMax] mapped pinned
+    char* span = nullptr;              // this batch's span (histogram | tile granules | ctl | summary + row statistics | mq slots)
+    char* zero_span = nullptr;         // the span its tail zeroes
+    BktRec* direct = nullptr;          // union bucket slots: [cap_users << bdshift]; BktRec::pad = queries 0..31 that selected the row
+    unsigned* direct_hi = nullptr;     // ... queries 32..63
+    long long* uoff = nullptr;         // the union result: [cap_users + 1]
+    int* urows = nullptr;              // [cap_users << bdshift]
+    unsigned* umlo = nullptr;
+    unsigned* umhi = nullptr;
+    bool union_ok = false;             // the union arrays hold every query of the finished batch
+    bool union_part = false;           // ... the queries that did not fall back
+    unsigned long long mu = 0;         // union rows
+    BatchHost* bh = nullptr;           // mapped pinned: the tail's summary + per-query totals
+    BatchHost* bh_dev = nullptr;
+    int lists_q = 0;                   // queries the per-query list storage below holds (0: not allocated)
+    int* counts_ord = nullptr;         // [lists_q][users_stride]
+    long long* offsets = nullptr;      // [lists_q][users_stride]
+    int* out_idx = nullptr;            // [lists_q][out_stride]
+    bool list_ok[kBatchMax];           // query q's counts / offsets / row list are in the list storage
+    HostSummary* h_sum = nullptr;      // [kBatchMax] mapped pinned (the ordered run's batched form publishes per query)
     HostSummary* h_sum_dev = nullptr;
     pie_query q[kBatchMax];
     bool fallback[kBatchMax];          // rerun on the general path (dense query, outgrown bucket, bad rows)
     Summary last[kBatchMax];
-    int* over_idx[kBatchMax] = {};     // row list of a fallback query that outgrew out_stride
+    int* over_idx[kBatchMax] = {};     // row list of a query that outgrew out_stride
     long long over_cap[kBatchMax] = {};
-    int* idx_of[kBatchMax] = {};       // where query q's row list lives after finish
-    int* msg = nullptr;                // optional per-query messages (caller-owned device-visible memory)
+    int* idx_of[kBatchMax] = {};       // where query q's row list lives (valid with list_ok[q])
+    int msg_kind = 0;                  // 0: none; 1: one message per query (lists); 2: ONE union message
+    int* msg = nullptr;                // caller-owned device-visible memory
     long long msg_stride = 0, msg_cap = 0;
     int msg_u_pad = 0;
     int* msg_counts = nullptr;
@@ -269,7 +284,10 @@ struct pie_ctx {
     bool ord_building = false;  // the scan being begun is the ordered run's build
     Slot slot[2];
     BatchSlot bslot[2];         // batched scans (pie_scan_batch_begin): two batches may be in flight, like two scans
-    char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating span SETS: kBatchMax spans each, query q at q * counts_span()
+    char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating batch spans (batch_span_bytes each)
+    long long* d_mat_tile = nullptr;   // materialisation scratch: [kBatchMax][tiles + 1] tile sums / prefixes
+    unsigned int* d_mat_qmax = nullptr; // ... [kBatchMax] largest per-user count
+    int mat_tiles = 0;
     int bspan_next = 0;
     int b_next = 0;             // batch slot the next begin uses
     int b_flight = 0;           // batches begun and not finished (0..2)
@@ -365,11 +383,15 @@ void free_batch(pie_ctx* c)
 {
     for (BatchSlot& b : c->bslot) {
         dfree(b.counts_ord); dfree(b.offsets); dfree(b.direct); dfree(b.out_idx);
-        for (int q = 0; q < kBatchMax; ++q) { dfree(b.over_idx[q]); b.over_cap[q] = 0; b.idx_of[q] = nullptr; }
-        b.in_flight = b.k2_pending = b.have_result = false;
+        dfree(b.direct_hi); dfree(b.uoff); dfree(b.urows); dfree(b.umlo); dfree(b.umhi);
+        b.lists_q = 0;
+        for (int q = 0; q < kBatchMax; ++q) { dfree(b.over_idx[q]); b.over_cap[q] = 0; b.idx_of[q] = nullptr; b.list_ok[q] = false; }
+        b.in_flight = b.k2_pending = b.have_result = b.union_ok = b.union_part = false;
         b.n_q = 0;
     }
     for (char*& sp : c->bspan) dfree(sp);
+    dfree(c->d_mat_tile); dfree(c->d_mat_qmax);
+    c->mat_tiles = 0;
     c->bspan_next = 0;
     c->b_next = 0;
     c->b_flight = 0;
@@ -1211,11 +1233,11 @@ int ord_batch_alloc(pie_ctx* c)
     OrderedRun& o = c->ord;
     if (o.bq_count) return PIE_OK;
     const size_t units = (size_t)o.units_cap, groups = units / 1024 + 2;
-    const bool ok = hipMalloc(&o.bq_count, (size_t)kBatchMax * units * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_local, (size_t)kBatchMax * units * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_gsum, (size_t)kBatchMax * groups * 8) == hipSuccess &&
-                    hipMalloc(&o.bq_gbase, (size_t)kBatchMax * groups * 8) == hipSuccess &&
-                    hipMalloc(&o.bq_ctl, (size_t)kBatchMax * sizeof(OrdCtl)) == hipSuccess && hipMalloc(&o.bq_runflag, (units / 32 + 2) * 4) == hipSuccess &&
+    const bool ok = hipMalloc(&o.bq_count, (size_t)kOrdBatchMax * units * 4) == hipSuccess &&
+                    hipMalloc(&o.bq_local, (size_t)kOrdBatchMax * units * 4) == hipSuccess &&
+                    hipMalloc(&o.bq_gsum, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
+                    hipMalloc(&o.bq_gbase, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
+                    hipMalloc(&o.bq_ctl, (size_t)kOrdBatchMax * sizeof(OrdCtl)) == hipSuccess && hipMalloc(&o.bq_runflag, (units / 32 + 2) * 4) == hipSuccess &&
                     hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess &&
                     hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess;
     if (!ok) {
@@ -1223,7 +1245,7 @@ int ord_batch_alloc(pie_ctx* c)
         dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
         return PIE_E_NOMEM;
     }
-    PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kBatchMax * sizeof(OrdCtl), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kOrdBatchMax * sizeof(OrdCtl), c->stream));
     PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
     PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
     return PIE_OK;
@@ -1241,24 +1263,27 @@ bool ordered_batch_wanted(const pie_ctx* c)
 }
 
 // six launches: key stream -> union records; per-query chunk counts; per-query prefix (two kernels); row lists + offsets; summaries
-void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
+// (a batch of more than kOrdBatchMax = 16 queries runs as consecutive sub-batches of 16 in the same stream: the staging record
+// keeps 16 query bits; the scratch arrays are reused in stream order, every query has its own result arrays and summary)
+void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs_all, bool fine, int q0, int nq)
 {
     OrderedRun& o = c->ord;
     const int bi = (int)(&b - c->bslot);
-    char* sums = o.bq_sum[bi];
+    char* sums = o.bq_sum[bi] + (size_t)q0 * ord_sum_bytes();
+    const pie_query* qs = qs_all + q0;
     int* uc = o.unit_count[o.uc_next];
     int* uc_other = o.unit_count[o.uc_next ^ 1];
     o.uc_next ^= 1;
     OrdUnion* ustage = reinterpret_cast<OrdUnion*>(c->slot[bi].sel);
     OrdBatchArgs a;
-    a.n_q = b.n_q;
+    a.n_q = nq;
     const unsigned impossible = fine ? 0xFFu : 0xFFFFu; // a query that falls back carries a key no row can reach
     unsigned mk = impossible;
-    for (int q = 0; q < b.n_q; ++q) {
+    for (int q = 0; q < nq; ++q) {
         a.q[q].now = qs[q].now;
         a.q[q].cutoff = qs[q].cutoff;
         a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));
-        a.q[q].now_key = b.fallback[q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
+        a.q[q].now_key = b.fallback[q0 + q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
         a.q[q].pad = 0;
         if (a.q[q].now_key < mk) mk = a.q[q].now_key;
     }
@@ -1277,20 +1302,21 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
     }
-    if (b.ev_index >= 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
-    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, b.n_q, o.bq_count, units_stride, o.bq_runflag);
+    if (b.ev_index >= 0 && q0 == 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
+    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, nq, o.bq_count, units_stride, o.bq_runflag);
     long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
     if (n_groups < 1) n_groups = 1;
     const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
-    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)b.n_q), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase,
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)nq), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase,
                        (OrdCtl*)nullptr, sum0, units_stride, group_stride, sum_stride);
-    hipLaunchKernelGGL(k_ord_prefix_groups, dim3((unsigned)b.n_q), dim3(256), 0, s, n_chunks, o.bq_gsum, o.bq_gbase, sum0, group_stride, sum_stride);
+    hipLaunchKernelGGL(k_ord_prefix_groups, dim3((unsigned)nq), dim3(256), 0, s, n_chunks, o.bq_gsum, o.bq_gbase, sum0, group_stride, sum_stride);
     const int copy_blocks = c->n_cus * 8;
     const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
     hipLaunchKernelGGL(k_ord_batch_emit, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks,
-                       b.n_q, ustage, uc, o.bq_local, o.bq_gbase, units_stride, group_stride, o.pay, b.out_idx, batch_out_stride(c), b.offsets,
-                       b.counts_ord, batch_users_stride(c), copy_blocks, sum0, sum_stride, uc_other, o.units_cap, o.bq_runflag, o.bq_count);
-    hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)b.n_q), dim3(64), 0, s, sum0, b.h_sum_dev, b.seq, sum_stride);
+                       nq, ustage, uc, o.bq_local, o.bq_gbase, units_stride, group_stride, o.pay, b.out_idx + (long long)q0 * batch_out_stride(c), batch_out_stride(c),
+                       b.offsets + (long long)q0 * batch_users_stride(c), b.counts_ord + (long long)q0 * batch_users_stride(c), batch_users_stride(c), copy_blocks,
+                       sum0, sum_stride, uc_other, o.units_cap, o.bq_runflag, o.bq_count);
+    hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)nq), dim3(64), 0, s, sum0, b.h_sum_dev + q0, b.seq, sum_stride);
 }
 
 // should this query run on the ordered run?  (mode 1: where the general path is weak)
@@ -1865,11 +1891,15 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
 
 
 // ---------------------------------------------------------------------------------------------- batched scans
-// Q queries in one table pass (pie_kernels.h "batched scan").  Buffers are allocated on first use for kBatchMax queries:
-// per batch slot counts / offsets / 16 direct slots per user / a row list of 16 rows per user, per query.
+// Q <= 64 queries in one table pass (pie_kernels.h "batched scan").  The pass and its tail produce the UNION of the selections
+// (per user the rows any query selected, ordered, with a query mask per row): that is the batch's result.  Per-query counts /
+// offsets / row lists live in list storage that is allocated and filled only when somebody asks for them
+// (pie_batch_read_results, per-query messages) or when a path produces them anyway (fallback scans, the ordered run).
 
 long long batch_users_stride(const pie_ctx* c) { return (((long long)c->cap_users + 1 + 31) / 32) * 32; }
 long long batch_out_stride(const pie_ctx* c) { return (long long)c->cap_users * kTinyMax; }
+size_t batch_mq_bytes() { return (size_t)kMqSlots * kBatchMax * 4; }
+size_t batch_span_bytes(const pie_ctx* c) { return counts_span(c) + batch_mq_bytes(); }
 
 bool batch_supported(const pie_ctx* c)
 {
@@ -1878,28 +1908,43 @@ bool batch_supported(const pie_ctx* c)
            (long long)c->cap_users * kTinyMax < (1LL << 31);
 }
 
-// full = false: only the per-query counts / offsets arrays (tables the batched pass cannot run on: every query goes
-// through the general path and its row list lives in a buffer of its own)
-int ensure_batch(pie_ctx* c, bool full)
+// the arrays of the batched pass: union bucket slots + the union result per batch slot, three rotating spans
+int ensure_batch(pie_ctx* c)
 {
-    const size_t us = (size_t)batch_users_stride(c), os = (size_t)batch_out_stride(c);
-    if (!c->bslot[0].counts_ord) {
-        for (BatchSlot& b : c->bslot) {
-            PIE_HIP(c, hipMalloc(&b.counts_ord, (size_t)kBatchMax * us * 4));
-            PIE_HIP(c, hipMalloc(&b.offsets, (size_t)kBatchMax * us * 8));
-        }
-    }
-    if (!full || c->batch_alloc) return PIE_OK;
+    if (c->batch_alloc) return PIE_OK;
+    const size_t slots = (size_t)c->cap_users << c->bdshift;
     for (BatchSlot& b : c->bslot) {
-        PIE_HIP(c, hipMalloc(&b.direct, ((size_t)c->cap_users << c->bdshift) * sizeof(BktRec)));
-        PIE_HIP(c, hipMalloc(&b.out_idx, (size_t)kBatchMax * (os > 0 ? os : 1) * 4));
+        PIE_HIP(c, hipMalloc(&b.direct, slots * sizeof(BktRec)));
+        PIE_HIP(c, hipMalloc(&b.direct_hi, slots * 4));
+        PIE_HIP(c, hipMalloc(&b.uoff, ((size_t)c->cap_users + 2) * 8));
+        PIE_HIP(c, hipMalloc(&b.urows, slots * 4));
+        PIE_HIP(c, hipMalloc(&b.umlo, slots * 4));
+        PIE_HIP(c, hipMalloc(&b.umhi, slots * 4));
     }
     for (char*& sp : c->bspan) {
-        PIE_HIP(c, hipMalloc(&sp, (size_t)kBatchMax * counts_span(c)));
-        PIE_HIP(c, hipMemsetAsync(sp, 0, (size_t)kBatchMax * counts_span(c), c->stream));
+        PIE_HIP(c, hipMalloc(&sp, batch_span_bytes(c)));
+        PIE_HIP(c, hipMemsetAsync(sp, 0, batch_span_bytes(c), c->stream));
     }
     c->bspan_next = 0;
     c->batch_alloc = true;
+    return PIE_OK;
+}
+
+// per-query list storage of a batch slot for at least n_q queries (16 / 32 / 64); growing it drops what it held, so it is
+// sized before anything of the batch is written to it
+int ensure_lists(pie_ctx* c, BatchSlot& b, int n_q)
+{
+    const int want = n_q <= 16 ? 16 : n_q <= 32 ? 32 : kBatchMax;
+    if (b.lists_q >= want) return PIE_OK;
+    PIE_HIP(c, hipStreamSynchronize(c->stream));
+    dfree(b.counts_ord); dfree(b.offsets); dfree(b.out_idx);
+    b.lists_q = 0;
+    for (int q = 0; q < kBatchMax; ++q) b.list_ok[q] = false;
+    const size_t us = (size_t)batch_users_stride(c), os = (size_t)batch_out_stride(c);
+    PIE_HIP(c, hipMalloc(&b.counts_ord, (size_t)want * us * 4));
+    PIE_HIP(c, hipMalloc(&b.offsets, (size_t)want * us * 8));
+    PIE_HIP(c, hipMalloc(&b.out_idx, (size_t)want * (os > 0 ? os : 1) * 4));
+    b.lists_q = want;
     return PIE_OK;
 }
 
@@ -1909,47 +1954,75 @@ BatchSlot* oldest_batch(pie_ctx* c)
     return &c->bslot[c->b_flight == 2 ? c->b_next : (c->b_next ^ 1)];
 }
 
-void fill_tail_args(pie_ctx* c, BatchSlot& b, BatchTailArgs& t)
+void fill_tail_args(pie_ctx* c, BatchSlot& b, UnionTailArgs& t)
 {
     t.n_q = b.n_q;
     t.n_users = c->n_users;
     t.tiles = (c->n_users + kK1Threads - 1) / kK1Threads;
-    t.dshift = c->bdshift;
+    t.dshift = b.dshift;
     t.span = b.span;
-    t.span_stride = (long long)counts_span(c);
     t.tiles_off = (long long)span_counts_bytes(c);
     t.ctl_off = (long long)(span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes());
     t.summary_off = t.ctl_off + 128;
-    // the whole next-but-one span set (all kBatchMax spans, whatever the batch sizes) is zeroed by this batch's tail
-    t.zero_span = b.zero_span;
-    t.zero_total16 = (long long)kBatchMax * (long long)(counts_span(c) / 16);
-    t.counts_ord = b.counts_ord;
-    t.offsets = b.offsets;
-    t.users_stride = batch_users_stride(c);
+    t.mq_off = (long long)counts_span(c);
+    t.zero_span = b.zero_span;   // the next-but-one batch's span
+    t.zero_total16 = (long long)(batch_span_bytes(c) / 16);
     t.direct = b.direct;
-    t.out_idx = b.out_idx;
-    t.out_stride = batch_out_stride(c);
-    t.host = b.h_sum_dev;
+    t.direct_hi = b.direct_hi;
+    t.uoff = b.uoff; t.urows = b.urows; t.umlo = b.umlo; t.umhi = b.umhi;
+    t.host = b.bh_dev;
     t.seq = b.seq;
-    t.msg = b.msg;
-    t.msg_stride = b.msg_stride;
+    t.msg = b.msg_kind == 2 ? b.msg : nullptr;
     t.u_pad = b.msg_u_pad;
     t.msg_cap = b.msg_cap;
-    t.msg_counts = b.msg_counts;
-    t.msg_counts_stride = b.msg_counts_stride;
+    static const int dbg = getenv("PIE_TAIL_DBG") ? (int)strtol(getenv("PIE_TAIL_DBG"), nullptr, 0) : 0;
+    t.dbg = dbg;
+}
+
+// the predicate tables of a batch (pie_kernels.h BatchTables) over the queries that take part in the pass
+void fill_batch_tables(const pie_ctx* c, const BatchSlot& b, const pie_query* qs, const unsigned* nk, BatchTables& t)
+{
+    int by_now[kBatchMax], by_cut[kBatchMax], nb = 0;
+    for (int q = 0; q < b.n_q; ++q)
+        if (!b.fallback[q]) { by_now[nb] = q; by_cut[nb] = q; ++nb; }
+    std::stable_sort(by_now, by_now + nb, [&](int x, int y) { return qs[x].now < qs[y].now; });
+    std::stable_sort(by_cut, by_cut + nb, [&](int x, int y) { return qs[x].cutoff < qs[y].cutoff; });
+    unsigned long long lv = 0, wn = 0;
+    t.live[0] = 0;
+    t.win[0] = 0;
+    for (int i = 0; i < kBatchMax; ++i) {
+        if (i < nb) {
+            t.now[i] = qs[by_now[i]].now;
+            t.nk[i] = nk[by_now[i]];
+            t.cutoff[i] = qs[by_cut[i]].cutoff;
+            lv |= 1ull << by_now[i];
+            wn |= 1ull << by_cut[i];
+        } else {
+            t.now[i] = INT64_MAX;
+            t.nk[i] = ~0u;
+            t.cutoff[i] = INT64_MAX;
+        }
+        t.live[i + 1] = lv;
+        t.win[i + 1] = wn;
+    }
+    for (int d = 0; d < 64; ++d) t.disc[d] = 0;
+    const unsigned long long table = c->n_disc >= 64 ? ~0ull : ((1ull << c->n_disc) - 1ull);
+    for (int i = 0; i < nb; ++i) { // every set bit of every query's mask, once
+        const int q = by_now[i];
+        for (unsigned long long m = qs[q].mask & table; m; m &= m - 1) t.disc[__builtin_ctzll(m)] |= 1ull << q;
+    }
 }
 
 void launch_batch_k2(pie_ctx* c, BatchSlot& b, hipStream_t s)
 {
-    BatchTailArgs t;
+    UnionTailArgs t;
     fill_tail_args(c, b, t);
-    const unsigned grid = (unsigned)(t.tiles * (t.n_q > 8 ? 2 : 1)); // more than 8 queries: two groups (pie_kernels.h)
-    if (t.n_q <= 4) hipLaunchKernelGGL(k_offsets_batch<4>, dim3(grid), dim3(kK1Threads), 0, s, t);
-    else hipLaunchKernelGGL(k_offsets_batch<8>, dim3(grid), dim3(kK1Threads), 0, s, t);
+    if (t.n_q > 32) hipLaunchKernelGGL(k_union_tail<true>, dim3((unsigned)t.tiles), dim3(kK1Threads), 0, s, t);
+    else hipLaunchKernelGGL(k_union_tail<false>, dim3((unsigned)t.tiles), dim3(kK1Threads), 0, s, t);
     b.k2_pending = false;
 }
 
-int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long msg_stride, int u_pad, long long msg_cap,
+int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg, long long msg_stride, int u_pad, long long msg_cap,
                 int* msg_counts, long long msg_counts_stride)
 {
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
@@ -1964,14 +2037,40 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     hipStream_t s = c->stream;
     b.n_q = n_q;
     b.have_result = false;
+    b.union_ok = b.union_part = false;
+    b.mu = 0;
     if (c->bres == &b) c->bres = nullptr;
+    b.msg_kind = msg ? msg_kind : 0;
     b.msg = msg; b.msg_stride = msg_stride; b.msg_u_pad = u_pad; b.msg_cap = msg_cap;
     b.msg_counts = msg_counts; b.msg_counts_stride = msg_counts_stride;
-    for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; }
+    for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; b.list_ok[q] = false; }
     b.ev_index = -1;
     b.ordered = false;
     const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c);
     b.unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
+    // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
+    // they would make every row a candidate for all queries; they run on the general path
+    int n_batched = 0;
+    bool fine = (c->k1_keyed & 0x800) && !c->fkey_poor;
+    if (!b.unsupported) {
+        for (int q = 0; q < n_q; ++q) {
+            bool dense = false;
+            if (!c->key_dirty && c->key_hist_rows == c->n) {
+                const int bin = (int)(host_key_of(c, qs[q].now) >> 3);
+                unsigned long long at_or_above = 0;
+                for (int k = bin; k < kKeyHistBins; ++k) at_or_above += c->key_hist[(size_t)k];
+                dense = (double)at_or_above >= kLiveFirstBelow * (double)c->n;
+            }
+            b.fallback[q] = dense;
+            if (!dense) {
+                ++n_batched;
+                if (qs[q].now < c->fkey_base) fine = false;
+            }
+        }
+        // nothing left to batch (every query is dense): no table pass at all — a pass whose smallest key is the impossible
+        // one would still make nearly every row a candidate
+        if (n_batched == 0) b.unsupported = true;
+    }
     if (b.unsupported) { // finish() runs every query on the general path
         for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
         b.in_flight = true;
@@ -1985,40 +2084,22 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         // replaced; their contents are per-batch scratch
         int rc0 = sync_all(c);
         if (rc0) return rc0;
-        BktRec* fresh[2] = {nullptr, nullptr};
-        const size_t bytes = ((size_t)c->cap_users << c->bdshift_want) * sizeof(BktRec);
-        if (bytes <= kDirectMaxBytes && hipMalloc(&fresh[0], bytes) == hipSuccess && hipMalloc(&fresh[1], bytes) == hipSuccess) {
-            for (int k = 0; k < 2; ++k) {
-                (void)hipFree(c->bslot[k].direct);
-                c->bslot[k].direct = fresh[k];
-            }
+        const size_t slots = (size_t)c->cap_users << c->bdshift_want;
+        if (slots * sizeof(BktRec) <= kDirectMaxBytes) {
             c->bdshift = c->bdshift_want;
+            for (BatchSlot& x : c->bslot) {
+                dfree(x.direct); dfree(x.direct_hi); dfree(x.uoff); dfree(x.urows); dfree(x.umlo); dfree(x.umhi);
+                x.have_result = false;
+            }
+            for (char*& sp : c->bspan) dfree(sp);
+            c->bres = nullptr;
+            c->batch_alloc = false;
         } else {
-            (void)hipGetLastError();
-            if (fresh[0]) (void)hipFree(fresh[0]);
             c->bdshift_want = c->bdshift;
         }
     }
-    int rc = ensure_batch(c, true);
+    int rc = ord_batch ? PIE_OK : ensure_batch(c);
     if (rc) return rc;
-    // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
-    // they would make every row a candidate for all queries; they run on the general path
-    int n_batched = 0;
-    bool fine = (c->k1_keyed & 0x800) && !c->fkey_poor;
-    for (int q = 0; q < n_q; ++q) {
-        bool dense = false;
-        if (!c->key_dirty && c->key_hist_rows == c->n) {
-            const int bin = (int)(host_key_of(c, qs[q].now) >> 3);
-            unsigned long long at_or_above = 0;
-            for (int k = bin; k < kKeyHistBins; ++k) at_or_above += c->key_hist[(size_t)k];
-            dense = (double)at_or_above >= kLiveFirstBelow * (double)c->n;
-        }
-        b.fallback[q] = dense;
-        if (!dense) {
-            ++n_batched;
-            if (qs[q].now < c->fkey_base) fine = false;
-        }
-    }
     b.fine_key = fine;
     b.dshift = c->bdshift;
     if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
@@ -2038,15 +2119,18 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         }
     }
     if (ord_batch) {
-        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for all queries
+        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column per 16 queries
         rc = ord_batch_alloc(c);
+        if (rc) return rc;
+        rc = ensure_lists(c, b, n_q);
         if (rc) return rc;
         BatchSlot& prev = c->bslot[c->b_next ^ 1];
         if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
         b.seq = ++c->bseq_counter;
         c->scans_begun++;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
-        launch_ordered_batch(c, b, s, qs, fine);
+        for (int q0 = 0; q0 < n_q; q0 += kOrdBatchMax)
+            launch_ordered_batch(c, b, s, qs, fine, q0, n_q - q0 < kOrdBatchMax ? n_q - q0 : kOrdBatchMax);
         PIE_HIP(c, hipGetLastError());
         b.ordered = true;
         b.k2_pending = false;
@@ -2055,7 +2139,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         c->b_next ^= 1;
         return PIE_OK;
     }
-    // spans: this batch's set and the one its K2 zeroes
+    // spans: this batch's and the one its tail zeroes
     b.span = c->bspan[c->bspan_next];
     c->bspan_next = (c->bspan_next + 1) % 3;
     b.zero_span = c->bspan[(c->bspan_next + 1) % 3];
@@ -2064,12 +2148,12 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     b.k1_blocks = c->plan_blocks[plan];
     c->scans_begun++;
     BatchSlot& other = c->bslot[c->b_next ^ 1];
-    const bool ride = c->b_flight == 1 && other.in_flight && other.k2_pending && !c->no_ride;
-    if (c->b_flight == 1 && other.in_flight && other.k2_pending && !ride) launch_batch_k2(c, other, s);
+    const bool tail_waits = c->b_flight == 1 && other.in_flight && other.k2_pending && !other.ordered;
+    const bool ride = tail_waits && !c->no_ride;
+    if (tail_waits && !ride) launch_batch_k2(c, other, s);
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
-#define PIE_BATCH_RIDE(KT, QT)                                                                                          \
-    hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT, QT>), dim3((unsigned)(b.k1_blocks + t.tiles * (t.n_q > 8 ? 2 : 1))), \
-                       dim3(kK1Threads), 0, s, a, t)
+#define PIE_BATCH_RIDE(KT, HI)                                                                                          \
+    hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT, HI>), dim3((unsigned)(b.k1_blocks + t.tiles)), dim3(kK1Threads), 0, s, a, t)
 #define PIE_BATCH(KT, KEYPTR, KEYFN, IMPOSSIBLE)                                                                         \
     do {                                                                                                                \
         BatchScanArgs<KT> a;                                                                                            \
@@ -2077,33 +2161,32 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
         a.n_users = c->n_users; a.n_q = n_q; a.dshift = c->bdshift;                                                     \
         a.counts = reinterpret_cast<int*>(b.span);                                                                      \
         a.summary = reinterpret_cast<Summary*>(b.span + span_counts_bytes(c) + span_tiles_bytes(c) + span_parts_bytes() + 128); \
-        a.direct = b.direct; a.run_shift = c->run_shift;                                                                \
+        a.direct = b.direct; a.direct_hi = b.direct_hi; a.run_shift = c->run_shift;                                     \
+        unsigned nk[kBatchMax];                                                                                         \
         unsigned mk = IMPOSSIBLE;                                                                                       \
         for (int q = 0; q < n_q; ++q) {                                                                                 \
-            a.q[q].now = qs[q].now; a.q[q].cutoff = qs[q].cutoff; a.q[q].pad = 0;                                       \
-            a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));                   \
-            a.q[q].now_key = b.fallback[q] ? (unsigned)(IMPOSSIBLE) : KEYFN(c, qs[q].now);                              \
-            if (a.q[q].now_key < mk) mk = a.q[q].now_key;                                                               \
+            nk[q] = KEYFN(c, qs[q].now);                                                                                \
+            if (!b.fallback[q] && nk[q] < mk) mk = nk[q];                                                               \
         }                                                                                                               \
         a.min_key = mk;                                                                                                 \
+        fill_batch_tables(c, b, qs, nk, a.tab);                                                                         \
         if (ride) {                                                                                                     \
-            BatchTailArgs t;                                                                                            \
+            UnionTailArgs t;                                                                                            \
             fill_tail_args(c, other, t);                                                                                \
-            if (t.n_q <= 4) PIE_BATCH_RIDE(KT, 4);                                                                      \
-            else PIE_BATCH_RIDE(KT, 8);                                                                                 \
+            if (t.n_q > 32) PIE_BATCH_RIDE(KT, true);                                                                   \
+            else PIE_BATCH_RIDE(KT, false);                                                                             \
             other.k2_pending = false;                                                                                   \
         } else {                                                                                                        \
             hipLaunchKernelGGL((k_scan_batch<8, true, KT>), dim3((unsigned)b.k1_blocks), dim3(kK1Threads), 0, s, a);    \
         }                                                                                                               \
     } while (0)
-    // a query that falls back carries a key no row can reach: it selects nothing here
+    // a query that falls back is not in the tables: it selects nothing here
     if (fine) PIE_BATCH(fkey_t, c->d_fkey, host_fine_key_of, 0xFFu);
     else PIE_BATCH(lkey_t, c->d_key, host_key_of, 0xFFFFu);
 #undef PIE_BATCH
 #undef PIE_BATCH_RIDE
     PIE_HIP(c, hipGetLastError());
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e1, s));
-    (void)n_batched;
     b.k2_pending = true;
     b.in_flight = true;
     c->b_flight++;
@@ -2111,8 +2194,37 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int* msg, long long ms
     return PIE_OK;
 }
 
+// where query q's row list of `m` rows lives in the list storage: its strided region, or a buffer of its own when it is longer
+int batch_list_dst(pie_ctx* c, BatchSlot& b, int q, long long m, int** dst_out)
+{
+    int* dst = b.out_idx ? b.out_idx + (long long)q * batch_out_stride(c) : nullptr;
+    if (!dst || m > batch_out_stride(c)) {
+        if (b.over_cap[q] < m || !b.over_idx[q]) {
+            PIE_HIP(c, hipStreamSynchronize(c->stream)); // an earlier copy may still be reading the old buffer's neighbours: keep it simple
+            dfree(b.over_idx[q]);
+            b.over_cap[q] = 0;
+            PIE_HIP(c, hipMalloc(&b.over_idx[q], (size_t)(m > 0 ? m : 1) * 4));
+            b.over_cap[q] = m > 0 ? m : 1;
+        }
+        dst = b.over_idx[q];
+    }
+    *dst_out = dst;
+    return PIE_OK;
+}
+
+// per-query message [off[0..u_pad] | M | rows] of a query whose lists are in the list storage
+void batch_pack_list_msg(pie_ctx* c, BatchSlot& b, int q)
+{
+    const long long m = (long long)b.last[q].m;
+    const long long total = (long long)b.msg_u_pad + 2 + (m < b.msg_cap ? m : b.msg_cap);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > (unsigned)c->n_cus * 8) blocks = (unsigned)c->n_cus * 8;
+    hipLaunchKernelGGL(k_pack_lists, dim3(blocks ? blocks : 1u), dim3(256), 0, c->stream, b.offsets + (long long)q * batch_users_stride(c), c->n_users,
+                       b.msg_u_pad, m, b.idx_of[q], b.msg_cap, b.msg + (long long)q * b.msg_stride);
+}
+
 // Queries of a batch on the general path, two scans in flight (the offsets kernel of one rides in the next one's table
-// pass); every result is copied into the batch's arrays in stream order, one wait at the end.
+// pass); every result is copied into the batch's list storage in stream order, one wait at the end.
 int batch_fallback_copy(pie_ctx* c, BatchSlot& b, int q)
 {
     Slot& sl = *c->res;
@@ -2121,21 +2233,14 @@ int batch_fallback_copy(pie_ctx* c, BatchSlot& b, int q)
     PIE_HIP(c, hipMemcpyAsync(b.counts_ord + (long long)q * us, sl.counts_ord, (size_t)c->n_users * 4, hipMemcpyDeviceToDevice, s));
     PIE_HIP(c, hipMemcpyAsync(b.offsets + (long long)q * us, sl.offsets, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToDevice, s));
     const long long m = (long long)sl.last.m;
-    int* dst = b.out_idx ? b.out_idx + (long long)q * batch_out_stride(c) : nullptr;
-    if (!dst || m > batch_out_stride(c)) {
-        if (b.over_cap[q] < m || !b.over_idx[q]) {
-            PIE_HIP(c, hipStreamSynchronize(s)); // an earlier copy may still be reading the old buffer's neighbours: keep it simple
-            dfree(b.over_idx[q]);
-            b.over_cap[q] = 0;
-            PIE_HIP(c, hipMalloc(&b.over_idx[q], (size_t)(m > 0 ? m : 1) * 4));
-            b.over_cap[q] = m > 0 ? m : 1;
-        }
-        dst = b.over_idx[q];
-    }
+    int* dst = nullptr;
+    int rc = batch_list_dst(c, b, q, m, &dst);
+    if (rc) return rc;
     if (m) PIE_HIP(c, hipMemcpyAsync(dst, sl.out_idx, (size_t)m * 4, hipMemcpyDeviceToDevice, s));
     b.idx_of[q] = dst;
-    if (b.msg) {
-        int rc = pie_pack_results_device(c, b.msg + (long long)q * b.msg_stride, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
+    b.list_ok[q] = true;
+    if (b.msg_kind == 1) {
+        rc = pie_pack_results_device(c, b.msg + (long long)q * b.msg_stride, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
         if (rc) return rc;
     }
     if (b.msg_counts)
@@ -2147,14 +2252,12 @@ int batch_fallback_copy(pie_ctx* c, BatchSlot& b, int q)
 int batch_fallback_many(pie_ctx* c, BatchSlot& b, const int* list, int n_list)
 {
     if (n_list == 0) return PIE_OK;
-    int rc = ensure_batch(c, false);
-    if (rc) return rc;
     const unsigned long long keep_mask = c->disc_mask;
     auto begin = [&](int q) {
         c->disc_mask = b.q[q].mask;
         return scan_begin(c, b.q[q].now, b.q[q].cutoff);
     };
-    rc = begin(list[0]);
+    int rc = begin(list[0]);
     for (int i = 0; i < n_list && rc == PIE_OK; ++i) {
         if (i + 1 < n_list) rc = begin(list[i + 1]);
         if (rc == PIE_OK) rc = scan_finish(c);
@@ -2171,6 +2274,63 @@ int batch_fallback_many(pie_ctx* c, BatchSlot& b, const int* list, int n_list)
     return PIE_OK;
 }
 
+// counts / offsets / row lists of the listed queries out of the batch's union (k_mat_*); returns with the lists complete in
+// stream order and, for sync = true, the per-query maxima read back
+int batch_materialize(pie_ctx* c, BatchSlot& b, const int* list, int n_list)
+{
+    if (n_list == 0) return PIE_OK;
+    if (!b.union_part) return fail(c, PIE_E_STATE, "the batch has no union to take query lists from");
+    int rc = ensure_lists(c, b, b.n_q);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int tiles = (c->n_users + 255) / 256;
+    if (c->mat_tiles < tiles || !c->d_mat_tile) {
+        PIE_HIP(c, hipStreamSynchronize(s));
+        dfree(c->d_mat_tile); dfree(c->d_mat_qmax);
+        const int cap_tiles = (c->cap_users + 255) / 256 + 1;
+        PIE_HIP(c, hipMalloc(&c->d_mat_tile, (size_t)kBatchMax * ((size_t)cap_tiles + 1) * 8));
+        PIE_HIP(c, hipMalloc(&c->d_mat_qmax, (size_t)kBatchMax * 4));
+        c->mat_tiles = cap_tiles;
+    }
+    MatArgs a;
+    a.n_users = c->n_users; a.tiles = tiles; a.n_list = n_list;
+    a.uoff = b.uoff; a.urows = b.urows; a.umlo = b.umlo; a.umhi = b.n_q > 32 ? b.umhi : nullptr;
+    a.counts = b.counts_ord; a.offsets = b.offsets; a.users_stride = batch_users_stride(c);
+    a.tile_sum = c->d_mat_tile; a.qmax = c->d_mat_qmax;
+    for (int i = 0; i < n_list; ++i) {
+        const int q = list[i];
+        int* dst = nullptr;
+        rc = batch_list_dst(c, b, q, (long long)b.last[q].m, &dst);
+        if (rc) return rc;
+        a.q_of[i] = (unsigned char)q;
+        a.out[i] = dst;
+        a.out_cap[i] = (long long)b.last[q].m;
+        b.idx_of[q] = dst;
+    }
+    PIE_HIP(c, hipMemsetAsync(c->d_mat_qmax, 0, (size_t)kBatchMax * 4, s));
+    hipLaunchKernelGGL(k_mat_count, dim3((unsigned)tiles, (unsigned)n_list), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_mat_prefix, dim3((unsigned)n_list), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_mat_write, dim3((unsigned)tiles, (unsigned)n_list), dim3(256), 0, s, a);
+    PIE_HIP(c, hipGetLastError());
+    unsigned int qmax[kBatchMax];
+    PIE_HIP(c, hipMemcpyAsync(qmax, c->d_mat_qmax, (size_t)n_list * 4, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    for (int i = 0; i < n_list; ++i) {
+        b.last[list[i]].max_count = qmax[i];
+        b.list_ok[list[i]] = true;
+    }
+    return PIE_OK;
+}
+
+// the lists of query qi of a finished batch, materialised if need be
+int batch_need_list(pie_ctx* c, BatchSlot& b, int qi)
+{
+    if (b.list_ok[qi]) return PIE_OK;
+    return batch_materialize(c, b, &qi, 1);
+}
+
+int batch_pack_union(pie_ctx* c, BatchSlot& b, void* dst_i32, size_t u_pad, size_t cap);
+
 int batch_finish(pie_ctx* c, int* ready_out)
 {
     if (ready_out) *ready_out = 0;
@@ -2184,11 +2344,13 @@ int batch_finish(pie_ctx* c, int* ready_out)
             launch_batch_k2(c, b, s);
             PIE_HIP(c, hipGetLastError());
         }
-        // wait for every query's summary (mapped host memory, seq last); bounded like the single-scan wait
+        // wait for the summary (mapped host memory, seq last); bounded like the single-scan wait.  The union tail publishes
+        // ONE summary for the batch; the ordered run's batched form one per query.
         timespec t0{};
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        for (int q = 0; q < b.n_q; ++q) {
-            volatile unsigned long long* seq = &b.h_sum[q].seq;
+        const int n_wait = b.ordered ? b.n_q : 1;
+        for (int q = 0; q < n_wait; ++q) {
+            volatile unsigned long long* seq = b.ordered ? &b.h_sum[q].seq : &b.bh->seq;
             unsigned long long spins = 0;
             while (*seq != b.seq) {
                 __builtin_ia32_pause();
@@ -2208,36 +2370,41 @@ int batch_finish(pie_ctx* c, int* ready_out)
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        for (int q = 0; q < b.n_q; ++q) {
-            b.last[q] = b.h_sum[q].s;
-            // a union bucket outgrew its slots (or a row list its capacity): rows were dropped, and nothing says which
-            // queries they belonged to, so every query of the batch is rerun on the general path
-            if (b.last[q].n_over > 0 || b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
-            b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
-        }
-        if (b.n_q > 8 && (b.last[8].n_over > 0 || b.last[0].n_over > 0)) { // either query group found the overflow: it holds for the whole batch
-            for (int q = 0; q < b.n_q; ++q) b.fallback[q] = true;
-        }
-        if (b.last[0].n_over > 0 || (b.n_q > 8 && b.last[8].n_over > 0)) {
-            if (c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
-            else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
+        bool overflow = false;
+        if (b.ordered) {
+            for (int q = 0; q < b.n_q; ++q) {
+                b.last[q] = b.h_sum[q].s;
+                if (b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
+                b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
+                b.list_ok[q] = !b.fallback[q];
+            }
+        } else {
+            const Summary us = b.bh->s;
+            b.mu = us.m;
+            // a union bucket outgrew its slots: rows were dropped, and nothing says which queries they belonged to, so every
+            // query of the batch is rerun on the general path
+            overflow = us.n_over > 0 || us.bad_rows > 0;
+            for (int q = 0; q < b.n_q; ++q) {
+                b.last[q] = us;                       // cand, chunk_max, bad_rows, n_over: the pass's; max_count: the union's
+                b.last[q].m = b.bh->mq[q];
+                if (overflow) b.fallback[q] = true;
+            }
+            if (us.n_over > 0) {
+                if (c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
+                else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
+            }
+            b.union_part = !overflow;
+            b.union_ok = !overflow;
+            for (int q = 0; q < b.n_q; ++q) b.union_ok = b.union_ok && !b.fallback[q];
+            choose_run_shift(c, us.cand, us.chunk_max, b.fine_key);
         }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
-        if (!b.ordered) choose_run_shift(c, b.last[0].cand, b.last[0].chunk_max, b.fine_key);
-        if (b.ordered && (b.msg || b.msg_counts)) {
+        if (b.ordered && (b.msg_kind == 1 || b.msg_counts)) {
             // the ordered chain writes no messages: pack them from the finished lists (the queries that fall back pack their own)
             all_ready = false;
-            const int bi = (int)(&b - c->bslot);
             for (int q = 0; q < b.n_q; ++q) {
                 if (b.fallback[q]) continue;
-                const Summary* sq = reinterpret_cast<const Summary*>(c->ord.bq_sum[bi] + (size_t)q * ord_sum_bytes());
-                if (b.msg) {
-                    const long long total = (long long)b.msg_u_pad + 2 + (long long)((long long)b.last[q].m < b.msg_cap ? (long long)b.last[q].m : b.msg_cap);
-                    unsigned blocks = (unsigned)((total + 255) / 256);
-                    if (blocks > (unsigned)c->n_cus * 8) blocks = (unsigned)c->n_cus * 8;
-                    hipLaunchKernelGGL(k_pack_results, dim3(blocks ? blocks : 1u), dim3(256), 0, s, b.offsets + (long long)q * batch_users_stride(c), c->n_users,
-                                       b.msg_u_pad, sq, b.out_idx + (long long)q * batch_out_stride(c), b.msg_cap, b.msg + (long long)q * b.msg_stride);
-                }
+                if (b.msg_kind == 1) batch_pack_list_msg(c, b, q);
                 if (b.msg_counts)
                     PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, b.counts_ord + (long long)q * batch_users_stride(c),
                                               (size_t)c->n_users * 4, hipMemcpyDefault, s));
@@ -2253,16 +2420,107 @@ int batch_finish(pie_ctx* c, int* ready_out)
             if (b.fallback[q]) list[n_list++] = q;
         if (n_list) {
             all_ready = false;
-            int rc = batch_fallback_many(c, b, list, n_list);
+            int rc = ensure_lists(c, b, b.n_q);
+            if (rc) return rc;
+            rc = batch_fallback_many(c, b, list, n_list);
             if (rc) return rc;
         }
     }
     b.have_result = true;
     c->bres = &b;
     c->last_was_batch = true;
-    if (ready_out) *ready_out = (all_ready && b.msg) ? 1 : (b.msg ? 0 : 1);
     for (int q = 0; q < b.n_q; ++q)
         if (b.last[q].bad_rows) return fail(c, PIE_E_INVAL, "query %d: %u selected rows carry a user id outside [0, %d)", q, b.last[q].bad_rows, c->n_users);
+    if (!b.ordered && (b.msg_kind == 1 || b.msg_counts)) {
+        // per-query messages of a batch on the general pass: the lists are materialised from the union, then packed
+        all_ready = false;
+        int list[kBatchMax], n_list = 0;
+        for (int q = 0; q < b.n_q; ++q)
+            if (!b.list_ok[q]) list[n_list++] = q;
+        int rc = batch_materialize(c, b, list, n_list);
+        if (rc) return rc;
+        for (int i = 0; i < n_list; ++i) {
+            const int q = list[i];
+            if (b.msg_kind == 1) batch_pack_list_msg(c, b, q);
+            if (b.msg_counts)
+                PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, b.counts_ord + (long long)q * batch_users_stride(c),
+                                          (size_t)c->n_users * 4, hipMemcpyDefault, s));
+        }
+        PIE_HIP(c, hipGetLastError());
+    }
+    if (b.msg_kind == 2 && !b.union_ok) {
+        // the tail could not write the whole union (queries fell back, or the batch ran on the ordered run): merged from the lists
+        all_ready = false;
+        int rc = batch_pack_union(c, b, b.msg, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
+        if (rc) return rc;
+    }
+    if (ready_out) *ready_out = b.msg_kind ? (all_ready ? 1 : 0) : 1;
+    return PIE_OK;
+}
+
+// The union message of a finished batch into caller memory, enqueued on the context's stream.  A batch whose union the tail
+// produced: one copy kernel.  Otherwise (queries fell back, the ordered run) the per-query lists are merged per user
+// (k_union_collect): 32 query bits, 32 union rows per user — beyond either the message says Mu = -1 (use the lists).
+int batch_pack_union(pie_ctx* c, BatchSlot& b, void* dst_i32, size_t u_pad, size_t cap)
+{
+    hipStream_t s = c->stream;
+    if (b.union_ok) {
+        size_t total = u_pad + 2 + (size_t)(b.mu < cap ? b.mu : cap);
+        size_t grid = (total + 255) / 256;
+        if (grid > (size_t)c->n_cus * 8) grid = (size_t)c->n_cus * 8;
+        hipLaunchKernelGGL(k_union_pack, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, s, c->n_users, (int)u_pad, b.uoff, b.urows, b.umlo,
+                           b.n_q > 32 ? b.umhi : (const unsigned*)nullptr, (long long)cap, (int*)dst_i32);
+        PIE_HIP(c, hipGetLastError());
+        return PIE_OK;
+    }
+    {   // every query's list is needed: the ones still only in the (partial) union are materialised
+        int list[kBatchMax], n_list = 0;
+        for (int q = 0; q < b.n_q; ++q)
+            if (!b.list_ok[q]) list[n_list++] = q;
+        int rc = batch_materialize(c, b, list, n_list);
+        if (rc) return rc;
+    }
+    const size_t padded = (((size_t)c->cap_users + 1023) / 1024 + 1) * 1024, groups = padded / 1024 + 2;
+    if (c->union_users < c->cap_users || !c->d_union) {
+        if ((size_t)c->cap_users * kUnionMax * sizeof(UnionRow) > ((size_t)4 << 30)) return fail(c, PIE_E_NOMEM, "union scratch for %d users exceeds 4 GiB", c->cap_users);
+        PIE_HIP(c, hipStreamSynchronize(s));
+        dfree(c->d_union); dfree(c->d_union_cnt); dfree(c->d_union_local); dfree(c->d_union_off);
+        PIE_HIP(c, hipMalloc(&c->d_union, (size_t)c->cap_users * kUnionMax * sizeof(UnionRow)));
+        PIE_HIP(c, hipMalloc(&c->d_union_cnt, padded * 4));
+        PIE_HIP(c, hipMalloc(&c->d_union_local, padded * 4));
+        PIE_HIP(c, hipMalloc(&c->d_union_off, 2 * groups * 8 + 256 + 64));
+        PIE_HIP(c, hipMemsetAsync(c->d_union_cnt, 0, padded * 4, s)); // entries behind the users stay zero for good
+        PIE_HIP(c, hipMemsetAsync(c->d_union_off, 0, 2 * groups * 8 + 256 + 64, s)); // incl. the prefix kernel's block counter
+        c->union_users = c->cap_users;
+    }
+    long long* gsum = c->d_union_off;
+    long long* gbase = c->d_union_off + groups;
+    Summary* usum = reinterpret_cast<Summary*>(reinterpret_cast<char*>(c->d_union_off + 2 * groups));
+    int* over = reinterpret_cast<int*>(reinterpret_cast<char*>(usum) + 256);
+    OrdCtl* uctl = reinterpret_cast<OrdCtl*>(reinterpret_cast<char*>(usum) + 256 + 16); // its counter returns to 0 by itself
+    if (b.n_q > 32) { // the merged form carries 32 query bits
+        const int one = 1;
+        PIE_HIP(c, hipMemcpyAsync(over, &one, 4, hipMemcpyHostToDevice, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    } else {
+        PIE_HIP(c, hipMemsetAsync(over, 0, 4, s));
+    }
+    UnionLists lists{};
+    for (int q = 0; q < b.n_q && q < 32; ++q) lists.idx[q] = b.idx_of[q];
+    const unsigned ublocks = (unsigned)((c->n_users + kUnionThreads - 1) / kUnionThreads);
+    hipLaunchKernelGGL(k_union_collect, dim3(ublocks ? ublocks : 1u), dim3(kUnionThreads), 0, s, b.n_q < 32 ? b.n_q : 32, c->n_users, b.offsets, batch_users_stride(c),
+                       lists, c->d_start, c->d_union, c->d_union_cnt, over);
+    long long n_groups = ((long long)c->n_users + 1023) >> 10;
+    if (n_groups < 1) n_groups = 1;
+    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
+    // a hundred groups at most: the one-launch form (the block that finishes last scans the group sums)
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, c->d_union_cnt, (long long)c->n_users, c->d_union_local, gsum, gbase,
+                       uctl, usum, 0LL, 0LL, 0LL);
+    unsigned wblocks = (unsigned)((u_pad + 2 + 255) / 256);
+    if (wblocks > (unsigned)c->n_cus * 8) wblocks = (unsigned)c->n_cus * 8;
+    hipLaunchKernelGGL(k_union_write, dim3(wblocks), dim3(256), 0, s, c->n_users, (int)u_pad, c->d_union_local, gbase, c->d_union_cnt, c->d_union, over,
+                       (long long)cap, (int*)dst_i32);
+    PIE_HIP(c, hipGetLastError());
     return PIE_OK;
 }
 
@@ -2319,6 +2577,9 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
         ok = ok && (e = hipHostMalloc(&b.h_sum, sizeof(HostSummary) * kBatchMax, hipHostMallocMapped)) == hipSuccess &&
              (e = hipHostGetDevicePointer((void**)&b.h_sum_dev, b.h_sum, 0)) == hipSuccess;
         if (ok) memset(b.h_sum, 0, sizeof(HostSummary) * kBatchMax);
+        ok = ok && (e = hipHostMalloc(&b.bh, sizeof(BatchHost), hipHostMallocMapped)) == hipSuccess &&
+             (e = hipHostGetDevicePointer((void**)&b.bh_dev, b.bh, 0)) == hipSuccess;
+        if (ok) memset(b.bh, 0, sizeof(BatchHost));
     }
     if (!ok) {
         fail(nullptr, PIE_E_NODEVICE, "context setup: %s", hipGetErrorString(e));
@@ -2363,6 +2624,7 @@ int pie_ctx_destroy(pie_ctx* c)
     }
     for (BatchSlot& b : c->bslot) {
         if (b.h_sum) (void)hipHostFree(b.h_sum);
+        if (b.bh) (void)hipHostFree(b.bh);
     }
     if (c->ord.h_stale) (void)hipHostFree(c->ord.h_stale);
     if (c->d_summary) (void)hipFree(c->d_summary);
@@ -2780,7 +3042,7 @@ int pie_scan_batch_begin(pie_ctx* c, const pie_query* queries, int n_q)
 {
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
-    return batch_begin(c, queries, n_q, nullptr, 0, 0, 0, nullptr, 0);
+    return batch_begin(c, queries, n_q, 0, nullptr, 0, 0, 0, nullptr, 0);
 }
 
 int pie_scan_batch_begin_packed(pie_ctx* c, const pie_query* queries, int n_q, void* msg_i32, size_t msg_stride_words, size_t u_pad,
@@ -2791,8 +3053,16 @@ int pie_scan_batch_begin_packed(pie_ctx* c, const pie_query* queries, int n_q, v
         return fail(c, PIE_E_INVAL, "bad message destination / u_pad < n_users / stride below u_pad + 2 + idx_cap");
     if (counts_i32 && counts_stride_words < (size_t)c->n_users) return fail(c, PIE_E_INVAL, "counts stride below n_users");
     PIE_HIP(c, hipSetDevice(c->device));
-    return batch_begin(c, queries, n_q, (int*)msg_i32, (long long)msg_stride_words, (int)u_pad, (long long)idx_cap, (int*)counts_i32,
+    return batch_begin(c, queries, n_q, 1, (int*)msg_i32, (long long)msg_stride_words, (int)u_pad, (long long)idx_cap, (int*)counts_i32,
                        (long long)counts_stride_words);
+}
+
+int pie_scan_batch_begin_union(pie_ctx* c, const pie_query* queries, int n_q, void* msg_i32, size_t u_pad, size_t cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!msg_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad union destination / u_pad < n_users");
+    PIE_HIP(c, hipSetDevice(c->device));
+    return batch_begin(c, queries, n_q, 2, (int*)msg_i32, 0, (int)u_pad, (long long)cap, nullptr, 0);
 }
 
 int pie_scan_batch_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
@@ -2817,11 +3087,65 @@ int pie_scan_batch(pie_ctx* c, const pie_query* queries, int n_q, size_t* m_out)
     return pie_scan_batch_finish(c, m_out);
 }
 
+int pie_batch_union_device_ptrs(pie_ctx* c, void** uoff_dev, void** rows_dev, void** mask_lo_dev, void** mask_hi_dev, size_t* mu_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (uoff_dev) *uoff_dev = nullptr;
+    if (rows_dev) *rows_dev = nullptr;
+    if (mask_lo_dev) *mask_lo_dev = nullptr;
+    if (mask_hi_dev) *mask_hi_dev = nullptr;
+    if (mu_out) *mu_out = 0;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    const BatchSlot& b = *c->bres;
+    if (!b.union_ok) return PIE_OK; // queries fell back / the batch ran on the ordered run: per-query lists only
+    if (uoff_dev) *uoff_dev = b.uoff;
+    if (rows_dev) *rows_dev = b.urows;
+    if (mask_lo_dev) *mask_lo_dev = b.umlo;
+    if (mask_hi_dev) *mask_hi_dev = b.n_q > 32 ? b.umhi : nullptr;
+    if (mu_out) *mu_out = (size_t)b.mu;
+    return PIE_OK;
+}
+
+int pie_batch_read_union(pie_ctx* c, int64_t* uoff_out, int32_t* rows_out, uint64_t* masks_out, size_t cap, size_t* mu_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (mu_out) *mu_out = 0;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    const BatchSlot& b = *c->bres;
+    if (!b.union_ok) return fail(c, PIE_E_STATE, "this batch has no union result (queries fell back to the general path, or it ran on the ordered run): read the per-query results");
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t a = c->stream;
+    const size_t mu = (size_t)b.mu;
+    if (mu_out) *mu_out = mu;
+    if (uoff_out) PIE_HIP(c, hipMemcpyAsync(uoff_out, b.uoff, ((size_t)c->n_users + 1) * 8, hipMemcpyDeviceToHost, a));
+    if ((rows_out || masks_out) && mu > cap) {
+        PIE_HIP(c, hipStreamSynchronize(a));
+        return fail(c, PIE_E_CAPACITY, "cap %zu < union rows %zu", cap, mu);
+    }
+    if (rows_out && mu) PIE_HIP(c, hipMemcpyAsync(rows_out, b.urows, mu * 4, hipMemcpyDeviceToHost, a));
+    std::vector<uint32_t> lo, hi;
+    if (masks_out && mu) {
+        lo.resize(mu);
+        PIE_HIP(c, hipMemcpyAsync(lo.data(), b.umlo, mu * 4, hipMemcpyDeviceToHost, a));
+        if (b.n_q > 32) {
+            hi.resize(mu);
+            PIE_HIP(c, hipMemcpyAsync(hi.data(), b.umhi, mu * 4, hipMemcpyDeviceToHost, a));
+        }
+    }
+    PIE_HIP(c, hipStreamSynchronize(a));
+    if (masks_out)
+        for (size_t i = 0; i < mu; ++i) masks_out[i] = (uint64_t)lo[i] | (hi.empty() ? 0ull : ((uint64_t)hi[i] << 32));
+    return PIE_OK;
+}
+
 int pie_batch_result_device_ptrs(pie_ctx* c, int qi, void** counts_dev, void** offsets_dev, void** idx_dev)
 {
     if (!c) return PIE_E_INVAL;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
     if (qi < 0 || qi >= c->bres->n_q) return fail(c, PIE_E_INVAL, "query %d outside the batch of %d", qi, c->bres->n_q);
+    PIE_HIP(c, hipSetDevice(c->device));
+    int rc = batch_need_list(c, *c->bres, qi);
+    if (rc) return rc;
     const long long us = batch_users_stride(c);
     if (counts_dev) *counts_dev = c->bres->counts_ord + (long long)qi * us;
     if (offsets_dev) *offsets_dev = c->bres->offsets + (long long)qi * us;
@@ -2833,11 +3157,37 @@ int pie_batch_read_user_feed(pie_ctx* c, int qi, int32_t user, int32_t* idx_out,
 {
     if (!c) return PIE_E_INVAL;
     if (k_out) *k_out = 0;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    BatchSlot& b = *c->bres;
+    if (qi < 0 || qi >= b.n_q) return fail(c, PIE_E_INVAL, "query %d outside the batch of %d", qi, b.n_q);
+    if (user < 0 || user >= c->n_users) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    if (b.union_ok && !b.list_ok[qi]) {
+        // straight from the union: the user's (few) union rows, filtered by the query's bit — no per-query list is ever built
+        long long off[2] = {0, 0};
+        PIE_HIP(c, hipMemcpyAsync(off, b.uoff + user, sizeof off, hipMemcpyDeviceToHost, c->stream));
+        PIE_HIP(c, hipStreamSynchronize(c->stream));
+        const size_t ku = (size_t)(off[1] - off[0]);
+        if (ku == 0) return PIE_OK;
+        int rows[1 << kUnionShiftMax];
+        unsigned masks[1 << kUnionShiftMax];
+        if (ku > (size_t)(1 << kUnionShiftMax)) return fail(c, PIE_E_STATE, "union bucket of %zu rows", ku);
+        PIE_HIP(c, hipMemcpyAsync(rows, b.urows + off[0], ku * 4, hipMemcpyDeviceToHost, c->stream));
+        PIE_HIP(c, hipMemcpyAsync(masks, (qi >= 32 ? b.umhi : b.umlo) + off[0], ku * 4, hipMemcpyDeviceToHost, c->stream));
+        PIE_HIP(c, hipStreamSynchronize(c->stream));
+        size_t k = 0;
+        for (size_t i = 0; i < ku; ++i) k += (masks[i] >> (qi & 31)) & 1u;
+        if (k_out) *k_out = k;
+        if (k == 0) return PIE_OK;
+        if (!idx_out || k > idx_cap) return fail(c, PIE_E_CAPACITY, "idx_cap %zu < feed length %zu", idx_cap, k);
+        size_t at = 0;
+        for (size_t i = 0; i < ku; ++i)
+            if ((masks[i] >> (qi & 31)) & 1u) idx_out[at++] = rows[i];
+        return PIE_OK;
+    }
     void *dc = nullptr, *dof = nullptr, *di = nullptr;
     int rc = pie_batch_result_device_ptrs(c, qi, &dc, &dof, &di);
     if (rc) return rc;
-    if (user < 0 || user >= c->n_users) return PIE_OK;
-    PIE_HIP(c, hipSetDevice(c->device));
     long long off[2] = {0, 0};
     PIE_HIP(c, hipMemcpyAsync(off, static_cast<long long*>(dof) + user, sizeof off, hipMemcpyDeviceToHost, c->stream));
     PIE_HIP(c, hipStreamSynchronize(c->stream));
@@ -2971,50 +3321,7 @@ int pie_batch_pack_union_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t 
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
     if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad union destination / u_pad < n_users");
     PIE_HIP(c, hipSetDevice(c->device));
-    const BatchSlot& b = *c->bres;
-    hipStream_t s = c->stream;
-    const size_t padded = (((size_t)c->cap_users + 1023) / 1024 + 1) * 1024, groups = padded / 1024 + 2;
-    if (c->union_users < c->cap_users || !c->d_union) {
-        if ((size_t)c->cap_users * kUnionMax * sizeof(UnionRow) > ((size_t)4 << 30)) return fail(c, PIE_E_NOMEM, "union scratch for %d users exceeds 4 GiB", c->cap_users);
-        PIE_HIP(c, hipStreamSynchronize(s));
-        dfree(c->d_union); dfree(c->d_union_cnt); dfree(c->d_union_local); dfree(c->d_union_off);
-        PIE_HIP(c, hipMalloc(&c->d_union, (size_t)c->cap_users * kUnionMax * sizeof(UnionRow)));
-        PIE_HIP(c, hipMalloc(&c->d_union_cnt, padded * 4));
-        PIE_HIP(c, hipMalloc(&c->d_union_local, padded * 4));
-        PIE_HIP(c, hipMalloc(&c->d_union_off, 2 * groups * 8 + 256 + 64));
-        PIE_HIP(c, hipMemsetAsync(c->d_union_cnt, 0, padded * 4, s)); // entries behind the users stay zero for good
-        PIE_HIP(c, hipMemsetAsync(c->d_union_off, 0, 2 * groups * 8 + 256 + 64, s)); // incl. the prefix kernel's block counter
-        c->union_users = c->cap_users;
-    }
-    long long* gsum = c->d_union_off;
-    long long* gbase = c->d_union_off + groups;
-    Summary* usum = reinterpret_cast<Summary*>(reinterpret_cast<char*>(c->d_union_off + 2 * groups));
-    int* over = reinterpret_cast<int*>(reinterpret_cast<char*>(usum) + 256);
-    OrdCtl* uctl = reinterpret_cast<OrdCtl*>(reinterpret_cast<char*>(usum) + 256 + 16); // its counter returns to 0 by itself
-    PIE_HIP(c, hipMemsetAsync(over, 0, 4, s));
-    UnionLists lists{};
-    for (int q = 0; q < b.n_q; ++q) lists.idx[q] = b.idx_of[q];
-    const unsigned ublocks = (unsigned)((c->n_users + kUnionThreads - 1) / kUnionThreads);
-    bool from_buckets = !b.ordered && !b.unsupported && b.span && b.direct;
-    for (int q = 0; q < b.n_q; ++q) from_buckets = from_buckets && !b.fallback[q];
-    if (from_buckets) // the general batched pass: its union bucket slots ARE the union (a query that fell back is not in them)
-        hipLaunchKernelGGL(k_union_from_buckets, dim3(ublocks ? ublocks : 1u), dim3(kUnionThreads), 0, s, c->n_users,
-                           reinterpret_cast<const int*>(b.span), b.direct, b.dshift, c->d_union, c->d_union_cnt, over);
-    else
-        hipLaunchKernelGGL(k_union_collect, dim3(ublocks ? ublocks : 1u), dim3(kUnionThreads), 0, s, b.n_q, c->n_users, b.offsets, batch_users_stride(c),
-                           lists, c->d_start, c->d_union, c->d_union_cnt, over);
-    long long n_groups = ((long long)c->n_users + 1023) >> 10;
-    if (n_groups < 1) n_groups = 1;
-    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus * 4 ? n_groups : (long long)c->n_cus * 4);
-    // a hundred groups at most: the one-launch form (the block that finishes last scans the group sums)
-    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, c->d_union_cnt, (long long)c->n_users, c->d_union_local, gsum, gbase,
-                       uctl, usum, 0LL, 0LL, 0LL);
-    unsigned wblocks = (unsigned)((u_pad + 2 + 255) / 256);
-    if (wblocks > (unsigned)c->n_cus * 8) wblocks = (unsigned)c->n_cus * 8;
-    hipLaunchKernelGGL(k_union_write, dim3(wblocks), dim3(256), 0, s, c->n_users, (int)u_pad, c->d_union_local, gbase, c->d_union_cnt, c->d_union, over,
-                       (long long)cap, (int*)dst_i32);
-    PIE_HIP(c, hipGetLastError());
-    return PIE_OK;
+    return batch_pack_union(c, *c->bres, dst_i32, u_pad, cap);
 }
 
 int pie_fetch_rows(pie_ctx* c, const int32_t* idx, size_t m, int64_t* start, int64_t* end, int32_t* user, int32_t* disc)
@@ -3239,9 +3546,10 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
         per_slot += (uint64_t)kPartMax * kPartCap * sizeof(SelRec);
     }
     out->workspace_bytes = rows ? 2 * per_slot + 3 * (uint64_t)counts_span(c) : 0;
-    if (c->batch_alloc) // batched scans: per slot 16 sets of counts / offsets / row lists + the union bucket slots, 3 span sets
-        out->workspace_bytes += 2 * ((uint64_t)kBatchMax * (uint64_t)batch_users_stride(c) * 12 + (uint64_t)kBatchMax * (uint64_t)batch_out_stride(c) * 4 +
-                                     ((uint64_t)users << c->bdshift) * sizeof(BktRec)) + 3 * (uint64_t)kBatchMax * (uint64_t)counts_span(c);
+    if (c->batch_alloc) // batched scans: per slot the union bucket slots (20 B each) + the union result (12 B per slot, 8 per user), 3 spans
+        out->workspace_bytes += 2 * (((uint64_t)users << c->bdshift) * (sizeof(BktRec) + 4 + 12) + ((uint64_t)users + 2) * 8) + 3 * (uint64_t)batch_span_bytes(c);
+    for (const BatchSlot& b : c->bslot) // per-query list storage, where somebody asked for lists
+        out->workspace_bytes += (uint64_t)b.lists_q * ((uint64_t)batch_users_stride(c) * 12 + (uint64_t)batch_out_stride(c) * 4);
     out->index_build_ms = c->index_build_ms;
     out->ordered_rows = c->ord.valid ? (uint64_t)c->ord.held : 0u;
     out->ordered_positions = c->ord.valid ? (uint64_t)c->ord.n : 0u;

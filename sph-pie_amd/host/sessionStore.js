@@ -301,7 +301,7 @@ function createStore(options){
   // ---- batched scan: the feed requests of one event-loop turn, ONE table pass (pie_scan_batch) ------------------------
   // queries: up to native batch size of {now, cutoff, disciplines}; -> selected rows per query.  batchUserFeed(qi, u) then
   // reads one user's rows of query qi (two small copies), like userFeed for a single scan.
-  const BATCH_MAX = 16;
+  const BATCH_MAX = 64;
   function scanBatchDevice(queries){
     if(queries.length < 1 || queries.length > BATCH_MAX){ throw new Error('a batch holds 1..' + BATCH_MAX + ' queries'); }
     flush();

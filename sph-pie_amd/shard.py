@@ -76,8 +76,15 @@ class HipShardBackend:
         """-> ([M per query], ready)"""
         return self.ctx.scan_batch_finish(packed=True)
 
+    union_direct = True   # batch_begin_union: the batch's own kernels write the union message
+
+    def batch_begin_union(self, queries, dst, u_pad, cap):
+        """A batch whose tail kernel writes the ONE union message of the step into dst as it goes."""
+        self.ctx.scan_batch_begin_union(queries, dst.data_ptr(), u_pad, cap)
+
     def batch_pack_union(self, dst, u_pad, cap):
-        """Enqueue (on result_stream) the UNION message of the last finished batch into dst: u_pad + 2 + 2 * cap int32 words."""
+        """Enqueue (on result_stream) the UNION message of the last finished batch into dst: u_pad + 2 + 2 * cap int32 words
+        (3 * cap when the batch holds more than 32 queries)."""
         self.ctx.batch_pack_union_device(dst.data_ptr(), u_pad, cap)
 
 
@@ -445,8 +452,9 @@ class UnionOverflow(RuntimeError):
 def union_feed(res, r, q, u):
     """Feed of user u (local index on shard r) for query q out of a union-mode result of BatchedFeeds.run_steps."""
     a, b = int(res["u_offsets"][r, u]), int(res["u_offsets"][r, u + 1])
-    rows, masks = res["rows"][r, a:b], res["masks"][r, a:b]
-    return rows[((masks >> q) & 1) == 1]
+    masks = res["masks_hi"] if q >= 32 else res["masks"]
+    rows, masks = res["rows"][r, a:b], masks[r, a:b]
+    return rows[((masks >> (q & 31)) & 1) == 1]
 
 
 class BatchedFeeds:
@@ -463,7 +471,10 @@ class BatchedFeeds:
     requests of the same few seconds and select almost the same rows, so the union is little longer than one list: an eighth
     of the bytes cross the links for Q = 16.  run_steps then returns u_offsets [world, U_pad+1], lengths [world], rows
     [world, cap], masks [world, cap]; Feed(r, q, u) = rows[r, a:b][(masks[r, a:b] >> q) & 1 == 1], a, b = u_offsets[r, u : u+2].
-    A shard whose users hold more than 32 union rows (skewed users) reports length -1: UnionOverflow, use the lists."""
+    With a backend that has batch_begin_union (the HIP backend) the batch's own tail kernel writes the message — nothing is
+    packed afterwards and no event sits between the scan stream and the gather.  More than 32 queries: a second mask word per
+    row (masks_hi).  A shard whose batch had to be merged from per-query lists (queries fell back, skewed users on the ordered
+    run) and holds more than 32 union rows for a user reports length -1: UnionOverflow, use the lists."""
 
     def __init__(self, backend, rank, world, n_users_local, q_max, group=None, cap=None, always_collective=False, union=False,
                  steps_per_gather=1, transport="device"):
@@ -491,7 +502,9 @@ class BatchedFeeds:
 
     def _sets(self):
         if self.sets is None or self.sets["cap"] != self.cap:
-            L = self.u_pad + 2 + (2 if self.union else 1) * self.cap
+            # union: rows + mask words (one word per 32 queries); lists: rows
+            self.mask_words = 2 if self.q_max > 32 else 1
+            L = self.u_pad + 2 + ((1 + self.mask_words) if self.union else 1) * self.cap
             # messages of one step: one (union) or q_max (lists); G steps share an all-gather
             Qm, W, G = (1 if self.union else self.q_max), self.world, self.steps_per_gather
             self.sets = {
@@ -579,8 +592,11 @@ class BatchedFeeds:
         lens = lens_all[:, last]
         if self.union:
             g = g[:, 0]
-            return {"u_offsets": g[:, : self.u_pad + 1], "lengths": lens[:, 0].clone(), "rows": g[:, self.u_pad + 2: self.u_pad + 2 + cap],
-                    "masks": g[:, self.u_pad + 2 + cap:]}
+            res = {"u_offsets": g[:, : self.u_pad + 1], "lengths": lens[:, 0].clone(), "rows": g[:, self.u_pad + 2: self.u_pad + 2 + cap],
+                   "masks": g[:, self.u_pad + 2 + cap: self.u_pad + 2 + 2 * cap]}
+            if self.mask_words == 2:
+                res["masks_hi"] = g[:, self.u_pad + 2 + 2 * cap: self.u_pad + 2 + 3 * cap]
+            return res
         return {"offsets": g[:, :nq, : self.u_pad + 1], "lengths": lens[:, :nq].clone(), "rows": g[:, :nq, self.u_pad + 2:]}
 
     def run_steps(self, k, queries):
@@ -604,8 +620,12 @@ class BatchedFeeds:
         def slot_of(i):
             return st["msg"][(i // G) % N_SETS][(i % G) * Qm * L: (i % G + 1) * Qm * L]
 
+        direct_union = self.union and bool(getattr(self.backend, "union_direct", False))
+
         def begin(i):
-            if self.union:
+            if direct_union:   # the batch's tail kernel writes the step's ONE message itself
+                self.backend.batch_begin_union(queries, slot_of(i), self.u_pad, cap)
+            elif self.union:
                 self.backend.batch_begin(queries)
             else:
                 self.backend.batch_begin(queries, slot_of(i), L, self.u_pad, cap)
@@ -628,7 +648,7 @@ class BatchedFeeds:
                 flying, pending = pending, None
             _, ready = self.backend.batch_finish()
             p = (i // G) % N_SETS
-            if self.union:   # the union message is packed from the finished lists, on the result stream
+            if self.union and not direct_union:   # packed from the finished batch, on the result stream
                 self.backend.batch_pack_union(slot_of(i), self.u_pad, cap)
                 ready = False
             group_ready = group_ready and ready

@@ -158,8 +158,8 @@ def test_two_batches_in_flight_and_table_changes(gpu_ctx, oracle):
 
 
 def test_batch_messages_equal_the_pack_kernel(pie, gpu_ctx, oracle):
-    """pie_scan_batch_begin_packed: every query's result message [off[0..u_pad] | M | rows] and counts copy, written by the
-    batch's offsets kernels into caller-owned memory (here mapped pinned host memory), equal what the results say."""
+    """pie_scan_batch_begin_packed: every query's result message [off[0..u_pad] | M | rows] and counts copy in caller-owned
+    memory (here mapped pinned host memory) equal what the results say."""
     n, U, D = 400009, 3001, 32
     cols = oracle.gen(SEED, n, 0, n, U, D, 0)
     gpu_ctx.load_columns(*cols, U)
@@ -185,7 +185,8 @@ def test_batch_messages_equal_the_pack_kernel(pie, gpu_ctx, oracle):
             assert np.array_equal(cnt_h[k * U:(k + 1) * U], w[0])
         gpu_ctx.scan_batch_begin_packed(qs[:5], msg_d, stride, u_pad, cap, cnt_d, U)
         ms, ready = gpu_ctx.scan_batch_finish(packed=True)
-        assert ready
+        assert not ready   # round 3: per-query messages are materialised from the batch's union and packed at finish
+        gpu_ctx.synchronize()
         for k, w in enumerate(want[:5]):
             m = msg_h[k * stride:(k + 1) * stride]
             assert np.array_equal(m[: U + 1], w[1].astype(np.int32)) and np.array_equal(m[u_pad + 2: u_pad + 2 + w[2].size], w[2])
@@ -200,7 +201,7 @@ def test_batch_argument_errors(gpu_ctx, oracle):
     with pytest.raises(Exception):
         gpu_ctx.scan_batch_begin([])
     with pytest.raises(Exception):
-        gpu_ctx.scan_batch_begin(mixed_queries(oracle, 17))
+        gpu_ctx.scan_batch_begin(mixed_queries(oracle, 65))
     with pytest.raises(Exception):
         gpu_ctx.scan_batch_finish()
     with pytest.raises(Exception):
@@ -433,3 +434,100 @@ def test_few_users_dense_queries_on_the_keyed_form(pie, oracle, monkeypatch):
                 want = oracle_answers(oracle, cols, U, D, batch)
                 for qi in range(len(batch)):
                     assert_same(ctx.batch_read_results(qi), want[qi], f"trial {trial} batch {k} q{qi}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 3: the union is the batch's primary result; up to 64 queries per table pass
+
+def union_from_oracle(oracle, cols, U, D, queries):
+    """numpy restatement of the union result: per user the rows any query selects, in (start, row) order, with a query mask per
+    row.  -> (uoff[U+1], rows, masks uint64)"""
+    s = cols[0]
+    sel = {}
+    for q, (c, off, idx) in enumerate(oracle_answers(oracle, cols, U, D, queries)):
+        for r in idx:
+            sel[int(r)] = sel.get(int(r), 0) | (1 << q)
+    rows = np.array(sorted(sel, key=lambda r: (int(cols[2][r]), int(s[r]), r)), np.int64)
+    users = cols[2][rows] if rows.size else np.zeros(0, np.int32)
+    uoff = np.zeros(U + 1, np.int64)
+    np.add.at(uoff, users.astype(np.int64) + 1, 1)
+    return np.cumsum(uoff), rows.astype(np.int32), np.array([sel[int(r)] for r in rows], np.uint64)
+
+
+@pytest.mark.parametrize("n,U,D,flags", [(65, 3, 2, 0), (100003, 97, 32, 0), (1 << 20, 10 ** 4, 32, 0), (3000017, 20011, 64, 5)])
+@pytest.mark.parametrize("nq", [1, 16, 33, 64])
+def test_union_is_the_primary_result(gpu_ctx, oracle, n, U, D, flags, nq):
+    """pie_batch_read_union against the numpy restatement word for word; every query's M; a user's feed read from the union;
+    the per-query lists materialised from it (counts / offsets / idx) against the oracle — for 1 .. 64 queries per pass."""
+    cols = oracle.gen(SEED, n, 0, n, U, D, flags)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    queries = mixed_queries(oracle, nq)
+    gpu_ctx.scan_batch_begin(queries)
+    ms = gpu_ctx.scan_batch_finish()
+    want = oracle_answers(oracle, cols, U, D, queries)
+    un = gpu_ctx.batch_read_union()
+    if max(int(w[0].max()) if w[0].size else 0 for w in want) <= 16 and un is not None:
+        w_uoff, w_rows, w_masks = union_from_oracle(oracle, cols, U, D, queries)
+        assert np.array_equal(un[0], w_uoff) and np.array_equal(un[1], w_rows) and np.array_equal(un[2], w_masks)
+    assert ms == [int(w[2].size) for w in want]
+    rng = np.random.default_rng(nq)
+    for u in [0, U - 1] + [int(x) for x in rng.integers(0, U, 6)]:     # per-request reads, straight from the union
+        for q in {0, nq - 1, nq // 2}:
+            c, off, idx = want[q]
+            assert np.array_equal(gpu_ctx.batch_read_user_feed(q, u), idx[off[u]:off[u + 1]]), (q, u)
+    for q in sorted({0, nq - 1, nq // 2, min(nq - 1, 32), min(nq - 1, 31)}):   # materialised on request, in any order
+        assert_same(gpu_ctx.batch_read_results(q), want[q], "query %d" % q)
+
+
+def test_batch_of_only_dense_queries_makes_no_table_pass(gpu_ctx, oracle):
+    """every query of the batch is dense (handed to the general path from the key histogram): the batched pass
+    must not run at all — no candidate rows — and the answers still equal the oracle's."""
+    n, U, D = 1 << 20, 5000, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    t0 = oracle.T0_MS
+    queries = [(t0 - 100 * DAY, t0 - 61 * DAY, 0xAAAAAAAAAAAAAAAA), (INT64_MIN, INT64_MIN, ALL), (t0 - 90 * DAY, INT64_MIN, 0xFF)]
+    got = gpu_ctx.scan_batch(queries)
+    for g, w in zip(got, oracle_answers(oracle, cols, U, D, queries)):
+        assert_same(g, w)
+    st = gpu_ctx.stats()
+    assert st["candidates"] == 0 and st["k1_variant"] == 0      # no batched pass ran
+    assert gpu_ctx.batch_read_union() is None                   # per-query results only
+
+
+def test_union_message_written_by_the_batch(gpu_ctx, oracle, pie):
+    """pie_scan_batch_begin_union: the tail kernel writes [uoff | Mu | rows | mask_lo | mask_hi] itself (ready = 1), for 16 and
+    for 64 queries, two batches in flight, into mapped host memory; equal to the union read back and to the oracle."""
+    n, U, D = 500009, 3001, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 1)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    for nq in (16, 64):
+        queries = mixed_queries(oracle, nq)
+        w_uoff, w_rows, w_masks = union_from_oracle(oracle, cols, U, D, queries)
+        mu = int(w_rows.size)
+        u_pad, cap = U + 5, mu + 7
+        words = u_pad + 2 + (3 if nq > 32 else 2) * cap
+        bufs = [gpu_ctx.host_alloc(words) for _ in range(2)]
+        for h, _, _ in bufs:
+            h[:] = -7
+        gpu_ctx.scan_batch_begin_union(queries, bufs[0][1], u_pad, cap)
+        gpu_ctx.scan_batch_begin_union(queries, bufs[1][1], u_pad, cap)
+        for h, _, _ in bufs:
+            ms, ready = gpu_ctx.scan_batch_finish(packed=True)
+            assert ready
+            assert np.array_equal(h[: U + 1], w_uoff.astype(np.int32)) and np.all(h[U + 1: u_pad + 2] == mu)
+            assert np.array_equal(h[u_pad + 2: u_pad + 2 + mu], w_rows)
+            lo = h[u_pad + 2 + cap: u_pad + 2 + cap + mu].astype(np.uint32).astype(np.uint64)
+            hi = h[u_pad + 2 + 2 * cap: u_pad + 2 + 2 * cap + mu].astype(np.uint32).astype(np.uint64) if nq > 32 else 0
+            assert np.array_equal(lo | (hi << np.uint64(32)) if nq > 32 else lo, w_masks)
+        # a message too small for the rows: truncated, Mu still says how many there are
+        small = gpu_ctx.host_alloc(u_pad + 2 + 3 * 10)
+        small[0][:] = -7
+        gpu_ctx.scan_batch_begin_union(queries, small[1], u_pad, 10)
+        ms, ready = gpu_ctx.scan_batch_finish(packed=True)
+        assert ready and int(small[0][u_pad + 1]) == mu and np.array_equal(small[0][u_pad + 2: u_pad + 12], w_rows[:10])
+        for _, _, addr in bufs + [small]:
+            gpu_ctx.host_free(addr)

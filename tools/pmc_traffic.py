@@ -67,7 +67,14 @@ def main():
             doc["hbm_gbs_at_kernel_trace_avg"] = doc["hbm_bytes_per_launch"] / avg_ns[k][1]
             doc["frac_of_8TBs"] = doc["hbm_gbs_at_kernel_trace_avg"] / 8000.0
         kernels[k] = doc
+    lib_hash = None
+    try:   # the digest of the sources the profiled library was built from (sph-pie_amd/build.py writes it beside the .so)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sph-pie_amd", "libpie_hip.so.srchash")) as f:
+            lib_hash = f.read().strip()
+    except OSError:
+        pass
     out = {
+        "lib_srchash": lib_hash,
         "source": "profiles/%s_{fetch,write,rdreq}.summary.csv + profiles/%s_kernel_stats.csv (tools/run_pmc.sh %s)" % (tag, tag, tag),
         "tag": tag,
         "workload": workload,

@@ -7,9 +7,9 @@ set -o pipefail
 tag=${1:-pmc}
 shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-cmd="python3 bench.py --steps 6 --warmup 3 --repeat 1 --no-cpu-baseline $*"
+cmd="python3 bench.py --steps 6 --warmup 3 --repeat 1 --no-cpu-baseline --no-mixed-leg $*"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_fetch -- $cmd > gpurun_out/${tag}_fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_write -- $cmd > gpurun_out/${tag}_write.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d gpurun_out/${tag}_rdreq -- $cmd > gpurun_out/${tag}_rdreq.log 2>&1 &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 30 --warmup 5 --repeat 2 --no-cpu-baseline $* > gpurun_out/${tag}_stats.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 30 --warmup 5 --repeat 2 --no-cpu-baseline --no-mixed-leg $* > gpurun_out/${tag}_stats.log 2>&1 &&
 python3 tools/pmc_traffic.py gpurun_out ${tag} ${TRAFFIC_OUT:-traffic.json} "${TRAFFIC_WORKLOAD:-bench.py default: 1e8 sessions / 1e5 users / 32 disciplines, random order, auth variant, spec query}"
