@@ -335,12 +335,12 @@ __device__ __forceinline__ T stream_load(const T* p)
 //           otherwise hammers one counter from all 64 lanes; chosen by the host from the share of selected rows whose
 //           lane neighbour has the same user, which every non-aggregated pass of this kernel counts.
 template <int UNROLL, bool NT, bool LATE_U, bool GQ = false, bool AGG = false>
-__global__ __launch_bounds__(kK1Threads) void k_scan_compact(
+__device__ __forceinline__ void scan_compact_body(
     const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
     const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
     unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
     int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, DirectSlots direct,
-    const unsigned char* __restrict__ qual = nullptr)
+    const unsigned char* __restrict__ qual, const int bid)
 {
     static_assert(!(GQ && LATE_U), "the group-qualified predicate needs the user column up front");
     __shared__ SelRec stage[kK1Waves][kStage];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     if (threadIdx.x == 0) { blk_cursor = 0; blk_live = 0; blk_dup = 0; }
     __syncthreads();
 
-    const long long c0 = (long long)blockIdx.x * rows_per_block;
+    const long long c0 = (long long)bid * rows_per_block;
     long long c1 = c0 + rows_per_block;
     if (c1 > n) c1 = n;
     SelRec* out = sel + c0;
@@ -479,10 +479,22 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_compact(
     if (lane == 0 && ndup) atomicAdd(&blk_dup, ndup);
     __syncthreads();
     if (threadIdx.x == 0) {
-        blk_count[blockIdx.x] = blk_cursor;
+        blk_count[bid] = blk_cursor;
         // the streaming form has no ambiguous keys: the second statistic carries its same-user-neighbour count instead
-        add_row_stats(summary, blk_live, blk_dup);
+        add_row_stats(summary, blk_live, blk_dup, bid);
     }
+}
+
+template <int UNROLL, bool NT, bool LATE_U, bool GQ = false, bool AGG = false>
+__global__ __launch_bounds__(kK1Threads) void k_scan_compact(
+    const long long* __restrict__ start, const long long* __restrict__ end, const int* __restrict__ user,
+    const int* __restrict__ disc, long long n, long long rows_per_block, long long now, long long cutoff,
+    unsigned long long mask, int n_users, int* __restrict__ counts, SelRec* __restrict__ sel,
+    int* __restrict__ sel_rank, int* __restrict__ blk_count, Summary* __restrict__ summary, DirectSlots direct,
+    const unsigned char* __restrict__ qual = nullptr)
+{
+    scan_compact_body<UNROLL, NT, LATE_U, GQ, AGG>(start, end, user, disc, n, rows_per_block, now, cutoff, mask, n_users, counts, sel, sel_rank,
+                                                   blk_count, summary, direct, qual, (int)blockIdx.x);
 }
 
 // K1, liveness-first form.  In a session store almost every row is expired (12 h TTL, months of history), so
@@ -1820,6 +1832,37 @@ __global__ __launch_bounds__(kK1Threads) void k_scan_keyed_with_tail(KeyedArgs<K
     }
 }
 
+// The same for the streaming form (the every-byte scan, dense queries): K2 of scan i in the first blocks of scan i + 1's
+// streaming pass, so a steady stream of such scans is one launch each.
+struct StreamArgs {
+    const long long* start;
+    const long long* end;
+    const int* user;
+    const int* disc;
+    long long n, rows_per_block, now, cutoff;
+    unsigned long long mask;
+    int n_users;
+    int* counts;
+    SelRec* sel;
+    int* sel_rank;
+    int* blk_count;
+    Summary* summary;
+    DirectSlots direct;
+};
+
+template <bool LATE_U>
+__global__ __launch_bounds__(kK1Threads) void k_scan_compact_with_tail(StreamArgs a, OffsetsArgs t)
+{
+    if ((int)blockIdx.x < t.n_tail) {
+        offsets_body<1, true, kK1Threads>(t.counts, t.counts_ord, t.n_users, t.tile_pub, t.ctl, t.offsets, t.seg_list, t.small_list, t.big_list, t.summary,
+                                          t.host, t.seq, t.zero_span, t.zero_vec16, t.direct, t.bkt, t.out_idx, t.msg, t.u_pad, t.msg_cap,
+                                          t.msg_counts, t.hot, t.hot_thr, t.hot_list, t.over_list, (int)blockIdx.x, t.n_tail);
+    } else {
+        scan_compact_body<4, true, LATE_U>(a.start, a.end, a.user, a.disc, a.n, a.rows_per_block, a.now, a.cutoff, a.mask, a.n_users, a.counts, a.sel,
+                                           a.sel_rank, a.blk_count, a.summary, a.direct, nullptr, (int)blockIdx.x - t.n_tail);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ batched scan: Q queries, one table pass
 //
 // SURVEY.md section 7 ("batch many queries per launch") / the north_star's "batched GPU scan": a server answers many
@@ -2073,7 +2116,6 @@ struct UnionTailArgs {
     int* msg;                  // optional union message (device-visible): [uoff[0..u_pad] | Mu | rows[cap) | mask_lo[cap) | mask_hi[cap) if n_q > 32]
     int u_pad;
     long long msg_cap;
-    int dbg;                   // PIE_TAIL_DBG: timing experiments only (skips parts of the kernel; results are then wrong)
 };
 
 __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane)
@@ -2102,7 +2144,7 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = t.tiles, U = t.n_users, nq = t.n_q;
-    if (t.zero_span && !(t.dbg & 16)) {
+    if (t.zero_span) {
         const int4 z = make_int4(0, 0, 0, 0);
         int4* zs = reinterpret_cast<int4*>(t.zero_span);
         for (long long i = (long long)gbid * BLOCK + threadIdx.x; i < t.zero_total16; i += (long long)nblk * BLOCK) zs[i] = z;
@@ -2113,7 +2155,6 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
     if (threadIdx.x == 0) tile_s = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
     const int tile = (int)tile_s;
-    if ((t.dbg >> 8) == 1) return;
     const int u = tile * BLOCK + (int)threadIdx.x;
     const bool in_u = u < U;
     const int* counts = reinterpret_cast<const int*>(t.span);
@@ -2134,7 +2175,7 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
         r.idx = INT32_MAX;
         r.pad = 0;
         unsigned h = 0;
-        if (nn <= 8 && k < nn && !(t.dbg & 2)) {
+        if (nn <= 8 && k < nn) {
             r = src[k];
             if constexpr (HI) h = t.direct_hi[slot0 + k];
         }
@@ -2168,7 +2209,6 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
             }
         }
     }
-    if ((t.dbg >> 8) == 2) { if (ks[0] == 12345 && ki[7] == 3) t.uoff[0] = km[3]; return; }
     // ONE prefix scan: the union counts
     const int incl = wave_incl_scan_i32(nn, lane);
     {
@@ -2193,9 +2233,9 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
     // query q selected" — by a carry-save adder tree, no loop over queries; then lane q of the wave collects query q's total
     // from four ballots per query.  No branch inside the loop: the chains of consecutive queries interleave (a first version
     // with one ballot per bucket slot and query, each behind a wave-uniform branch, cost 20 of the kernel's 50 us at Q = 64).
-    const bool mid = nn > 8 && !(t.dbg & 32);
+    const bool mid = nn > 8;
     unsigned acc = 0;
-    if (!(t.dbg & 1)) {
+    {
         auto fa = [](unsigned a, unsigned b, unsigned c, unsigned& carry) { const unsigned x = a ^ b; carry = (a & b) | (c & x); return x ^ c; };
         unsigned pl[4], ph[4];
         {
@@ -2240,13 +2280,12 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
             }
         }
     }
-    if ((t.dbg >> 8) == 3) return;
     // base = sum of the granules of the tiles in front of this one
     long long part = 0;
     unsigned pmax = 0;
     {
         const unsigned long long* pub = reinterpret_cast<const unsigned long long*>(t.span + t.tiles_off);
-        for (int tt = threadIdx.x; tt < ((t.dbg & 4) ? 0 : tile); tt += BLOCK) {
+        for (int tt = threadIdx.x; tt < tile; tt += BLOCK) {
             unsigned long long v;
             do {
                 v = __hip_atomic_load(&pub[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2273,14 +2312,13 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
         run += base;
         for (int w = 0; w < wave; ++w) run += s_sum[w];
     }
-    if ((t.dbg >> 8) == 4) { if (run == 12345) t.uoff[0] = run; return; }
     int* msg_rows = t.msg ? t.msg + t.u_pad + 2 : nullptr;
     int* msg_lo = t.msg ? msg_rows + t.msg_cap : nullptr;
     int* msg_hi = t.msg ? msg_lo + t.msg_cap : nullptr;
     if (in_u) {
         t.uoff[u] = run;
         if (t.msg) msg_store(t.msg + u, (int)run);
-        if (nn >= 1 && nn <= 8 && !(t.dbg & 8)) {
+        if (nn >= 1 && nn <= 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (k < nn) {
@@ -2365,7 +2403,6 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
         const long long m_all = s_total;
         for (int uu = U + threadIdx.x; uu <= t.u_pad + 1; uu += BLOCK) msg_store(t.msg + uu, (int)m_all);
     }
-    if ((t.dbg >> 8) == 5) return;
     // completion: the last block hands the summary and the per-query totals to the host (see offsets_body)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

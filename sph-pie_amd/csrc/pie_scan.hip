@@ -958,6 +958,15 @@ bool keyed_can_carry(const pie_ctx* c, const Slot& sl)
     return (sl.variant & ~0x840) == 0x485;
 }
 
+// ... and so do the plain streaming forms (nontemporal loads, unroll 4, with or without late user materialisation): the
+// every-byte scan and dense queries on tables without an ordered run.  PIE_STREAM_RIDE=0 turns it off (A/B runs).
+bool stream_can_carry(const pie_ctx* c, const Slot& sl)
+{
+    if (c->d_qual || !(sl.variant == 0x01 || sl.variant == 0x03)) return false;
+    const char* v = getenv("PIE_STREAM_RIDE"); // read per scan (only on this rare form): in-process A/B runs flip it
+    return !(v && atoi(v) == 0);
+}
+
 void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, long long now, long long cutoff, unsigned long long mask)
 {
     OffsetsArgs t;
@@ -970,6 +979,15 @@ void launch_keyed_with_tail(pie_ctx* c, Slot& sl, Slot& tail, hipStream_t s, lon
     t.n_tail = (c->n_users + kK1Threads - 1) / kK1Threads;
     tail.msg_by_k2 = tail.msg != nullptr;
     const unsigned grid = (unsigned)(sl.k1_blocks + t.n_tail);
+    if (!(sl.variant & 0x400)) { // a streaming form carries the tail
+        StreamArgs a;
+        a.start = c->d_start; a.end = c->d_end; a.user = c->d_user; a.disc = c->d_disc; a.n = c->n; a.rows_per_block = sl.rows_per_block;
+        a.now = now; a.cutoff = cutoff; a.mask = mask; a.n_users = c->n_users; a.counts = sl.counts; a.sel = sl.sel; a.sel_rank = sl.sel_rank;
+        a.blk_count = sl.blk_count; a.summary = sl.sum; a.direct = direct_of(c, sl);
+        if (sl.variant & 2) hipLaunchKernelGGL((k_scan_compact_with_tail<true>), dim3(grid), dim3(kK1Threads), 0, s, a, t);
+        else hipLaunchKernelGGL((k_scan_compact_with_tail<false>), dim3(grid), dim3(kK1Threads), 0, s, a, t);
+        return;
+    }
 #define PIE_RIDE(KT, KEYPTR, NOWKEY)                                                                                     \
     do {                                                                                                                \
         KeyedArgs<KT> a;                                                                                                \
@@ -1591,7 +1609,8 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg, int msg_u_
     // K2 of the scan already in flight (if it is still pending) rides in this scan's launch when both fit the fused
     // kernel; otherwise it goes first, on its own
     Slot& other = c->slot[c->next_slot ^ 1];
-    const bool ride = c->n_flight == 1 && other.in_flight && other.k2_pending && tail_can_ride(c, other) && keyed_can_carry(c, sl);
+    const bool ride = c->n_flight == 1 && other.in_flight && other.k2_pending && tail_can_ride(c, other) &&
+                      (keyed_can_carry(c, sl) || stream_can_carry(c, sl));
     if (c->n_flight == 1 && other.in_flight && other.k2_pending && !ride) {
         launch_k2(c, other, s, other.zero_span, (long long)(counts_span(c) / 16));
         other.k2_pending = false;
@@ -1638,10 +1657,14 @@ int scan_finish(pie_ctx* c, Slot* which)
     if (!slp) return fail(c, PIE_E_STATE, "pie_scan_finish without pie_scan_begin");
     Slot& sl = *slp;
     hipStream_t a = c->stream;
+    const bool e2_recorded = sl.k2_pending && sl.ev_index >= 0;
     if (sl.k2_pending) { // no later scan took it along
         launch_k2(c, sl, a, sl.zero_span, (long long)(counts_span(c) / 16));
         PIE_HIP(c, hipGetLastError());
         sl.k2_pending = false;
+        // "last kernel end" of a scan whose buckets all fit their slots is the end of K2: the event goes in right behind it,
+        // not after the host has woken up on the summary (a scan that needs K3 / K4 records it again behind those)
+        if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, a));
     }
     // wait for K2's last block to publish the summary in mapped host memory (no copy node, no event wait).  The wait is
     // bounded (PIE_WAIT_DEADLINE_MS, default 20 s): a kernel that never finishes must not hang the caller — in the Node
@@ -1835,7 +1858,9 @@ int scan_finish(pie_ctx* c, Slot* which)
         }
     }
     PIE_HIP(c, hipGetLastError());
-    if (sl.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, a));
+    // kernels were queued behind K2 (or K2 rode in a later scan's launch: the event has not been recorded at all)
+    const bool more = (sl.last.m > 0 && (staged || !sl.direct || sl.last.n_seg > 0 || sl.last.n_small > 0)) || sl.last.n_big > 0;
+    if (sl.ev_index >= 0 && (more || !e2_recorded)) PIE_HIP(c, hipEventRecord(c->ring[sl.ev_index].e2, a));
     sl.have_result = true;
     c->res = &sl;
     c->last_was_batch = false;
@@ -1975,8 +2000,6 @@ void fill_tail_args(pie_ctx* c, BatchSlot& b, UnionTailArgs& t)
     t.msg = b.msg_kind == 2 ? b.msg : nullptr;
     t.u_pad = b.msg_u_pad;
     t.msg_cap = b.msg_cap;
-    static const int dbg = getenv("PIE_TAIL_DBG") ? (int)strtol(getenv("PIE_TAIL_DBG"), nullptr, 0) : 0;
-    t.dbg = dbg;
 }
 
 // the predicate tables of a batch (pie_kernels.h BatchTables) over the queries that take part in the pass

@@ -419,15 +419,15 @@ function get(port, cookie){
     const feedsA = createFeedService(store), feedsB = createFeedService(store);
     const t1 = base + 3000 * 977 + 5;
     const requests = [];
-    for(let k = 0; k < 40; k++){
+    for(let k = 0; k < 150; k++){
       requests.push({userId: 'user-' + (k % 37), query: {now: t1 + (k % 19) * 1000, cutoff: base + (k % 3) * 100000, disciplines: k % 4 === 0 ? ['drones', 'audio'] : undefined}});
     }
     requests.push({userId: 'nobody', query: {now: t1, cutoff: 0}});
     fakeNow = t1;
     const bodies = feedsA.eventsJsonForRequests(requests);
-    eq(feedsA.batchesRun() >= 2, true);                            // 19 x 3 x 2 distinct keys at most 16 per batch
+    eq(feedsA.batchesRun() >= 2, true);                            // 150 distinct (now, cutoff, disciplines) keys, at most 64 per batch
     requests.forEach((r, i) => { eq(bodies[i].equals(feedsB.eventsJsonForUser(r.userId, r.query)), true, 'request ' + i); });
-    eq(bodies[40].toString(), '{"events":[]}');
+    eq(bodies[150].toString(), '{"events":[]}');
     // over HTTP: concurrent requests are answered from one batch
     const users = new Map();
     for(let u = 0; u < 37; u++){ users.set('user-' + u, {id: 'user-' + u, roles: ['drones.crew']}); }
