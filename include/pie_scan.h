@@ -333,19 +333,45 @@ pie_ctx *pie_comm_ctx(pie_comm *comm, int32_t rank);
 /* Every local shard generates the synthetic corpus on its own GPU and keeps the rows of its users (pie_gen_synthetic +
  * pie_shard_table): the sharded form of BASELINE.json configs[3]. */
 int pie_comm_gen_synthetic_sharded(pie_comm *comm, uint64_t seed, int64_t n_total, int32_t n_users, int32_t n_disc, uint32_t flags);
-/* One step: every local shard runs ONE batched scan of the n_q queries, whose offsets kernels write the shard's n_q result
+/* One synchronous step, per-query lists: every local shard runs ONE batched scan of the n_q queries and leaves its n_q result
  * messages ([off[0..u_pad] | M | rows], pie_pack_results_device's layout); the messages are exchanged (direct pattern: one
  * send and one receive per peer inside one ncclGroup); returns when every local rank holds all world x n_q messages.
  * u_pad: 0 in a single-process communicator (the largest shard's user count is used); in a process-per-GPU communicator
  * the value every rank agreed on, with the row capacity reserved beforehand (pie_comm_reserve) — the message length must be
- * the same everywhere.  m_out (may be NULL): local_ranks x n_q selected-row counts. */
+ * the same everywhere.  m_out (may be NULL): local_ranks x n_q selected-row counts.
+ * The exchange always runs (a list longer than the capacity is truncated, M stays in its header); the capacity check is made
+ * on the gathered headers, so EVERY rank returns PIE_E_CAPACITY together: reserve pie_comm_needed_cap() and repeat. */
 int pie_comm_scan_batch_gather(pie_comm *comm, const pie_query *queries, int32_t n_q, int32_t u_pad, size_t *m_out);
 int pie_comm_reserve(pie_comm *comm, int32_t n_q, int32_t u_pad, size_t idx_cap);
+/* Rows to reserve after PIE_E_CAPACITY (the largest list / union any rank reported, with headroom): the same on every rank. */
+size_t pie_comm_needed_cap(const pie_comm *comm);
 /* The gathered messages as rank `at_rank` holds them: device pointer and strides (words), or one message copied to the host. */
 int pie_comm_gathered_device_ptr(pie_comm *comm, int32_t at_rank, void **base_out, size_t *rank_stride_words,
                                  size_t *query_stride_words, size_t *u_pad_out);
 int pie_comm_read_gathered(pie_comm *comm, int32_t at_rank, int32_t src_rank, int32_t qi, int32_t *offsets_out /* u_pad + 1 */,
                            int32_t *idx_out, size_t idx_cap, size_t *m_out);
+
+/* ---- the pipelined exchange: ONE union message per step (layout: pie_scan_batch_begin_union), written by each shard's own
+ * batch kernels; the exchange of step i runs on a side stream while the shards scan steps i+1, i+2.  Order of calls:
+ *     step_reserve;  begin(0); begin(1); finish(0); begin(2); collect(0); finish(1); begin(3); collect(1); ...
+ * at most two steps begun and unfinished, at most four uncollected (rotating buffer sets).  Every rank of a
+ * process-per-GPU communicator makes the same calls in the same order.
+ * step_reserve: u_pad as in pie_comm_scan_batch_gather; union_cap = rows per message.
+ * step_finish:  waits for the oldest begun step's summaries on every local shard (m_out: local_ranks x n_q, may be NULL),
+ *               then queues its exchange; does not wait for it.
+ * step_collect: waits for the oldest queued exchange (side stream only); *step_out = its step number (0, 1, 2, ...).
+ *               PIE_E_CAPACITY — on every rank alike, from the gathered Mu words — when a union outgrew union_cap (reserve
+ *               pie_comm_needed_cap() once nothing is in flight, repeat) or could not be formed at all (Mu = -1). */
+int pie_comm_step_reserve(pie_comm *comm, int32_t n_q, int32_t u_pad, size_t union_cap);
+int pie_comm_step_begin(pie_comm *comm, const pie_query *queries, int32_t n_q);
+int pie_comm_step_finish(pie_comm *comm, size_t *m_out);
+int pie_comm_step_collect(pie_comm *comm, int64_t *step_out);
+/* The gathered union messages of a collected step as rank `at_rank` holds them (valid until four more steps have begun):
+ * message of rank r at base + r * rank_stride_words; or one message copied to the host (masks_out: 64-bit mask per row). */
+int pie_comm_step_gathered_ptr(pie_comm *comm, int32_t at_rank, int64_t step, void **base_out, size_t *rank_stride_words,
+                               size_t *u_pad_out, size_t *cap_out);
+int pie_comm_step_read_gathered(pie_comm *comm, int32_t at_rank, int32_t src_rank, int64_t step, int32_t *uoff_out /* u_pad + 1 */,
+                                int32_t *rows_out, uint64_t *masks_out, size_t cap, size_t *mu_out);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,13 @@ _SIGS = [
     ("pie_comm_gen_synthetic_sharded", C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_uint32]),
     ("pie_comm_scan_batch_gather", C.c_int, [_P, C.POINTER(PieQuery), C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     ("pie_comm_reserve", C.c_int, [_P, C.c_int32, C.c_int32, C.c_size_t]),
+    ("pie_comm_needed_cap", C.c_size_t, [_P]),
+    ("pie_comm_step_reserve", C.c_int, [_P, C.c_int32, C.c_int32, C.c_size_t]),
+    ("pie_comm_step_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int32]),
+    ("pie_comm_step_finish", C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    ("pie_comm_step_collect", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("pie_comm_step_gathered_ptr", C.c_int, [_P, C.c_int32, C.c_int64, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("pie_comm_step_read_gathered", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_comm_gathered_device_ptr", C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("pie_comm_read_gathered", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
 ]
@@ -660,6 +667,45 @@ class PieComm:
         m = (C.c_size_t * (nl * len(queries)))()
         self._check(self._lib.pie_comm_scan_batch_gather(self._c, arr, len(queries), int(u_pad), m))
         return [[int(m[k * len(queries) + q]) for q in range(len(queries))] for k in range(nl)]
+
+    # ---- the pipelined union exchange (pie_comm_step_*)
+    def needed_cap(self):
+        return int(self._lib.pie_comm_needed_cap(self._c))
+
+    def step_reserve(self, n_q, u_pad=0, union_cap=1024):
+        self._check(self._lib.pie_comm_step_reserve(self._c, int(n_q), int(u_pad), int(union_cap)))
+
+    def step_begin(self, queries):
+        arr = PieScan._queries(queries)
+        self._check(self._lib.pie_comm_step_begin(self._c, arr, len(queries)))
+        self._step_nq = getattr(self, "_step_nq", [])
+        self._step_nq.append(len(queries))
+
+    def step_finish(self):
+        """-> M[local rank][query] of the oldest begun step; its exchange is queued, not waited for."""
+        nq = self._step_nq.pop(0)
+        nl = int(self._lib.pie_comm_local_ranks(self._c))
+        m = (C.c_size_t * (nl * nq))()
+        self._check(self._lib.pie_comm_step_finish(self._c, m))
+        return [[int(m[k * nq + q]) for q in range(nq)] for k in range(nl)]
+
+    def step_collect(self):
+        """Wait for the oldest queued exchange.  -> its step number; PieError(PIE_E_CAPACITY) on every rank alike when a union
+        outgrew the reserved capacity (needed_cap() says what to reserve)."""
+        step = C.c_int64(-1)
+        self._check(self._lib.pie_comm_step_collect(self._c, C.byref(step)))
+        return int(step.value)
+
+    def step_read_gathered(self, at_rank, src_rank, step):
+        """-> (uoff[u_pad + 1] int32, rows[Mu] int32, masks[Mu] uint64) of src_rank's union message of `step` as at_rank holds it."""
+        base, rs, up, cap = _P(), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self._lib.pie_comm_step_gathered_ptr(self._c, int(at_rank), int(step), C.byref(base), C.byref(rs), C.byref(up), C.byref(cap)))
+        uoff = np.empty(up.value + 1, np.int32)
+        mu = C.c_size_t(0)
+        self._check(self._lib.pie_comm_step_read_gathered(self._c, int(at_rank), int(src_rank), int(step), _ptr(uoff), None, None, 0, C.byref(mu)))
+        rows, masks = np.empty(max(mu.value, 1), np.int32), np.empty(max(mu.value, 1), np.uint64)
+        self._check(self._lib.pie_comm_step_read_gathered(self._c, int(at_rank), int(src_rank), int(step), None, _ptr(rows), _ptr(masks), mu.value, C.byref(mu)))
+        return uoff, rows[: mu.value], masks[: mu.value]
 
     def read_gathered(self, at_rank, src_rank, qi):
         """-> (offsets[u_pad + 1] int32, idx[M] int32) of (src_rank, query qi) as rank at_rank holds it."""

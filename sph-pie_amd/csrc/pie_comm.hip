@@ -15,6 +15,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -45,9 +46,12 @@ Rccl g_rccl;
 bool load_rccl(char* err, size_t errlen)
 {
     if (g_rccl.handle) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // PIE_RCCL_LIB: another library with the same entry points (tests/stub_rccl.c: several "ranks" of ONE process on ONE GPU,
+    // which RCCL itself refuses — the stand-in that lets the communicator's logic run with world > 1 on a one-GPU box)
+    const char* names[] = {getenv("PIE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) {
+        if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
     }
@@ -96,6 +100,18 @@ struct pie_comm {
     int q_max = 0;
     long long u_pad = 0, cap = 0, L = 0;
     int last_nq = 0;
+    long long need = 0;            // row capacity the last exchange called for (the largest list / union any rank reported)
+    // pipelined union exchange (pie_comm_step_*): kSets rotating buffer sets per local rank, a side stream per local rank
+    static constexpr int kSets = 4;
+    std::vector<hipStream_t> xstream;                 // local index -> exchange stream
+    std::vector<int*> umsg[kSets], ugath[kSets];      // [set][local index]: this rank's union message / the gathered ones [world][UL]
+    std::vector<hipEvent_t> ev_ready[kSets], ev_done[kSets];
+    int* h_mu[kSets] = {nullptr, nullptr, nullptr, nullptr}; // pinned: [local index][world] the Mu word of every gathered message
+    long long u_cap = 0, UL = 0;   // union rows per message, words per message (u_pad + 2 + mask_words' share)
+    int u_words = 2;               // words per union row in a message: row + one or two mask words
+    long long begun = 0, finished = 0, collected = 0;  // steps begun / exchanges issued / exchanges collected
+    int step_nq[kSets] = {0, 0, 0, 0};
+    int step_rc[kSets] = {0, 0, 0, 0};   // a step whose finish failed on this process: its collect reports it
     char err[512] = "";
 };
 
@@ -174,6 +190,8 @@ pie_comm* new_comm(int world, int n_local)
     return c;
 }
 
+void free_step_buffers(pie_comm* c);
+
 int local_index(const pie_comm* c, int rank)
 {
     for (int k = 0; k < c->n_local; ++k)
@@ -194,7 +212,8 @@ int pie_comm_create(const int32_t* device_ids, int32_t n, pie_comm** comm_out)
     if (!device_ids || n < 1 || n > 64) return cfail(nullptr, PIE_E_INVAL, "1..64 devices expected (got %d)", n);
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
-            if (device_ids[a] == device_ids[b]) return cfail(nullptr, PIE_E_INVAL, "device %d listed twice: one shard per GPU", device_ids[a]);
+            if (device_ids[a] == device_ids[b] && !getenv("PIE_RCCL_LIB")) // (the test stand-in runs several shards on one GPU)
+                return cfail(nullptr, PIE_E_INVAL, "device %d listed twice: one shard per GPU", device_ids[a]);
     char why[200];
     if (!load_rccl(why, sizeof why)) return cfail(nullptr, PIE_E_NODEVICE, "%s", why);
     pie_comm* c = new_comm(n, n);
@@ -281,7 +300,20 @@ int pie_comm_destroy(pie_comm* c)
         (void)hipSetDevice(c->device[k]);
         if (c->stream[k]) (void)hipStreamSynchronize(c->stream[k]);
     }
+    for (int k = 0; k < c->n_local; ++k) {
+        (void)hipSetDevice(c->device[k]);
+        if (k < (int)c->xstream.size() && c->xstream[k]) (void)hipStreamSynchronize(c->xstream[k]);
+    }
     free_buffers(c);
+    free_step_buffers(c);
+    for (int k = 0; k < c->n_local; ++k) {
+        (void)hipSetDevice(c->device[k]);
+        for (int s = 0; s < pie_comm::kSets; ++s) {
+            if (k < (int)c->ev_ready[s].size() && c->ev_ready[s][k]) (void)hipEventDestroy(c->ev_ready[s][k]);
+            if (k < (int)c->ev_done[s].size() && c->ev_done[s][k]) (void)hipEventDestroy(c->ev_done[s][k]);
+        }
+        if (k < (int)c->xstream.size() && c->xstream[k]) (void)hipStreamDestroy(c->xstream[k]);
+    }
     for (int k = 0; k < c->n_local; ++k) {
         (void)hipSetDevice(c->device[k]);
         if (c->comm[k] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm[k]);
@@ -313,51 +345,19 @@ int pie_comm_gen_synthetic_sharded(pie_comm* c, uint64_t seed, int64_t n_total, 
     return PIE_OK;
 }
 
-int pie_comm_scan_batch_gather(pie_comm* c, const pie_query* queries, int32_t n_q, int32_t u_pad_in, size_t* m_out)
+namespace {
+
+// the direct exchange of one fixed-length message per rank: inside one group every local rank posts one send and one
+// receive per peer (each message crosses its own xGMI link once); its own message is a local copy on the same stream
+int exchange(pie_comm* c, const std::vector<int*>& msg, const std::vector<int*>& gath, size_t count, size_t rank_stride, const std::vector<hipStream_t>& streams)
 {
-    if (!c) return PIE_E_INVAL;
-    if (!queries || n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", PIE_BATCH_MAX, n_q);
-    // u_pad: the largest shard's user count — every message has one length.  A single-process communicator sees every
-    // shard; ranks of a process-per-GPU communicator agree on it beforehand and pass it in (u_pad_in > 0).
-    long long u_pad = u_pad_in;
-    std::vector<pie_stats> st((size_t)c->n_local);
-    for (int k = 0; k < c->n_local; ++k) {
-        st[k].struct_size = sizeof(pie_stats);
-        PIE_CCTX(c, k, pie_stats_get(c->ctx[k], &st[k]));
-        if (u_pad_in <= 0 && (long long)st[k].users > u_pad) u_pad = (long long)st[k].users;
-        if ((long long)st[k].users > u_pad) return cfail(c, PIE_E_INVAL, "rank %d holds %llu users, above u_pad %lld", c->rank_of[k], (unsigned long long)st[k].users, u_pad);
-    }
-    if (c->n_local != c->world && u_pad_in <= 0) return cfail(c, PIE_E_INVAL, "process-per-GPU communicator: pass the agreed u_pad");
-    std::vector<size_t> m((size_t)c->n_local * (size_t)n_q, 0);
-    long long cap = c->cap > 0 ? c->cap : 1024;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        int rc = ensure_buffers(c, n_q, u_pad, cap);
-        if (rc) return rc;
-        // 1. every shard scans its batch; the scan's own kernels write the n_q messages back to back
-        for (int k = 0; k < c->n_local; ++k)
-            PIE_CCTX(c, k, pie_scan_batch_begin_packed(c->ctx[k], queries, n_q, c->msg[k], (size_t)c->L, (size_t)c->u_pad, (size_t)c->cap, nullptr, 0));
-        long long need = 0;
-        for (int k = 0; k < c->n_local; ++k) {
-            int ready = 0;
-            PIE_CCTX(c, k, pie_scan_batch_finish_packed(c->ctx[k], &m[(size_t)k * n_q], &ready));
-            for (int q = 0; q < n_q; ++q)
-                if ((long long)m[(size_t)k * n_q + q] > need) need = (long long)m[(size_t)k * n_q + q];
-        }
-        if (need <= c->cap) break;
-        // a row list outgrew the messages (in a process-per-GPU communicator every rank must see the same `need`: the
-        // caller keeps the capacity in step through pie_comm_reserve)
-        if (c->n_local != c->world) return cfail(c, PIE_E_CAPACITY, "row list of %lld rows exceeds the reserved capacity %lld: pie_comm_reserve", need, c->cap);
-        cap = need + need / 16 + 64;
-    }
-    // 2. the exchange, direct pattern: one send and one receive per peer, all inside one group
-    const size_t count = (size_t)n_q * (size_t)c->L;
     PIE_CNCCL(c, g_rccl.GroupStart());
     for (int k = 0; k < c->n_local; ++k) {
         const int me = c->rank_of[k];
         for (int p = 0; p < c->world; ++p) {
             if (p == me) continue;
-            ncclResult_t r1 = g_rccl.Send(c->msg[k], count, kNcclInt32, p, c->comm[k], c->stream[k]);
-            ncclResult_t r2 = g_rccl.Recv(c->gath[k] + (size_t)p * (size_t)c->q_max * (size_t)c->L, count, kNcclInt32, p, c->comm[k], c->stream[k]);
+            ncclResult_t r1 = g_rccl.Send(msg[k], count, kNcclInt32, p, c->comm[k], streams[k]);
+            ncclResult_t r2 = g_rccl.Recv(gath[k] + (size_t)p * rank_stride, count, kNcclInt32, p, c->comm[k], streams[k]);
             if (r1 != 0 || r2 != 0) {
                 (void)g_rccl.GroupEnd();
                 return cfail(c, PIE_E_HIP, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(r1 != 0 ? r1 : r2));
@@ -365,16 +365,285 @@ int pie_comm_scan_batch_gather(pie_comm* c, const pie_query* queries, int32_t n_
         }
     }
     PIE_CNCCL(c, g_rccl.GroupEnd());
-    for (int k = 0; k < c->n_local; ++k) { // own message: a local copy, same stream
+    for (int k = 0; k < c->n_local; ++k) {
         PIE_CHIP(c, hipSetDevice(c->device[k]));
-        PIE_CHIP(c, hipMemcpyAsync(c->gath[k] + (size_t)c->rank_of[k] * (size_t)c->q_max * (size_t)c->L, c->msg[k], count * 4, hipMemcpyDeviceToDevice, c->stream[k]));
+        PIE_CHIP(c, hipMemcpyAsync(gath[k] + (size_t)c->rank_of[k] * rank_stride, msg[k], count * 4, hipMemcpyDeviceToDevice, streams[k]));
+    }
+    return PIE_OK;
+}
+
+// u_pad every rank uses: the largest shard's user count (single process), or the value the ranks agreed on
+int resolve_u_pad(pie_comm* c, int32_t u_pad_in, long long* u_pad_out)
+{
+    long long u_pad = u_pad_in;
+    for (int k = 0; k < c->n_local; ++k) {
+        pie_stats st;
+        st.struct_size = sizeof(pie_stats);
+        PIE_CCTX(c, k, pie_stats_get(c->ctx[k], &st));
+        if (u_pad_in <= 0 && (long long)st.users > u_pad) u_pad = (long long)st.users;
+        if ((long long)st.users > u_pad) return cfail(c, PIE_E_INVAL, "rank %d holds %llu users, above u_pad %lld", c->rank_of[k], (unsigned long long)st.users, u_pad);
+    }
+    if (c->n_local != c->world && u_pad_in <= 0) return cfail(c, PIE_E_INVAL, "process-per-GPU communicator: pass the agreed u_pad");
+    *u_pad_out = u_pad;
+    return PIE_OK;
+}
+
+void free_step_buffers(pie_comm* c)
+{
+    for (int s = 0; s < pie_comm::kSets; ++s) {
+        for (int k = 0; k < c->n_local; ++k) {
+            (void)hipSetDevice(c->device[k]);
+            if (k < (int)c->umsg[s].size() && c->umsg[s][k]) (void)hipFree(c->umsg[s][k]);
+            if (k < (int)c->ugath[s].size() && c->ugath[s][k]) (void)hipFree(c->ugath[s][k]);
+        }
+        c->umsg[s].assign((size_t)c->n_local, nullptr);
+        c->ugath[s].assign((size_t)c->n_local, nullptr);
+        if (c->h_mu[s]) (void)hipHostFree(c->h_mu[s]);
+        c->h_mu[s] = nullptr;
+    }
+    c->u_cap = c->UL = 0;
+}
+
+// rotating buffer sets of the pipelined union exchange; only while no step is in flight
+int ensure_step_buffers(pie_comm* c, int n_q, long long u_pad, long long cap)
+{
+    const int words = n_q > 32 ? 3 : 2;
+    if (c->UL > 0 && c->u_pad == u_pad && cap <= c->u_cap && words <= c->u_words && c->umsg[0].size() == (size_t)c->n_local && c->umsg[0][0]) return PIE_OK;
+    if (c->begun != c->collected) return cfail(c, PIE_E_STATE, "steps are in flight: collect them before the message size changes");
+    free_step_buffers(c);
+    c->u_pad = u_pad;
+    c->u_cap = cap;
+    c->u_words = words > c->u_words ? words : c->u_words;
+    c->UL = u_pad + 2 + (long long)c->u_words * cap;
+    if (c->xstream.size() != (size_t)c->n_local) c->xstream.assign((size_t)c->n_local, nullptr);
+    for (int s = 0; s < pie_comm::kSets; ++s) {
+        if (c->ev_ready[s].size() != (size_t)c->n_local) { c->ev_ready[s].assign((size_t)c->n_local, nullptr); c->ev_done[s].assign((size_t)c->n_local, nullptr); }
+        PIE_CHIP(c, hipHostMalloc(&c->h_mu[s], (size_t)c->n_local * (size_t)c->world * 4, hipHostMallocDefault));
     }
     for (int k = 0; k < c->n_local; ++k) {
         PIE_CHIP(c, hipSetDevice(c->device[k]));
-        PIE_CHIP(c, hipStreamSynchronize(c->stream[k]));
+        if (!c->xstream[k]) PIE_CHIP(c, hipStreamCreateWithFlags(&c->xstream[k], hipStreamNonBlocking));
+        for (int s = 0; s < pie_comm::kSets; ++s) {
+            PIE_CHIP(c, hipMalloc(&c->umsg[s][k], (size_t)c->UL * 4));
+            PIE_CHIP(c, hipMalloc(&c->ugath[s][k], (size_t)c->UL * 4 * (size_t)c->world));
+            PIE_CHIP(c, hipMemset(c->umsg[s][k], 0, (size_t)c->UL * 4));
+            if (!c->ev_ready[s][k]) PIE_CHIP(c, hipEventCreateWithFlags(&c->ev_ready[s][k], hipEventDisableTiming));
+            if (!c->ev_done[s][k]) PIE_CHIP(c, hipEventCreateWithFlags(&c->ev_done[s][k], hipEventDisableTiming));
+        }
     }
-    c->last_nq = n_q;
+    return PIE_OK;
+}
+
+} // namespace
+
+// One synchronous step, per-query lists.  The exchange ALWAYS runs once every local shard has finished its batch — the
+// messages have the fixed length L and simply truncate a list that outgrew the capacity (M stays in the header) — and the
+// capacity check is made on the GATHERED headers, which every rank sees alike: all ranks return PIE_E_CAPACITY together
+// (pie_comm_needed_cap says what to reserve), none is left waiting inside ncclSend / ncclRecv for a peer that bailed out
+// (ADVICE r02).  An error on one local shard still finishes the batches begun on the others before it is reported.
+int pie_comm_scan_batch_gather(pie_comm* c, const pie_query* queries, int32_t n_q, int32_t u_pad_in, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!queries || n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", PIE_BATCH_MAX, n_q);
+    if (c->begun != c->collected) return cfail(c, PIE_E_STATE, "pipelined steps are in flight (pie_comm_step_*): collect them first");
+    long long u_pad = 0;
+    int rc = resolve_u_pad(c, u_pad_in, &u_pad);
+    if (rc) return rc;
+    std::vector<size_t> m((size_t)c->n_local * (size_t)n_q, 0);
+    long long cap = c->cap > 0 ? c->cap : 1024;
+    std::vector<int> heads((size_t)c->world * (size_t)n_q);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = ensure_buffers(c, n_q, u_pad, cap);
+        if (rc) return rc;
+        // 1. every shard scans its batch and leaves its n_q messages back to back in msg[k]
+        int begun = 0, first_rc = PIE_OK;
+        for (int k = 0; k < c->n_local && first_rc == PIE_OK; ++k) {
+            first_rc = pie_scan_batch_begin_packed(c->ctx[k], queries, n_q, c->msg[k], (size_t)c->L, (size_t)c->u_pad, (size_t)c->cap, nullptr, 0);
+            if (first_rc == PIE_OK) ++begun;
+            else cfail(c, first_rc, "rank %d: %s", c->rank_of[k], pie_last_error(c->ctx[k]));
+        }
+        for (int k = 0; k < begun; ++k) { // every batch that was begun is finished, whatever happened elsewhere
+            int ready = 0;
+            const int r2 = pie_scan_batch_finish_packed(c->ctx[k], &m[(size_t)k * n_q], &ready);
+            if (r2 != PIE_OK && first_rc == PIE_OK) {
+                first_rc = r2;
+                cfail(c, r2, "rank %d: %s", c->rank_of[k], pie_last_error(c->ctx[k]));
+            }
+        }
+        if (first_rc != PIE_OK) return first_rc; // a local failure (bad argument, HIP error): no rank of THIS process entered the exchange
+        // 2. the exchange: always
+        const size_t count = (size_t)n_q * (size_t)c->L;
+        rc = exchange(c, c->msg, c->gath, count, (size_t)c->q_max * (size_t)c->L, c->stream);
+        if (rc) return rc;
+        // 3. every rank's M words, as gathered at the first local rank: the same numbers on every rank of the communicator
+        PIE_CHIP(c, hipSetDevice(c->device[0]));
+        for (int p = 0; p < c->world; ++p)
+            PIE_CHIP(c, hipMemcpy2DAsync(&heads[(size_t)p * n_q], 4, c->gath[0] + (size_t)p * (size_t)c->q_max * (size_t)c->L + (size_t)c->u_pad + 1,
+                                         (size_t)c->L * 4, 4, (size_t)n_q, hipMemcpyDeviceToHost, c->stream[0]));
+        for (int k = 0; k < c->n_local; ++k) {
+            PIE_CHIP(c, hipSetDevice(c->device[k]));
+            PIE_CHIP(c, hipStreamSynchronize(c->stream[k]));
+        }
+        long long need = 0;
+        for (int v : heads) need = v > need ? v : need;
+        c->need = need;
+        c->last_nq = n_q;
+        if (need <= c->cap) break;
+        if (c->n_local != c->world || attempt == 2)
+            return cfail(c, PIE_E_CAPACITY, "a row list of %lld rows exceeds the reserved capacity %lld on some rank: every rank calls pie_comm_reserve(pie_comm_needed_cap) and repeats the step", need, c->cap);
+        cap = need + need / 16 + 64; // a single process owns every rank: grow and run the step again
+    }
     if (m_out) memcpy(m_out, m.data(), m.size() * sizeof(size_t));
+    return PIE_OK;
+}
+
+size_t pie_comm_needed_cap(const pie_comm* c) { return c ? (size_t)(c->need + c->need / 16 + 64) : 0; }
+
+// ---- the pipelined exchange: ONE union message per step, written by the batch's own tail kernel; the exchange of a step
+// runs on a side stream while the shards scan the next ones (the C-ABI counterpart of shard.py's BatchedFeeds.run_steps)
+int pie_comm_step_reserve(pie_comm* c, int32_t n_q, int32_t u_pad_in, size_t union_cap)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "bad reservation");
+    long long u_pad = 0;
+    int rc = resolve_u_pad(c, u_pad_in, &u_pad);
+    if (rc) return rc;
+    return ensure_step_buffers(c, n_q, u_pad, (long long)(union_cap > 0 ? union_cap : 1024));
+}
+
+int pie_comm_step_begin(pie_comm* c, const pie_query* queries, int32_t n_q)
+{
+    if (!c) return PIE_E_INVAL;
+    if (!queries || n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", PIE_BATCH_MAX, n_q);
+    if (c->UL <= 0) return cfail(c, PIE_E_STATE, "pie_comm_step_reserve first");
+    if ((n_q > 32 ? 3 : 2) > c->u_words) return cfail(c, PIE_E_STATE, "reserved for batches of at most 32 queries: pie_comm_step_reserve again");
+    if (c->begun - c->finished >= 2) return cfail(c, PIE_E_STATE, "two steps are already begun: pie_comm_step_finish first");
+    if (c->begun - c->collected >= pie_comm::kSets) return cfail(c, PIE_E_STATE, "%d steps are uncollected: pie_comm_step_collect first", pie_comm::kSets);
+    const int s = (int)(c->begun % pie_comm::kSets);
+    int begun = 0, rc = PIE_OK;
+    for (int k = 0; k < c->n_local && rc == PIE_OK; ++k) {
+        rc = pie_scan_batch_begin_union(c->ctx[k], queries, n_q, c->umsg[s][k], (size_t)c->u_pad, (size_t)c->u_cap);
+        if (rc == PIE_OK) ++begun;
+        else cfail(c, rc, "rank %d: %s", c->rank_of[k], pie_last_error(c->ctx[k]));
+    }
+    if (rc != PIE_OK) { // the step is not counted; what the other shards began is finished and dropped
+        for (int k = 0; k < begun; ++k) (void)pie_scan_batch_finish_packed(c->ctx[k], nullptr, nullptr);
+        return rc;
+    }
+    c->step_nq[s] = n_q;
+    c->begun++;
+    return PIE_OK;
+}
+
+int pie_comm_step_finish(pie_comm* c, size_t* m_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (c->finished >= c->begun) return cfail(c, PIE_E_STATE, "pie_comm_step_finish without pie_comm_step_begin");
+    const int s = (int)(c->finished % pie_comm::kSets);
+    const int n_q = c->step_nq[s];
+    std::vector<size_t> m((size_t)c->n_local * (size_t)n_q, 0);
+    int first_rc = PIE_OK;
+    for (int k = 0; k < c->n_local; ++k) {
+        int ready = 0;
+        const int rc = pie_scan_batch_finish_packed(c->ctx[k], &m[(size_t)k * n_q], &ready);
+        if (rc != PIE_OK && first_rc == PIE_OK) {
+            first_rc = rc;
+            cfail(c, rc, "rank %d: %s", c->rank_of[k], pie_last_error(c->ctx[k]));
+        }
+        // ready = 0: the message was packed on the context's stream after the batch: the exchange stream waits for exactly that
+        PIE_CHIP(c, hipSetDevice(c->device[k]));
+        if (!ready) {
+            PIE_CHIP(c, hipEventRecord(c->ev_ready[s][k], c->stream[k]));
+            PIE_CHIP(c, hipStreamWaitEvent(c->xstream[k], c->ev_ready[s][k], 0));
+        }
+    }
+    c->finished++;
+    c->step_rc[s] = first_rc;
+    if (first_rc != PIE_OK) return first_rc; // every local batch has been finished; no exchange is queued for this step (its collect says so)
+    // the exchange of this step, on the side streams: nothing here waits for it
+    int rc = exchange(c, c->umsg[s], c->ugath[s], (size_t)c->UL, (size_t)c->UL, c->xstream);
+    if (rc) return rc;
+    for (int k = 0; k < c->n_local; ++k) {
+        PIE_CHIP(c, hipSetDevice(c->device[k]));
+        PIE_CHIP(c, hipMemcpy2DAsync(c->h_mu[s] + (size_t)k * (size_t)c->world, 4, c->ugath[s][k] + (size_t)c->u_pad + 1, (size_t)c->UL * 4, 4,
+                                     (size_t)c->world, hipMemcpyDeviceToHost, c->xstream[k]));
+        PIE_CHIP(c, hipEventRecord(c->ev_done[s][k], c->xstream[k]));
+    }
+    if (m_out) memcpy(m_out, m.data(), m.size() * sizeof(size_t));
+    return PIE_OK;
+}
+
+int pie_comm_step_collect(pie_comm* c, int64_t* step_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (c->collected >= c->finished) return cfail(c, PIE_E_STATE, "no exchange to collect: pie_comm_step_finish first");
+    const int s = (int)(c->collected % pie_comm::kSets);
+    if (step_out) *step_out = (int64_t)c->collected;
+    if (c->step_rc[s] != PIE_OK) {
+        c->collected++;
+        return cfail(c, PIE_E_STATE, "step %lld failed in pie_comm_step_finish (status %d): nothing was exchanged", (long long)c->collected - 1, c->step_rc[s]);
+    }
+    for (int k = 0; k < c->n_local; ++k) {
+        PIE_CHIP(c, hipSetDevice(c->device[k]));
+        PIE_CHIP(c, hipEventSynchronize(c->ev_done[s][k])); // the side stream only: the shards' scan streams run on
+    }
+    c->collected++;
+    long long need = 0;
+    bool merged_overflow = false;
+    for (int p = 0; p < c->world; ++p) { // every rank holds the same world Mu words
+        const int mu = c->h_mu[s][p];
+        if (mu < 0) merged_overflow = true;
+        if (mu > need) need = mu;
+    }
+    c->need = need;
+    if (merged_overflow)
+        return cfail(c, PIE_E_CAPACITY, "a shard's union could not be formed (Mu = -1: queries fell back and a user's merged union exceeds 32 rows, or more than 32 queries): use pie_comm_scan_batch_gather for this batch");
+    if (need > c->u_cap)
+        return cfail(c, PIE_E_CAPACITY, "a union of %lld rows exceeds the reserved capacity %lld on some rank: collect what is in flight, pie_comm_step_reserve(pie_comm_needed_cap), repeat the step", need, c->u_cap);
+    return PIE_OK;
+}
+
+int pie_comm_step_gathered_ptr(pie_comm* c, int32_t at_rank, int64_t step, void** base_out, size_t* rank_stride_words, size_t* u_pad_out, size_t* cap_out)
+{
+    if (!c) return PIE_E_INVAL;
+    const int k = local_index(c, at_rank);
+    if (k < 0 || c->UL <= 0) return cfail(c, PIE_E_STATE, "rank %d is not local to this communicator or nothing was reserved", at_rank);
+    if (step < 0 || step >= c->collected || step + pie_comm::kSets <= c->begun) return cfail(c, PIE_E_STATE, "step %lld is not collected or its buffers were reused", (long long)step);
+    if (base_out) *base_out = c->ugath[step % pie_comm::kSets][k];
+    if (rank_stride_words) *rank_stride_words = (size_t)c->UL;
+    if (u_pad_out) *u_pad_out = (size_t)c->u_pad;
+    if (cap_out) *cap_out = (size_t)c->u_cap;
+    return PIE_OK;
+}
+
+int pie_comm_step_read_gathered(pie_comm* c, int32_t at_rank, int32_t src_rank, int64_t step, int32_t* uoff_out, int32_t* rows_out, uint64_t* masks_out,
+                                size_t cap, size_t* mu_out)
+{
+    if (!c) return PIE_E_INVAL;
+    void* base = nullptr;
+    int rc = pie_comm_step_gathered_ptr(c, at_rank, step, &base, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (src_rank < 0 || src_rank >= c->world) return cfail(c, PIE_E_INVAL, "source rank outside the communicator");
+    const int k = local_index(c, at_rank);
+    PIE_CHIP(c, hipSetDevice(c->device[k]));
+    const int* msg = static_cast<const int*>(base) + (size_t)src_rank * (size_t)c->UL;
+    int mu32 = 0;
+    PIE_CHIP(c, hipMemcpy(&mu32, msg + c->u_pad + 1, 4, hipMemcpyDeviceToHost));
+    const size_t mu = mu32 > 0 ? (size_t)mu32 : 0;
+    if (mu_out) *mu_out = mu;
+    if (uoff_out) PIE_CHIP(c, hipMemcpy(uoff_out, msg, ((size_t)c->u_pad + 1) * 4, hipMemcpyDeviceToHost));
+    const size_t have = mu < (size_t)c->u_cap ? mu : (size_t)c->u_cap;
+    if ((rows_out || masks_out) && have > cap) return cfail(c, PIE_E_CAPACITY, "cap %zu < %zu union rows", cap, have);
+    if (rows_out && have) PIE_CHIP(c, hipMemcpy(rows_out, msg + c->u_pad + 2, have * 4, hipMemcpyDeviceToHost));
+    if (masks_out && have) {
+        std::vector<uint32_t> lo(have), hi;
+        PIE_CHIP(c, hipMemcpy(lo.data(), msg + c->u_pad + 2 + c->u_cap, have * 4, hipMemcpyDeviceToHost));
+        if (c->u_words == 3 && c->step_nq[step % pie_comm::kSets] > 32) {
+            hi.resize(have);
+            PIE_CHIP(c, hipMemcpy(hi.data(), msg + c->u_pad + 2 + 2 * c->u_cap, have * 4, hipMemcpyDeviceToHost));
+        }
+        for (size_t i = 0; i < have; ++i) masks_out[i] = (uint64_t)lo[i] | (hi.empty() ? 0ull : ((uint64_t)hi[i] << 32));
+    }
     return PIE_OK;
 }
 

@@ -59,7 +59,14 @@
     X(int, pie_comm_gen_synthetic_sharded, (pie_comm *, uint64_t, int64_t, int32_t, int32_t, uint32_t))             \
     X(int, pie_comm_scan_batch_gather, (pie_comm *, const pie_query *, int32_t, int32_t, size_t *))                 \
     X(int, pie_comm_gathered_device_ptr, (pie_comm *, int32_t, void **, size_t *, size_t *, size_t *))              \
-    X(int, pie_comm_read_gathered, (pie_comm *, int32_t, int32_t, int32_t, int32_t *, int32_t *, size_t, size_t *))
+    X(int, pie_comm_read_gathered, (pie_comm *, int32_t, int32_t, int32_t, int32_t *, int32_t *, size_t, size_t *))            \
+    X(size_t, pie_comm_needed_cap, (const pie_comm *))                                                              \
+    X(int, pie_comm_step_reserve, (pie_comm *, int32_t, int32_t, size_t))                                           \
+    X(int, pie_comm_step_begin, (pie_comm *, const pie_query *, int32_t))                                           \
+    X(int, pie_comm_step_finish, (pie_comm *, size_t *))                                                            \
+    X(int, pie_comm_step_collect, (pie_comm *, int64_t *))                                                          \
+    X(int, pie_comm_step_gathered_ptr, (pie_comm *, int32_t, int64_t, void **, size_t *, size_t *, size_t *))       \
+    X(int, pie_comm_step_read_gathered, (pie_comm *, int32_t, int32_t, int64_t, int32_t *, int32_t *, uint64_t *, size_t, size_t *))
 
 #define X(ret, name, args) static ret(*p_##name) args;
 PIE_SYMBOLS(X)
@@ -129,18 +136,30 @@ static void *typed(napi_env env, napi_value v, napi_typedarray_type want, size_t
  * libuv pool the box is `busy` and every other entry point refuses it (PIE_E_STATE) instead of racing the worker on the
  * context's state; after ctxDestroy the box stays (the external keeps pointing at it) with ctx = NULL, so a stale handle
  * throws instead of touching freed memory.  `owned` = 0: the context belongs to a communicator (commCtx). */
-typedef struct {
+struct comm_box_s;
+typedef struct ctx_box_s {
     pie_ctx *ctx;
     int busy;
     int owned;
+    /* a context handed out by commCtx: it lives inside its communicator.  The box holds a reference on the communicator's
+     * JS handle (the communicator cannot be collected while a context handle is alive) and sits on the communicator's list,
+     * so commDestroy can clear box->ctx: a stale handle then throws PIE_E_STATE like a destroyed context. */
+    struct comm_box_s *parent;
+    struct ctx_box_s *next;
+    napi_ref comm_ref;
 } ctx_box;
+
+static void comm_unlink_ctx(ctx_box *b);
 
 static void box_finalize(napi_env env, void *data, void *hint)
 {
-    (void)env;
     (void)hint;
     ctx_box *b = (ctx_box *)data;
     if (b && b->ctx && b->owned && !b->busy && p_pie_ctx_destroy) p_pie_ctx_destroy(b->ctx);
+    if (b) {
+        comm_unlink_ctx(b);
+        if (b->comm_ref) napi_delete_reference(env, b->comm_ref);
+    }
     free(b);
 }
 
@@ -994,7 +1013,7 @@ static napi_value fn_scan_batch(napi_env env, napi_callback_info info)
     pie_query q[PIE_BATCH_MAX];
     int n_q = 0;
     if (!read_queries(env, argv[1], argv[2], argv[3], q, &n_q)) {
-        napi_throw_type_error(env, NULL, "scanBatch(ctx, BigInt64Array nows, BigInt64Array cutoffs, BigUint64Array masks): 1..16 queries, equal lengths");
+        napi_throw_type_error(env, NULL, "scanBatch(ctx, BigInt64Array nows, BigInt64Array cutoffs, BigUint64Array masks): 1..64 queries, equal lengths");
         return NULL;
     }
     size_t m[PIE_BATCH_MAX];
@@ -1039,17 +1058,65 @@ static napi_value throw_comm(napi_env env, pie_comm *cm, int rc)
     return NULL;
 }
 
-typedef struct {
+typedef struct comm_box_s {
     pie_comm *comm;
+    ctx_box *boxes; /* context handles handed out by commCtx and still alive */
 } comm_box;
+
+static void comm_unlink_ctx(ctx_box *b)
+{
+    if (!b->parent) return;
+    for (ctx_box **pp = &b->parent->boxes; *pp; pp = &(*pp)->next)
+        if (*pp == b) {
+            *pp = b->next;
+            break;
+        }
+    b->parent = NULL;
+    b->next = NULL;
+}
+
+/* the communicator's contexts are about to die (or just died): every handle to them becomes a destroyed context */
+static void comm_orphan_ctxs(comm_box *cb)
+{
+    for (ctx_box *b = cb->boxes; b;) {
+        ctx_box *nx = b->next;
+        b->ctx = NULL;
+        b->parent = NULL;
+        b->next = NULL;
+        b = nx;
+    }
+    cb->boxes = NULL;
+}
+
+static int comm_any_busy(const comm_box *cb)
+{
+    for (const ctx_box *b = cb->boxes; b; b = b->next)
+        if (b->busy) return 1;
+    return 0;
+}
 
 static void comm_finalize(napi_env env, void *data, void *hint)
 {
     (void)env;
     (void)hint;
     comm_box *b = (comm_box *)data;
+    if (b) comm_orphan_ctxs(b);
     if (b && b->comm && p_pie_comm_destroy) p_pie_comm_destroy(b->comm);
     free(b);
+}
+
+static comm_box *get_comm_box(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((comm_box *)p)->comm) {
+        napi_throw_type_error(env, NULL, "expected a live pie communicator");
+        return NULL;
+    }
+    if (comm_any_busy((comm_box *)p)) {
+        throw_state(env, "pie_comm error -6: an asynchronous scan is in flight on one of this communicator's contexts");
+        return NULL;
+    }
+    return (comm_box *)p;
 }
 
 static pie_comm *get_comm(napi_env env, napi_value v)
@@ -1097,7 +1164,9 @@ static napi_value fn_comm_destroy(napi_env env, napi_callback_info info)
         return NULL;
     }
     comm_box *b = (comm_box *)p;
-    if (b->comm) p_pie_comm_destroy(b->comm); /* contexts handed out by commCtx die with it: do not use them afterwards */
+    if (comm_any_busy(b)) return throw_state(env, "pie_comm error -6: an asynchronous scan is in flight on one of this communicator's contexts");
+    comm_orphan_ctxs(b); /* handles handed out by commCtx now read as destroyed contexts */
+    if (b->comm) p_pie_comm_destroy(b->comm);
     b->comm = NULL;
     return js_int(env, 0);
 }
@@ -1120,15 +1189,27 @@ static napi_value fn_comm_ctx(napi_env env, napi_callback_info info)
     CHECK(env, napi_get_value_int32(env, argv[1], &rank));
     pie_ctx *ctx = p_pie_comm_ctx(cm, rank);
     if (!ctx) return throw_state(env, "pie_comm error -6: that rank is not local to this communicator");
+    void *pcb = NULL;
+    CHECK(env, napi_get_value_external(env, argv[0], &pcb));
+    comm_box *cb = (comm_box *)pcb;
     ctx_box *b = (ctx_box *)calloc(1, sizeof *b);
     napi_value ext;
-    if (!b || napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
+    if (!b || napi_create_reference(env, argv[0], 1, &b->comm_ref) != napi_ok) {
+        free(b);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    if (napi_create_external(env, b, box_finalize, NULL, &ext) != napi_ok) {
+        napi_delete_reference(env, b->comm_ref);
         free(b);
         napi_throw_error(env, NULL, "out of memory");
         return NULL;
     }
     b->ctx = ctx;
     b->owned = 0;
+    b->parent = cb;
+    b->next = cb->boxes;
+    cb->boxes = b;
     return ext;
 }
 
@@ -1157,8 +1238,9 @@ static napi_value fn_comm_gen(napi_env env, napi_callback_info info)
 static napi_value fn_comm_scan_gather(napi_env env, napi_callback_info info)
 {
     ARGS(4)
-    pie_comm *cm = get_comm(env, argv[0]);
-    if (!cm) return NULL;
+    comm_box *cbx = get_comm_box(env, argv[0]); /* refuses while scanAsync runs on one of the shard contexts */
+    if (!cbx) return NULL;
+    pie_comm *cm = cbx->comm;
     pie_query q[PIE_BATCH_MAX];
     int n_q = 0;
     if (!read_queries(env, argv[1], argv[2], argv[3], q, &n_q)) {
@@ -1227,6 +1309,135 @@ static napi_value fn_comm_upad(napi_env env, napi_callback_info info)
     return js_int(env, (int64_t)u_pad);
 }
 
+/* ---- the pipelined union exchange (pie_comm_step_*): commStepReserve(comm, nQ, unionCap); commStepBegin(comm, nows, cutoffs,
+ * masks); commStepFinish(comm) -> [rank][query] M; commStepCollect(comm) -> step number (throws code -5 on every rank alike when a
+ * union outgrew the reservation: commNeededCap says what to reserve); commStepReadGathered(comm, at, src, step, uoff, rows, masks) */
+static napi_value fn_comm_needed_cap(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    return js_int(env, (int64_t)p_pie_comm_needed_cap(cm));
+}
+
+static napi_value fn_comm_step_reserve(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    comm_box *cbx = get_comm_box(env, argv[0]);
+    if (!cbx) return NULL;
+    int32_t n_q = 0;
+    int64_t cap = 0;
+    CHECK(env, napi_get_value_int32(env, argv[1], &n_q));
+    CHECK(env, napi_get_value_int64(env, argv[2], &cap));
+    int rc = p_pie_comm_step_reserve(cbx->comm, n_q, 0, (size_t)(cap > 0 ? cap : 0));
+    if (rc) return throw_comm(env, cbx->comm, rc);
+    return js_int(env, 0);
+}
+
+static int step_nq_ring[8];
+static unsigned step_nq_head = 0, step_nq_tail = 0; /* queries of the steps begun and not finished (at most two) */
+
+static napi_value fn_comm_step_begin(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    comm_box *cbx = get_comm_box(env, argv[0]);
+    if (!cbx) return NULL;
+    pie_query q[PIE_BATCH_MAX];
+    int n_q = 0;
+    if (!read_queries(env, argv[1], argv[2], argv[3], q, &n_q)) {
+        napi_throw_type_error(env, NULL, "commStepBegin(comm, BigInt64Array nows, BigInt64Array cutoffs, BigUint64Array masks)");
+        return NULL;
+    }
+    int rc = p_pie_comm_step_begin(cbx->comm, q, n_q);
+    if (rc) return throw_comm(env, cbx->comm, rc);
+    step_nq_ring[step_nq_head++ & 7] = n_q;
+    return js_int(env, 0);
+}
+
+static napi_value fn_comm_step_finish(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    comm_box *cbx = get_comm_box(env, argv[0]);
+    if (!cbx) return NULL;
+    if (step_nq_tail == step_nq_head) return throw_state(env, "pie_comm error -6: commStepFinish without commStepBegin");
+    const int n_q = step_nq_ring[step_nq_tail++ & 7];
+    const int world = p_pie_comm_world(cbx->comm);
+    size_t *m = (size_t *)calloc((size_t)world * (size_t)n_q, sizeof *m);
+    if (!m) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    int rc = p_pie_comm_step_finish(cbx->comm, m);
+    if (rc) {
+        free(m);
+        return throw_comm(env, cbx->comm, rc);
+    }
+    napi_value out;
+    napi_create_array_with_length(env, (size_t)world, &out);
+    for (int r = 0; r < world; ++r) {
+        napi_value row;
+        napi_create_array_with_length(env, (size_t)n_q, &row);
+        for (int k = 0; k < n_q; ++k) napi_set_element(env, row, (uint32_t)k, js_int(env, (int64_t)m[(size_t)r * n_q + k]));
+        napi_set_element(env, out, (uint32_t)r, row);
+    }
+    free(m);
+    return out;
+}
+
+static napi_value fn_comm_step_collect(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    comm_box *cbx = get_comm_box(env, argv[0]);
+    if (!cbx) return NULL;
+    int64_t step = -1;
+    int rc = p_pie_comm_step_collect(cbx->comm, &step);
+    if (rc) return throw_comm(env, cbx->comm, rc);
+    return js_int(env, step);
+}
+
+/* commStepReadGathered(comm, atRank, srcRank, step, uoff Int32Array[>= uPad + 1], rows Int32Array, masks BigUint64Array) -> Mu */
+static napi_value fn_comm_step_read(napi_env env, napi_callback_info info)
+{
+    ARGS(7)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int32_t at = 0, src = 0;
+    int64_t step = 0;
+    size_t no = 0, nr = 0, nm = 0, mu = 0, u_pad = 0, rs = 0, cap = 0;
+    void *base = NULL;
+    CHECK(env, napi_get_value_int32(env, argv[1], &at));
+    CHECK(env, napi_get_value_int32(env, argv[2], &src));
+    CHECK(env, napi_get_value_int64(env, argv[3], &step));
+    int32_t *off = typed(env, argv[4], napi_int32_array, &no), *rows = typed(env, argv[5], napi_int32_array, &nr);
+    uint64_t *masks = typed(env, argv[6], napi_biguint64_array, &nm);
+    int rc = p_pie_comm_step_gathered_ptr(cm, at, step, &base, &rs, &u_pad, &cap);
+    if (rc) return throw_comm(env, cm, rc);
+    if (!off || !rows || !masks || no < u_pad + 1) {
+        napi_throw_type_error(env, NULL, "commStepReadGathered(comm, at, src, step, Int32Array[>= uPad + 1], Int32Array rows, BigUint64Array masks)");
+        return NULL;
+    }
+    rc = p_pie_comm_step_read_gathered(cm, at, src, step, off, rows, masks, nr < nm ? nr : nm, &mu);
+    if (rc) return throw_comm(env, cm, rc);
+    return js_int(env, (int64_t)mu);
+}
+
+/* commStepUPad(comm, atRank, step) -> users per union message */
+static napi_value fn_comm_step_upad(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    pie_comm *cm = get_comm(env, argv[0]);
+    if (!cm) return NULL;
+    int32_t at = 0;
+    int64_t step = 0;
+    size_t u_pad = 0, rs = 0, cap = 0;
+    void *base = NULL;
+    CHECK(env, napi_get_value_int32(env, argv[1], &at));
+    CHECK(env, napi_get_value_int64(env, argv[2], &step));
+    int rc = p_pie_comm_step_gathered_ptr(cm, at, step, &base, &rs, &u_pad, &cap);
+    if (rc) return throw_comm(env, cm, rc);
+    return js_int(env, (int64_t)u_pad);
+}
+
 /* stats(ctx) -> {rows, users, selected, algBytes, k1MsSum, scanMsSum, nProfiled, maxBucket} */
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
@@ -1290,6 +1501,9 @@ static napi_value init(napi_env env, napi_value exports)
         {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed},
         {"commCreate", fn_comm_create}, {"commDestroy", fn_comm_destroy}, {"commWorld", fn_comm_world}, {"commCtx", fn_comm_ctx},
         {"commGenSyntheticSharded", fn_comm_gen}, {"commScanBatchGather", fn_comm_scan_gather}, {"commReadGathered", fn_comm_read}, {"commUPad", fn_comm_upad},
+        {"commNeededCap", fn_comm_needed_cap}, {"commStepReserve", fn_comm_step_reserve}, {"commStepBegin", fn_comm_step_begin},
+        {"commStepFinish", fn_comm_step_finish}, {"commStepCollect", fn_comm_step_collect}, {"commStepReadGathered", fn_comm_step_read},
+        {"commStepUPad", fn_comm_step_upad},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         napi_value fn;

@@ -497,9 +497,50 @@ function get(port, cookie){
     native.ctxDestroy(single);
     assert.throws(() => native.scanDevice(single, nows[0], cuts[0]), e => e.code === -6);
     checks += 3;
+    // the pipelined union exchange through the addon: reserve, two steps begun ahead, finish / collect, every query's feed a
+    // filter of the gathered union; a reservation that is too small is reported at collect (code -5) with what to reserve
+    {
+      const single2 = native.ctxCreate(0);
+      native.genSynthetic(single2, 0x5EED5EED, n, 0, n, U, D, 0);
+      native.commStepReserve(comm, 3, 8);
+      native.commStepBegin(comm, nows, cuts, masks);
+      native.commStepFinish(comm);
+      assert.throws(() => native.commStepCollect(comm), e => e.code === -5);
+      const need = native.commNeededCap(comm);
+      eq(need > 8, true);
+      native.commStepReserve(comm, 3, need);
+      const steps = [];
+      native.commStepBegin(comm, nows, cuts, masks);
+      for(let i = 0; i < 5; i++){
+        if(i + 1 < 5){ native.commStepBegin(comm, nows, cuts, masks); }
+        const msq = native.commStepFinish(comm);
+        eq(msq[0].length, 3);
+        if(i >= 1){ steps.push(native.commStepCollect(comm)); }
+      }
+      steps.push(native.commStepCollect(comm));
+      eq(steps, [1, 2, 3, 4, 5]);
+      const up = native.commStepUPad(comm, 0, 5);
+      const uoff = new Int32Array(up + 1), rows = new Int32Array(need), um = new BigUint64Array(need);
+      const mu = native.commStepReadGathered(comm, 0, 0, 5, uoff, rows, um);
+      eq(uoff[U], mu);
+      for(let q = 0; q < 3; q++){
+        native.setDisciplines(single2, masks[q], D);
+        const counts = new Int32Array(U), offsets = new BigInt64Array(U + 1), idx = new Int32Array(n);
+        const m = native.scan(single2, nows[q], cuts[q], counts, offsets, idx);
+        const mine = [];
+        for(let i = 0; i < mu; i++){ if((um[i] >> BigInt(q)) & 1n){ mine.push(rows[i]); } }
+        eq(mine.length, m, 'union query ' + q);
+        eq(Buffer.from(Int32Array.from(mine).buffer).equals(Buffer.from(idx.buffer, 0, m * 4)), true, 'union rows of query ' + q);
+      }
+      native.ctxDestroy(single2);
+      checks += 4;
+    }
     native.commDestroy(comm);
     assert.throws(() => native.commWorld(comm), /communicator/);
-    checks++;
+    // ADVICE r02: a context handle handed out by commCtx must not outlive its communicator as a dangling pointer
+    assert.throws(() => native.scanDevice(shard, nows[0], cuts[0]), e => e.code === -6);
+    assert.throws(() => native.stats(shard), e => e.code === -6);
+    checks += 3;
   }
   // ---- 8. the ordered run behind the store: same feeds as the general path, on a skewed table, after touches and deletes
   {
