@@ -122,10 +122,19 @@ int pie_prune_before(pie_ctx *ctx, int64_t cutoff, int32_t *rows_out, size_t cap
 /* Retention purge with calendar-month arithmetic (server/storage/sqlProvider.js:863-890 _purgeExpiredArchives, :991-1009
  * _isArchiveExpired / _addMonths; ARCHIVE_RETENTION_MONTHS = 2, :10): tombstone every row with
  * now >= addMonths(start, months), where addMonths is JS `setMonth(getMonth() + months)` on a local-time Date (day
- * overflow rolls into the next month) and local time = UTC + tz_offset_ms (a fixed offset of whole minutes; DST is not
- * modelled).  rows_out / n_purged as in pie_delete_user. */
+ * overflow rolls into the next month) and local time = UTC + tz_offset_ms (a fixed offset of whole minutes; zones with
+ * daylight saving: pie_retention_purge_tz).  rows_out / n_purged as in pie_delete_user. */
 int pie_retention_purge(pie_ctx *ctx, int64_t now, int32_t months, int64_t tz_offset_ms, int32_t *rows_out, size_t cap,
                         size_t *n_purged);
+/* The same under a REAL time zone (the reference's Date is local: daylight saving moves the result by the hour the clocks
+ * move).  The zone travels as the transition table the host builds from its own zone rules (sph-pie_amd/host/tzTable.js,
+ * binding.tz_table): offsets_ms[0] applies before transitions_utc_ms[0], offsets_ms[i + 1] from transitions_utc_ms[i] on
+ * (n_transitions + 1 offsets; local = UTC + offset).  The device follows ECMA-262 exactly: offset in force at the UTC instant,
+ * month shift on the local fields, and a resulting local time that is skipped or repeated at a transition is read with the
+ * offset before the transition.  Instants outside the table's span use its first / last offset.  n_transitions = 0 is the
+ * fixed-offset form.  Pinned by tests/golden/addmonths_zones.json (JS engine vectors under seven zones). */
+int pie_retention_purge_tz(pie_ctx *ctx, int64_t now, int32_t months, const int64_t *transitions_utc_ms, const int64_t *offsets_ms,
+                           int32_t n_transitions, int32_t *rows_out, size_t cap, size_t *n_purged);
 
 /* ---- discipline predicate table: replaces findDiscipline() lookups (server/disciplineConfig.js:88-97) -
  * bit d of mask = rows of discipline d are wanted; bits >= n_disc are ignored. n_disc <= 64. */

@@ -50,6 +50,10 @@ def lib():
         l.pie_oracle_archive_queue.argtypes = [P, P, P, C.c_size_t, C.c_int32, C.c_int64, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_add_months.restype = C.c_int64
         l.pie_oracle_add_months.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_int)]
+        l.pie_oracle_add_months_tz.restype = C.c_int64
+        l.pie_oracle_add_months_tz.argtypes = [C.c_int64, C.c_int32, P, P, C.c_int32, C.POINTER(C.c_int)]
+        l.pie_oracle_retention_queue_tz.restype = C.c_int
+        l.pie_oracle_retention_queue_tz.argtypes = [P, P, C.c_size_t, C.c_int64, C.c_int32, P, P, C.c_int32, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_retention_queue.restype = C.c_int
         l.pie_oracle_retention_queue.argtypes = [P, P, C.c_size_t, C.c_int64, C.c_int32, C.c_int64, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.pie_oracle_splitmix64.restype = C.c_uint64
@@ -171,6 +175,61 @@ def add_months(ts, months, tz_offset_ms=0):
     nan = C.c_int(0)
     v = lib().pie_oracle_add_months(int(ts), int(months), int(tz_offset_ms), C.byref(nan))
     return None if nan.value else v
+
+
+def add_months_tz(ts, months, transitions, offsets):
+    """setMonth on a local Date under the zone given as a transition table (see pie_oracle.h).  -> int or None (NaN)"""
+    T, off = np.ascontiguousarray(transitions, np.int64), np.ascontiguousarray(offsets, np.int64)
+    nan = C.c_int(0)
+    v = lib().pie_oracle_add_months_tz(int(ts), int(months), _p(T), _p(off), int(T.size), C.byref(nan))
+    return None if nan.value else v
+
+
+def retention_queue_tz(start, end, now, months, transitions, offsets):
+    start, end = np.ascontiguousarray(start, np.int64), np.ascontiguousarray(end, np.int64)
+    T, off = np.ascontiguousarray(transitions, np.int64), np.ascontiguousarray(offsets, np.int64)
+    n = start.shape[0]
+    q = np.empty(max(n, 1), np.int32)
+    k = C.c_size_t(0)
+    rc = lib().pie_oracle_retention_queue_tz(_p(start), _p(end), n, int(now), int(months), _p(T), _p(off), int(T.size), _p(q), n, C.byref(k))
+    if rc != 0:
+        raise RuntimeError("pie_oracle_retention_queue_tz rc=%d" % rc)
+    return q[: k.value].copy()
+
+
+def tz_table(zone, from_ms=0, to_ms=4102444800000):
+    """The transition table of `zone` from Python's zoneinfo (a different engine and data set from the JS one that produced the
+    golden tables): (transitions[n], offsets[n + 1]) in ms, probed day by day and bisected to the millisecond."""
+    import datetime
+    import zoneinfo
+    z = zoneinfo.ZoneInfo(zone)
+    epoch = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc)
+
+    def off(ms):
+        d = (epoch + datetime.timedelta(milliseconds=int(ms))).astimezone(z)
+        return int(d.utcoffset() / datetime.timedelta(milliseconds=1))
+
+    day = 86400000
+    T, O = [], [off(from_ms)]
+    prev_t, prev_o = from_ms, O[0]
+    t = from_ms + day
+    while prev_t < to_ms:
+        at = min(t, to_ms)
+        o = off(at)
+        if o != prev_o:
+            lo, hi = prev_t, at
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if off(mid) == prev_o:
+                    lo = mid
+                else:
+                    hi = mid
+            T.append(hi)
+            O.append(o)
+            prev_o = o
+        prev_t = at
+        t += day
+    return np.array(T, np.int64), np.array(O, np.int64)
 
 
 def calendar_cutoff(now_ms, months_back=2, tz="UTC"):

@@ -413,6 +413,67 @@ int64_t pie_oracle_add_months(int64_t ts, int32_t months, int64_t tz_offset_ms, 
     return (int64_t)out;
 }
 
+/* The same under a REAL time zone, given as the transition table the host builds from the engine's zone rules
+ * (sph-pie_amd/host/tzTable.js): off[0] applies before T[0], off[i + 1] from T[i] on.  ECMAScript semantics of
+ * `d.setMonth(d.getMonth() + months)` (ECMA-262 Date.prototype.setMonth, LocalTime / UTC abstract operations):
+ *   t      = LocalTime(ts)          = ts + offset in force at the UTC instant ts
+ *   t2     = MakeDate(MakeDay(Year(t), Month(t) + months, Date(t)), TimeWithinDay(t))     (day overflow rolls over)
+ *   result = TimeClip(UTC(t2)),  UTC(t2) = t2 - offset for the LOCAL time t2, where a local time that is skipped (clocks put
+ *            forward) or repeated (clocks put back) "must be interpreted using the time zone offset before the transition".
+ * Pinned by tests/golden/addmonths_zones.json (vectors from the JS engine's own Date under seven zones). */
+static int64_t tz_offset_at_utc(const int64_t *T, const int64_t *off, int32_t n, int64_t t)
+{
+    int32_t k = 0;
+    while (k < n && T[k] <= t) ++k; /* an oracle: linear */
+    return off[k];
+}
+
+static int64_t tz_utc_from_local(const int64_t *T, const int64_t *off, int32_t n, int64_t tl)
+{
+    /* transition i happens, read on the OLD offset's clock, at local time T[i] + off[i] */
+    int32_t k = 0;
+    while (k < n && T[k] + off[k] <= tl) ++k;
+    int64_t u = tl - off[k];
+    if (k >= 1 && u < T[k - 1]) u = tl - off[k - 1]; /* skipped local time (clocks put forward): the offset before the transition */
+    return u;
+}
+
+int64_t pie_oracle_add_months_tz(int64_t ts, int32_t months, const int64_t *T, const int64_t *off, int32_t n, int *is_nan)
+{
+    if (is_nan) *is_nan = 0;
+    if (ts > JS_DATE_MAX || ts < -JS_DATE_MAX) return ts;
+    const __int128 local = (__int128)ts + tz_offset_at_utc(T, off, n, ts);
+    int64_t secs = (int64_t)(local / 1000), ms = (int64_t)(local % 1000);
+    if (ms < 0) { ms += 1000; secs -= 1; }
+    time_t t = (time_t)secs;
+    struct tm tm;
+    if (!gmtime_r(&t, &tm)) { if (is_nan) *is_nan = 1; return 0; }
+    tm.tm_mon += months;
+    const time_t t2 = timegm(&tm);
+    const __int128 out_local = (__int128)t2 * 1000 + ms;
+    if (out_local > 2 * (__int128)JS_DATE_MAX || out_local < -2 * (__int128)JS_DATE_MAX) { if (is_nan) *is_nan = 1; return 0; }
+    const int64_t out = tz_utc_from_local(T, off, n, (int64_t)out_local);
+    if (out > JS_DATE_MAX || out < -JS_DATE_MAX) { if (is_nan) *is_nan = 1; return 0; }
+    return out;
+}
+
+int pie_oracle_retention_queue_tz(const int64_t *start, const int64_t *end, size_t n_rows, int64_t now, int32_t months,
+                                  const int64_t *T, const int64_t *off, int32_t n, int32_t *queue, size_t cap, size_t *q_out)
+{
+    size_t q = 0;
+    for (size_t i = 0; i < n_rows; ++i) {
+        if (end[i] == INT64_MIN) continue;
+        int nan = 0;
+        const int64_t expiry = pie_oracle_add_months_tz(start[i], months, T, off, n, &nan);
+        if (!nan && now >= expiry) {
+            if (q < cap) queue[q] = (int32_t)i;
+            ++q;
+        }
+    }
+    if (q_out) *q_out = q;
+    return q > cap ? -1 : 0;
+}
+
 int pie_oracle_retention_queue(const int64_t *start, const int64_t *end, size_t n, int64_t now, int32_t months,
                                int64_t tz_offset_ms, int32_t *queue, size_t cap, size_t *q_out)
 {

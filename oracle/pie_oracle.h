@@ -85,6 +85,12 @@ int pie_oracle_archive_queue(const int64_t *start, const int64_t *end, const int
  * This restatement goes through libc (gmtime_r / timegm) — a different route from the product's integer civil-date
  * arithmetic — and is pinned by tests/golden/addmonths_utc.json (vectors from the JS engine's own Date). */
 int64_t pie_oracle_add_months(int64_t ts, int32_t months, int64_t tz_offset_ms, int *is_nan);
+/* the same under a real time zone given as a transition table (off[0] before T[0], off[i + 1] from T[i] on; ms): ECMA-262
+ * setMonth on a local Date, skipped / repeated local times read with the offset before the transition; pinned by
+ * tests/golden/addmonths_zones.json */
+int64_t pie_oracle_add_months_tz(int64_t ts, int32_t months, const int64_t *T, const int64_t *off, int32_t n, int *is_nan);
+int pie_oracle_retention_queue_tz(const int64_t *start, const int64_t *end, size_t n_rows, int64_t now, int32_t months,
+                                  const int64_t *T, const int64_t *off, int32_t n, int32_t *queue, size_t cap, size_t *q_out);
 /* rows (not tombstoned) with now >= addMonths(start, months), ascending row order (:863-890 _purgeExpiredArchives) */
 int pie_oracle_retention_queue(const int64_t *start, const int64_t *end, size_t n, int64_t now, int32_t months,
                                int64_t tz_offset_ms, int32_t *queue, size_t cap, size_t *q_out);

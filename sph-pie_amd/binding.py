@@ -70,6 +70,7 @@ _SIGS = [
     ("pie_delete_user", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_prune_before", C.c_int, [_P, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_retention_purge", C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_retention_purge_tz", C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_append_rows", C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int32]),
     ("pie_set_disciplines", C.c_int, [_P, C.c_uint64, C.c_int32]),
     ("pie_scan", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -263,11 +264,19 @@ class PieScan:
         self._check(self._lib.pie_prune_before(self._ctx, int(cutoff), _ptr(rows), self.n, C.byref(k)))
         return rows[: k.value].copy()
 
-    def retention_purge(self, now, months=2, tz_offset_ms=0):
-        """Tombstone rows with now >= addMonths(start, months) (JS calendar-month arithmetic); -> their ascending indices."""
+    def retention_purge(self, now, months=2, tz_offset_ms=0, tz_table=None):
+        """Tombstone rows with now >= addMonths(start, months) (JS calendar-month arithmetic on a LOCAL date); -> their ascending
+        indices.  tz_table = (transitions_utc_ms, offsets_ms) for a zone with daylight saving (binding.tz_table(zone)); else the
+        fixed offset tz_offset_ms."""
         k = C.c_size_t(0)
         rows = np.empty(max(self.n, 1), np.int32)
-        self._check(self._lib.pie_retention_purge(self._ctx, int(now), int(months), int(tz_offset_ms), _ptr(rows), self.n, C.byref(k)))
+        if tz_table is not None:
+            T, off = np.ascontiguousarray(tz_table[0], np.int64), np.ascontiguousarray(tz_table[1], np.int64)
+            if off.shape[0] != T.shape[0] + 1:
+                raise ValueError("a table of n transitions carries n + 1 offsets")
+            self._check(self._lib.pie_retention_purge_tz(self._ctx, int(now), int(months), _ptr(T), _ptr(off), int(T.shape[0]), _ptr(rows), self.n, C.byref(k)))
+        else:
+            self._check(self._lib.pie_retention_purge(self._ctx, int(now), int(months), int(tz_offset_ms), _ptr(rows), self.n, C.byref(k)))
         return rows[: k.value].copy()
 
     def set_disciplines(self, mask, n_disc):
@@ -721,3 +730,38 @@ class PieComm:
 
 def shard_of(user, n_shards):
     return load_library().pie_shard_of(int(user), int(n_shards))
+
+
+def tz_table(zone, from_ms=0, to_ms=4102444800000):
+    """Transition table of an IANA zone for retention_purge(tz_table=...): (transitions_utc_ms[n], offsets_ms[n + 1]), from
+    Python's zoneinfo, probed day by day and bisected to the millisecond (the Node host builds the same table from the JS
+    engine: host/tzTable.js)."""
+    import datetime
+    import zoneinfo
+    z = zoneinfo.ZoneInfo(zone)
+    epoch = datetime.datetime(1970, 1, 1, tzinfo=datetime.timezone.utc)
+    ms1 = datetime.timedelta(milliseconds=1)
+
+    def off(ms):
+        return int((epoch + datetime.timedelta(milliseconds=int(ms))).astimezone(z).utcoffset() / ms1)
+
+    day = 86400000
+    trans, offs = [], [off(from_ms)]
+    prev_t, prev_o, t = from_ms, offs[0], from_ms + day
+    while prev_t < to_ms:
+        at = min(t, to_ms)
+        o = off(at)
+        if o != prev_o:
+            lo, hi = prev_t, at
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if off(mid) == prev_o:
+                    lo = mid
+                else:
+                    hi = mid
+            trans.append(hi)
+            offs.append(o)
+            prev_o = o
+        prev_t = at
+        t += day
+    return np.array(trans, np.int64), np.array(offs, np.int64)

@@ -3228,12 +3228,71 @@ __global__ __launch_bounds__(256) void k_validate_users(const int* __restrict__ 
 // NaN (ok = false), for which `now >= expiry` is false.
 __device__ __forceinline__ long long floor_div(long long a, long long b) { const long long q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
+// A zone as the host's transition table in device memory (pie_retention_purge_tz): words [0] = n, [1] = months, then T[n] (UTC
+// instants of the transitions), L[n] (the same instants on the OLD offset's local clock: T[i] + off[i]), off[n + 1]
+// (off[0] before T[0], off[i + 1] from T[i] on).  ECMA-262 LocalTime / UTC: a local time that is skipped or repeated at a
+// transition is read with the offset before the transition.
+struct TzView {
+    const long long* T;
+    const long long* L;
+    const long long* off;
+    int n;
+};
+__device__ __forceinline__ TzView tz_view(const long long* p)
+{
+    TzView z;
+    z.n = (int)p[0];
+    z.T = p + 2;
+    z.L = z.T + z.n;
+    z.off = z.L + z.n;
+    return z;
+}
+// entries of an ascending table that are <= x
+__device__ __forceinline__ int tz_rank(const long long* tab, int n, long long x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tab[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ long long tz_utc_from_local(const TzView& z, long long tl)
+{
+    const int k = tz_rank(z.L, z.n, tl);
+    long long u = tl - z.off[k];
+    if (k >= 1 && u < z.T[k - 1]) u = tl - z.off[k - 1]; // skipped local time: the offset before the transition
+    return u;
+}
+
+// the month shift on the LOCAL fields: local -> local (JS MakeDay normalisation: day overflow rolls into the next month)
+__device__ __forceinline__ long long shift_months_local(long long local, int months);
+
 __device__ __forceinline__ long long add_months_ms(long long ts, int months, long long tz_ms, bool& ok)
 {
-    constexpr long long kMax = 8640000000000000LL, kDay = 86400000LL;
+    constexpr long long kMax = 8640000000000000LL;
     ok = true;
     if (ts > kMax || ts < -kMax) return ts;
-    const long long local = ts + tz_ms; // |ts| <= 8.64e15, |tz| <= a day: no overflow
+    const long long out = shift_months_local(ts + tz_ms, months) - tz_ms; // |ts| <= 8.64e15, |tz| <= a day: no overflow
+    if (out > kMax || out < -kMax) ok = false;
+    return out;
+}
+
+__device__ __forceinline__ long long add_months_tz(long long ts, int months, const TzView& z, bool& ok)
+{
+    constexpr long long kMax = 8640000000000000LL;
+    ok = true;
+    if (ts > kMax || ts < -kMax) return ts;
+    const long long local = ts + z.off[tz_rank(z.T, z.n, ts)];
+    const long long out = tz_utc_from_local(z, shift_months_local(local, months));
+    if (out > kMax || out < -kMax) ok = false;
+    return out;
+}
+
+__device__ __forceinline__ long long shift_months_local(long long local, int months)
+{
+    constexpr long long kDay = 86400000LL;
     const long long days = floor_div(local, kDay);
     const long long ms_of_day = local - days * kDay;
     // civil_from_days (proleptic Gregorian; day 0 = 1970-01-01)
@@ -3257,10 +3316,7 @@ __device__ __forceinline__ long long add_months_ms(long long ts, int months, lon
     const long long doy2 = (153 * (m2 > 2 ? m2 - 3 : m2 + 9) + 2) / 5;        // day of (March-based) year of the 1st
     const long long doe2 = yoe2 * 365 + yoe2 / 4 - yoe2 / 100 + doy2;
     const long long days2 = era2 * 146097 + doe2 - 719468 + (d - 1);
-    const long long out_local = days2 * kDay + ms_of_day;                     // < ~9e15 * small: fits
-    const long long out = out_local - tz_ms;
-    if (out > kMax || out < -kMax) ok = false;
-    return out;
+    return days2 * kDay + ms_of_day;                                          // < ~9e15 * small: fits
 }
 
 template <int MODE>
@@ -3278,9 +3334,14 @@ __device__ __forceinline__ bool list_match(const long long* __restrict__ end, co
         // MODE 3  retention purge (/root/reference/server/storage/sqlProvider.js:863-890,991-997): now >= addMonths(start,
         //         months); `a` = now, `b` packs months (low 16 bits, signed) and the zone offset in minutes (above)
         if (end[r] == INT64_MIN) return false;
+        bool ok;
+        if constexpr (MODE == 4) { // ... under a real time zone: `b` = device address of the zone's transition table (TzView)
+            const long long* tab = reinterpret_cast<const long long*>(b);
+            const long long expiry = add_months_tz(reinterpret_cast<const long long*>(user)[r], (int)tab[1], tz_view(tab), ok);
+            return ok && a >= expiry;
+        }
         const int months = (int)(short)(b & 0xFFFF);
         const long long tz_ms = (b >> 16) * 60000LL;
-        bool ok;
         const long long expiry = add_months_ms(reinterpret_cast<const long long*>(user)[r], months, tz_ms, ok);
         return ok && a >= expiry;
     }

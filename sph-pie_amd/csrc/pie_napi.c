@@ -36,6 +36,7 @@
     X(int, pie_read_columns, (pie_ctx *, int64_t *, int64_t *, int32_t *, int32_t *, size_t))                       \
     X(int, pie_set_end, (pie_ctx *, const int32_t *, const int64_t *, size_t))                                      \
     X(int, pie_delete_user, (pie_ctx *, int32_t, int32_t *, size_t, size_t *))                                      \
+    X(int, pie_retention_purge_tz, (pie_ctx *, int64_t, int32_t, const int64_t *, const int64_t *, int32_t, int32_t *, size_t, size_t *)) \
     X(int, pie_set_disciplines, (pie_ctx *, uint64_t, int32_t))                                                     \
     X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
     X(int, pie_fetch_rows, (pie_ctx *, const int32_t *, size_t, int64_t *, int64_t *, int32_t *, int32_t *))        \
@@ -424,6 +425,30 @@ static napi_value fn_delete_user(napi_env env, napi_callback_info info)
         return NULL;
     }
     int rc = p_pie_delete_user(ctx, user, rows, cap, &k);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)k);
+}
+
+/* retentionPurgeTz(ctx, now, months, transitions BigInt64Array[n], offsets BigInt64Array[n + 1], rowsOut Int32Array) -> rows
+ * tombstoned (rowsOut holds them, ascending): now >= addMonths(start, months) with `setMonth` on a LOCAL Date under the zone the
+ * table describes (host/tzTable.js builds it from this process's zone rules); sqlProvider.js:863-890,991-1009 */
+static napi_value fn_retention_purge_tz(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int64_t now = 0;
+    int32_t months = 0;
+    size_t nt = 0, no = 0, cap = 0, k = 0;
+    CHECK(env, napi_get_value_int64(env, argv[1], &now));
+    CHECK(env, napi_get_value_int32(env, argv[2], &months));
+    int64_t *tr = typed(env, argv[3], napi_bigint64_array, &nt), *off = typed(env, argv[4], napi_bigint64_array, &no);
+    int32_t *rows = typed(env, argv[5], napi_int32_array, &cap);
+    if (!tr || !off || !rows || no != nt + 1) {
+        napi_throw_type_error(env, NULL, "retentionPurgeTz(ctx, now, months, BigInt64Array transitions[n], BigInt64Array offsets[n + 1], Int32Array rowsOut)");
+        return NULL;
+    }
+    int rc = p_pie_retention_purge_tz(ctx, now, months, tr, off, (int32_t)nt, rows, cap, &k);
     if (rc) return throw_pie(env, ctx, rc);
     return js_int(env, (int64_t)k);
 }
@@ -1494,7 +1519,7 @@ static napi_value init(napi_env env, napi_value exports)
     } table[] = {
         {"open", fn_open}, {"deviceCount", fn_device_count}, {"ctxCreate", fn_ctx_create}, {"ctxDestroy", fn_ctx_destroy},
         {"loadColumns", fn_load_columns}, {"appendRows", fn_append_rows}, {"genSynthetic", fn_gen},
-        {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user},
+        {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user}, {"retentionPurgeTz", fn_retention_purge_tz},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
         {"setOrderedRun", fn_set_ordered_run},

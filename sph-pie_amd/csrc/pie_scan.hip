@@ -1896,7 +1896,7 @@ int run_row_list(pie_ctx* c, long long a, long long b, int32_t* out, size_t cap,
     const int blocks = c->plan_blocks[0];
     const long long rpb = c->plan_rows[0];
     // MODE 2 matches on the start column: it travels through the kernels' generic second-column pointer
-    const int* col2 = (MODE == 2 || MODE == 3) ? reinterpret_cast<const int*>(c->d_start) : c->d_user;
+    const int* col2 = (MODE == 2 || MODE == 3 || MODE == 4) ? reinterpret_cast<const int*>(c->d_start) : c->d_user;
     hipLaunchKernelGGL(k_list_count<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b, sl.blk_count);
     hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
     hipLaunchKernelGGL(k_list_write<MODE>, dim3(blocks), dim3(256), 0, s, c->d_end, col2, c->n, rpb, a, b,
@@ -2982,6 +2982,42 @@ int pie_retention_purge(pie_ctx* c, int64_t now, int32_t months, int64_t tz_offs
     if (c->n == 0) return PIE_OK;
     const long long packed = ((tz_offset_ms / 60000) << 16) | (long long)((unsigned)months & 0xFFFFu);
     return run_row_list<3>(c, (long long)now, packed, rows_out, cap, n_purged);
+}
+
+int pie_retention_purge_tz(pie_ctx* c, int64_t now, int32_t months, const int64_t* transitions_utc_ms, const int64_t* offsets_ms,
+                           int32_t n_transitions, int32_t* rows_out, size_t cap, size_t* n_purged)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_purged) *n_purged = 0;
+    if (months < -32768 || months > 32767) return fail(c, PIE_E_INVAL, "months outside int16");
+    if (n_transitions < 0 || n_transitions > 65536 || !offsets_ms || (n_transitions > 0 && !transitions_utc_ms))
+        return fail(c, PIE_E_INVAL, "bad transition table");
+    const int n = n_transitions;
+    for (int i = 0; i <= n; ++i)
+        if (offsets_ms[i] > 2 * 86400000LL || offsets_ms[i] < -2 * 86400000LL) return fail(c, PIE_E_INVAL, "offset %d outside two days", i);
+    // transitions ascending, and ascending on the old offset's local clock too (what the local -> UTC search relies on)
+    for (int i = 1; i < n; ++i)
+        if (transitions_utc_ms[i] <= transitions_utc_ms[i - 1] || transitions_utc_ms[i] + offsets_ms[i] <= transitions_utc_ms[i - 1] + offsets_ms[i - 1])
+            return fail(c, PIE_E_INVAL, "transitions must ascend (entry %d)", i);
+    if (c->n == 0) return PIE_OK;
+    PIE_HIP(c, hipSetDevice(c->device));
+    // the table on the device: [n, months, T[n], L[n], off[n + 1]] through the context's staging block
+    const size_t words = 2 + (size_t)n * 2 + (size_t)n + 1;
+    if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "a scan is in flight");
+    int rc = sync_all(c); // the staging block is shared with appends / touches
+    if (rc) return rc;
+    rc = ensure_stage(c, words * 8);
+    if (rc) return rc;
+    long long* h = reinterpret_cast<long long*>(c->h_stage);
+    h[0] = n;
+    h[1] = months;
+    for (int i = 0; i < n; ++i) {
+        h[2 + i] = transitions_utc_ms[i];
+        h[2 + n + i] = transitions_utc_ms[i] + offsets_ms[i];
+    }
+    for (int i = 0; i <= n; ++i) h[2 + 2 * n + i] = offsets_ms[i];
+    PIE_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, words * 8, hipMemcpyHostToDevice, c->stream));
+    return run_row_list<4>(c, (long long)now, (long long)(uintptr_t)c->d_stage, rows_out, cap, n_purged);
 }
 
 int pie_set_disciplines(pie_ctx* c, uint64_t mask, int32_t n_disc)

@@ -243,6 +243,24 @@ function createStore(options){
     return undefined;
   }
 
+  // Retention purge with calendar-month arithmetic (SURVEY 8f-2; /root/reference/server/storage/sqlProvider.js:863-890, :991-1009:
+  // a record goes once now >= addMonths(createdAt, months), addMonths = `setMonth(getMonth() + months)` on a LOCAL Date).
+  // The device does the month arithmetic for every row under this process's time zone, handed over as a transition table
+  // (tzTable.js: built from the engine's own zone rules, so daylight saving moves the result exactly as it does for the
+  // reference's Date).  -> number of sessions dropped
+  function purgeRetention(months, now){
+    const tz = require('./tzTable').defaultTzTable();
+    flush();
+    const list = rowList();
+    const k = native.retentionPurgeTz(ctx, now === undefined ? Date.now() : now, months === undefined ? 2 : months, tz.transitions, tz.offsets, list);
+    generation++;
+    for(let i = 0; i < k; i++){
+      forget(list[i]);
+      retire(list[i]);
+    }
+    return k;
+  }
+
   // ---- the batched feed scan (replaces the per-request loop) ------------------------------------------
   // -> {counts Int32Array[U], offsets BigInt64Array[U+1], idx Int32Array[M], m, userIds}
   function scanFeeds(query){
@@ -372,7 +390,7 @@ function createStore(options){
   }
 
   return {
-    createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions,
+    createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions, purgeRetention,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
     scanFeeds, scanDevice, userFeed, scanBatchDevice, batchUserFeed, BATCH_MAX, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
     compact, compactions: () => compactions, tableRows: () => rows.length,

@@ -693,6 +693,64 @@ def test_retention_purge_calendar_months(gpu_ctx, oracle):
             assert np.array_equal(gpu_ctx.retention_purge(now, 2, tz), oracle.retention_queue(s, e, now, 2, tz))
 
 
+def test_retention_purge_under_real_time_zones(pie, gpu_ctx, oracle):
+    """`setMonth` on a LOCAL Date under daylight saving.  pie_retention_purge_tz with the transition table
+    the JS host built (tests/golden/addmonths_zones.json carries it beside the vectors): (1) every JS-engine vector of every
+    zone, the boundary probed to the millisecond — now = expiry purges, one millisecond earlier does not — all rows of a zone
+    in ONE table per probe; (2) whole lists against the oracle's table-driven restatement; (3) a table without transitions is
+    the fixed-offset entry point; (4) a table from Python's zoneinfo gives the same answers; malformed tables are refused."""
+    g = json.load(open(os.path.join(GOLDEN, "addmonths_zones.json")))
+    n_checked = 0
+    for zone, z in g["zones"].items():
+        T, off = np.array(z["transitions"], np.int64), np.array(z["offsets"], np.int64)
+        by_m = {}
+        for ts, m, want in z["cases"]:
+            if want is not None:
+                by_m.setdefault(m, []).append((ts, want))
+        for m, lst in by_m.items():
+            ts = np.array([t for t, _ in lst], np.int64)
+            want = np.array([w for _, w in lst], np.int64)
+            e = np.full(ts.size, 2 ** 62, np.int64)
+            zc = np.zeros(ts.size, np.int32)
+            # rows sorted by expiry: at now = want[k] exactly the rows with expiry <= want[k] go, at want[k] - 1 those below it
+            order = np.argsort(want, kind="stable")
+            ts, want = ts[order], want[order]
+            for k in sorted(set([0, ts.size // 3, ts.size // 2, ts.size - 1])):
+                for probe in (0, -1):
+                    gpu_ctx.load_columns(ts, e, zc, zc, 1)
+                    got = gpu_ctx.retention_purge(int(want[k]) + probe, m, tz_table=(T, off))
+                    assert np.array_equal(got, np.nonzero(want <= int(want[k]) + probe)[0].astype(np.int32)), (zone, m, k, probe)
+            gpu_ctx.load_columns(ts, e, zc, zc, 1)
+            now = int(np.median(want))
+            assert np.array_equal(gpu_ctx.retention_purge(now, m, tz_table=(T, off)), oracle.retention_queue_tz(ts, e, now, m, T, off)), (zone, m)
+            n_checked += ts.size
+        if T.size == 0:   # no transitions: the fixed-offset entry point gives the same rows
+            ts = np.array([c[0] for c in z["cases"]], np.int64)
+            e = np.full(ts.size, 2 ** 62, np.int64)
+            zc = np.zeros(ts.size, np.int32)
+            now = int(np.median(ts))
+            gpu_ctx.load_columns(ts, e, zc, zc, 1)
+            a = gpu_ctx.retention_purge(now, 2, tz_table=(T, off))
+            gpu_ctx.load_columns(ts, e, zc, zc, 1)
+            assert np.array_equal(a, gpu_ctx.retention_purge(now, 2, int(off[0])))
+    assert n_checked > 10000
+    # the synthetic corpus under New York and Lord Howe (30-minute DST), zoneinfo's table, against the oracle with the JS table
+    n, U = 300000, 50
+    s, e, u, d = oracle.gen(SEED, n, 0, n, U, 3, 1)
+    e[::9] = INT64_MIN
+    for zone in ("America/New_York", "Australia/Lord_Howe"):
+        z = g["zones"][zone]
+        py_table = pie.tz_table(zone, 631152000000, 2145916800000)
+        for now in (oracle.T0_MS, oracle.T0_MS - 30 * DAY, oracle.T0_MS - 58 * DAY):
+            gpu_ctx.load_columns(s, e, u, d, U)
+            assert np.array_equal(gpu_ctx.retention_purge(now, 2, tz_table=py_table), oracle.retention_queue_tz(s, e, now, 2, z["transitions"], z["offsets"]))
+    gpu_ctx.load_columns(s, e, u, d, U)
+    with pytest.raises(pie.PieError):   # transitions out of order
+        gpu_ctx.retention_purge(oracle.T0_MS, 2, tz_table=(np.array([5, 3], np.int64), np.array([0, 3600000, 0], np.int64)))
+    with pytest.raises(ValueError):
+        gpu_ctx.retention_purge(oracle.T0_MS, 2, tz_table=(np.array([5], np.int64), np.array([0], np.int64)))
+
+
 def test_column_files_round_trip(pie, gpu_ctx, oracle, tmp_path):
     """Flat column files: save, load into a fresh context, same table and same feeds; bad directories fail loudly."""
     n, U = 123457, 321

@@ -71,3 +71,18 @@ def test_node_host_on_gpu(pie):
     assert pie.build_napi() is not None
     out = run_node("gpu_test.js", 300)
     assert "host gpu_test ok" in out
+
+
+@needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("zone", ["America/New_York", "Australia/Lord_Howe", "America/Havana", "UTC"])
+def test_retention_purge_through_the_node_host_in_a_dst_zone(pie, zone):
+    """f2 through the Node host under a real time zone: store.purgeRetention (device month arithmetic under the table
+    host/tzTable.js builds from the engine's zone rules) drops exactly the sessions the JS engine's own Date arithmetic — the
+    reference's, sqlProvider.js:991-1009 — says, incl. sessions whose shifted instant lands on a clock change."""
+    assert pie.build_napi() is not None
+    env = dict(os.environ, TZ=zone)
+    res = subprocess.run([node, os.path.join(HOST, "test", "gpu_tz_test.js")], cwd=REPO, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout
+    assert "host gpu_tz_test ok" in res.stdout

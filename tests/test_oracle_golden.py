@@ -247,3 +247,34 @@ def test_multithread_oracle_equals_single_thread(oracle):
             got = oracle.scan_mt(*cols, U, now, cutoff, mask & 0xFFFFFFFF, threads)
             for x, y in zip(got, want):
                 assert np.array_equal(x, y)
+
+
+def test_add_months_under_real_time_zones(oracle):
+    """f2 under daylight saving: the oracle's restatement of `setMonth` on a LOCAL Date — offset at the UTC
+    instant, civil month shift, skipped / repeated local times read with the offset before the transition — against the JS
+    engine's own Date under seven zones (tests/golden/addmonths_zones.json, oracle/gen_addmonths_zones_golden.js), computed
+    with the transition table the product's host built in the same JS process."""
+    g = json.load(open(os.path.join(GOLDEN, "addmonths_zones.json")))
+    n = 0
+    for zone, z in g["zones"].items():
+        T, off = z["transitions"], z["offsets"]
+        assert len(off) == len(T) + 1
+        for ts, m, want in z["cases"]:
+            assert oracle.add_months_tz(ts, m, T, off) == want, (zone, ts, m)
+            n += 1
+        if not T:   # a zone without transitions is the fixed-offset form
+            for ts, m, want in z["cases"][:50]:
+                assert oracle.add_months(ts, m, off[0]) == want
+    assert n > 10000
+
+
+def test_zoneinfo_table_agrees_with_the_js_table(oracle):
+    """The same table from a different engine and data set (Python zoneinfo): every transition the JS host found between 1990 and
+    2037 is there, to the millisecond, with the same offsets — the table format and the probing are not an artefact of one engine."""
+    g = json.load(open(os.path.join(GOLDEN, "addmonths_zones.json")))
+    lo, hi = 631152000000, 2145916800000
+    for zone in ("America/New_York", "Europe/Berlin", "Australia/Lord_Howe", "Asia/Kolkata"):
+        T, off = oracle.tz_table(zone, lo, hi)
+        z = g["zones"][zone]
+        js = [(t, o) for t, o in zip(z["transitions"], z["offsets"][1:]) if lo < t <= hi]
+        assert js == list(zip(T.tolist(), off[1:].tolist())), zone
