@@ -219,11 +219,12 @@ def main():
     ap.add_argument("--mixed-rows", type=int, default=1000, help="--mode mixed: sessions created and sessions touched per step")
     ap.add_argument("--mixed-clock", choices=["query", "end"], default="query",
                     help="--mode mixed: sessions are created at the query's clock (default) or after the corpus's last createdAt")
-    ap.add_argument("--mode", choices=["scan", "expired", "mixed"], default="scan",
+    ap.add_argument("--mode", choices=["scan", "expired", "mixed", "archive"], default="scan",
                     help="scan: the headline feed scan; expired: the 'next' row of SURVEY.md 8f-1 — newly-expired change "
                          "predicate -> ordered dispatch queue (reads only the end column: 8 B/row algorithmic); mixed: every step "
                          "creates --mixed-rows sessions (append) and touches as many (set_end) before its scan: the upkeep of the "
-                         "derived key columns inside the timed region")
+                         "derived key columns inside the timed region; archive: the reference's archive chain (sqlProvider.js:758-816: "
+                         "group min -> threshold -> whole groups in first-appearance order) as one device chain per step")
     ap.add_argument("--queries-per-launch", type=int, default=64,
                     help="every step is ONE batched scan of Q queries (Q feed requests, each with its own `now`, answered by one table "
                          "pass: pie_scan_batch_*); value counts Q x U feeds per step; 1 = one query per step (single_query reports that "
@@ -311,6 +312,9 @@ def main():
     feeds = ShardedFeeds(backend, rank, world, u_local, always_collective=gather, batch=args.gather_batch, transport=transport) if gather else None
 
     expired_window = (T0_MS - 30 * DAY, T0_MS - 29 * DAY)   # one day of expiries: ~0.83 % of the rows queue up
+    # the archive chain: a group (user) qualifies iff its earliest session is at least an hour older than `now`; with `now` two
+    # hours into the corpus ~29 % of the groups (those with a session in the corpus's first hour) and of the rows are queued
+    archive_query = (T0_MS - 120 * DAY + 2 * 3600 * 1000, 3600 * 1000)
     Q = max(1, min(args.queries_per_launch, pie.PIE_BATCH_MAX))
     # the batch: Q requests that arrived within a few seconds of each other — each samples its own clock (sessionStore.js:67),
     # same day's cutoff, same role mask; query 0 is the single-query workload
@@ -343,6 +347,10 @@ def main():
         if args.mode == "expired":
             for _ in range(k):
                 last = ctx.expired_queue(expired_window[0], expired_window[1], fetch=False)
+            return last
+        if args.mode == "archive":
+            for _ in range(k):
+                last = ctx.archive_queue(archive_query[0], archive_query[1], fetch=False)
             return last
         if args.mode == "mixed":
             # a live server between two feed scans: logins (createSession -> append) and touches (touchSession -> set_end),
@@ -416,10 +424,11 @@ def main():
     # HIP events around the scan kernels, on the stream they are launched on; every 16th step (at least three per region)
     # carries them (an event between two kernels drains the pipeline for a few microseconds)
     profile_every = args.profile_every if args.profile_every > 0 else max(1, min(16, args.steps // 3))
-    ctx.set_profiling(1 if args.mode == "expired" else profile_every)
+    ctx.set_profiling(1 if args.mode in ("expired", "archive") else profile_every)
     region_ms, kernel_ms_regions, scan_ms_regions, n_prof = [], [], [], 0
     last = None
     mixed_regions = []
+    arch_acc = [0.0, 0, 0]
     for _ in range(max(args.repeat, 1)):
         mixed_state.update({"append_s": 0.0, "touch_s": 0.0, "scan_s": 0.0, "n": 0})
         dt, last = timed_region(run_steps, args.steps)
@@ -431,7 +440,13 @@ def main():
             kernel_ms_regions.append(st["k1_ms_sum"] / st["n_profiled"])
             scan_ms_regions.append(st["scan_ms_sum"] / st["n_profiled"])
             n_prof += st["n_profiled"]
+        if args.mode == "archive":
+            a = ctx.archive_stats()
+            arch_acc[0] += a[0]
+            arch_acc[1] += a[1]
+            arch_acc[2] = a[2]
         ctx.stats_reset()
+    arch_stats = tuple(arch_acc)
     ctx.set_profiling(0)
     st = ctx.stats()
     batch_ms = None
@@ -507,6 +522,26 @@ def main():
         tot_rows, tot_users = int(t[0]), int(t[1])
 
     line = None
+    if rank == 0 and args.mode == "archive":
+        a_ms, a_calls, a_alg = arch_stats
+        chain_ms = a_ms / max(a_calls, 1)
+        line = {
+            "metric": "archive chain (SURVEY 8f-1, sqlProvider.js:758-816): sessions scanned/sec; value counts table rows per chain",
+            "value": tot_rows / (ms_per_step * 1e-3), "unit": "sessions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "timing": {"timed_regions": len(region_ms), "ms_per_step": spread(region_ms)},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "archive chain on %d sessions / %d users: group = user, now = corpus start + 2 h, window 1 h" % (N, U),
+                       "queued_rows": int(last), "queued_fraction": int(last) / max(n_local, 1)},
+            "roofline": {"bound": "hbm", "kernel": "the whole chain: k_group_stats | k_arch_qualify | radix sort (U) | k_arch_rank | k_arch_count | "
+                                                  "k_block_prefix | k_arch_write | radix sort (M)",
+                         "alg_bytes_per_chain": a_alg, "alg_bytes_note": "20 B/row group statistics (start, end, user) + 12 B/row selection (end, user) + 4 B per queued row",
+                         "chain_ms": chain_ms, "chains_timed": a_calls, "achieved": a_alg / (chain_ms * 1e-3) / 1e9 if chain_ms > 0 else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a_alg / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if chain_ms > 0 else None,
+                         "traffic": None},
+        }
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+        ctx.close()
+        return
     if rank == 0:
         variant = st["k1_variant"]
         info = ctx.table_info()   # again: an ordered run, if the scans called for one, was built during the warm-up

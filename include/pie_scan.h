@@ -267,8 +267,13 @@ int pie_expired_queue(pie_ctx *ctx, int64_t prev_now, int64_t now, int32_t *queu
  * session table with the user column as the group key: a group's earliest = min(start) over its (non-tombstoned)
  * rows; it qualifies iff now - earliest >= window_ms (:798, AUTO_ARCHIVE_WINDOW_MS :9); every row of a qualifying
  * group is queued, groups in order of first appearance (Map insertion order), rows in table order inside a group —
- * the order in which :834-861 dispatches them. */
+ * the order in which :834-861 dispatches them.  Entirely on the device: one pass for the group statistics, the threshold and
+ * the first-appearance ranks per group, an order-preserving selection pass, a stable sort of the queued rows by group rank. */
 int pie_archive_queue(pie_ctx *ctx, int64_t now, int64_t window_ms, int32_t *queue_out, size_t cap, size_t *q_out);
+/* Measurement of the archive chain: with pie_set_profiling on, the device time (first kernel start -> end of the last sort) of
+ * the chains since pie_stats_reset and their number; the algorithmic bytes of the last one: 20 B/row for the group statistics
+ * (start, end, user) + 12 B/row for the selection (end, user) + 4 B per queued row. */
+int pie_archive_stats(pie_ctx *ctx, double *ms_sum_out, uint32_t *calls_out, uint64_t *alg_bytes_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------- */
 /* Pin the form of the table pass (the codes of pie_stats.k1_variant, DESIGN.md section 8: 0x01 reads every byte of the

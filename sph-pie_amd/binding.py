@@ -105,6 +105,7 @@ _SIGS = [
     ("pie_fetch_rows", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P, _P]),
     ("pie_expired_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_archive_queue", C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_archive_stats", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("pie_set_profiling", C.c_int, [_P, C.c_int]),
     ("pie_stats_get", C.c_int, [_P, C.POINTER(PieStats)]),
     ("pie_stats_reset", C.c_int, [_P]),
@@ -548,12 +549,22 @@ class PieScan:
         self._check(self._lib.pie_expired_queue(self._ctx, int(prev_now), int(now), _ptr(out), self.n, C.byref(q)))
         return out[: q.value].copy()
 
-    def archive_queue(self, now, window_ms=43200000):
-        """Rows of every group (user) whose earliest start is at least window_ms old, groups in first-appearance order."""
+    def archive_queue(self, now, window_ms=43200000, fetch=True):
+        """Rows of every group (user) whose earliest start is at least window_ms old, groups in first-appearance order.
+        fetch=False: leave the queue on the device, return its length."""
         q = C.c_size_t(0)
+        if not fetch:
+            self._check(self._lib.pie_archive_queue(self._ctx, int(now), int(window_ms), None, 0, C.byref(q)))
+            return q.value
         out = np.empty(max(self.n, 1), np.int32)
         self._check(self._lib.pie_archive_queue(self._ctx, int(now), int(window_ms), _ptr(out), self.n, C.byref(q)))
         return out[: q.value].copy()
+
+    def archive_stats(self):
+        """-> (device ms summed over the profiled archive chains, their number, algorithmic bytes of the last one)"""
+        ms, calls, alg = C.c_double(0), C.c_uint32(0), C.c_uint64(0)
+        self._check(self._lib.pie_archive_stats(self._ctx, C.byref(ms), C.byref(calls), C.byref(alg)))
+        return ms.value, calls.value, alg.value
 
     # ---- sharding on the device
     def shard_table(self, rank, world):

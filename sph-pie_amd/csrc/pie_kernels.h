@@ -3667,40 +3667,150 @@ __global__ __launch_bounds__(256) void k_expired_gather(const int* __restrict__ 
 // the `list.reduce(min)` and the Map insertion order of /root/reference/server/storage/sqlProvider.js:763-794.
 // A row only issues an atomic when it improves the value it reads first (minima only decrease, so a stale read can
 // only cause a redundant atomic, never a missed one): ~ln(group size) atomics per group instead of one per row.
-__global__ __launch_bounds__(256) void k_group_stats(const long long* __restrict__ start, const long long* __restrict__ end,
-                                                     const int* __restrict__ user, long long n, int n_users,
-                                                     long long* __restrict__ min_start, int* __restrict__ first_row)
-{
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
-        if (end[r] == INT64_MIN) continue;
-        const int g = user[r];
-        if ((unsigned)g >= (unsigned)n_users) continue;
-        const long long sv = start[r];
-        if (sv < min_start[g]) atomicMin(&min_start[g], sv);
-        if ((int)r < first_row[g]) atomicMin(&first_row[g], (int)r);
-    }
-}
 
-__global__ __launch_bounds__(256) void k_group_init(long long* __restrict__ min_start, int* __restrict__ first_row, int n_users)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < n_users) {
-        min_start[g] = INT64_MAX;
-        first_row[g] = INT32_MAX;
-    }
-}
 
 // queue = concatenation of the qualifying groups' row lists in first-appearance order: group k (user grp_user[k]) owns
 // queue[grp_off[k] .. grp_off[k+1]); its rows sit, already in row order, at idx[offsets[user] .. +counts[user])
-__global__ __launch_bounds__(256) void k_group_gather(const int* __restrict__ grp_user, const long long* __restrict__ grp_off,
-                                                      int n_groups, const long long* __restrict__ offsets,
-                                                      const int* __restrict__ idx, int* __restrict__ queue, long long cap)
+// ---- the archive chain on the device (pie_archive_queue; /root/reference/server/storage/sqlProvider.js:758-816,834-861).
+// No table pass gathers per-group state from L2 (a first device version kept min(start) and the first row of every group with
+// guarded atomics: two L2 gathers per row, 1.6 ms for the statistics pass alone at cfg3):
+//   * a group qualifies iff now - min(start) >= window  <=>  SOME live row of it has start <= now - window: the flag pass only
+//     touches per-group state for rows that pass that compare (a bit in a bitmap, tested before it is set);
+//   * the selection looks the bitmap up in LDS;
+//   * first-appearance order needs no per-row work at all: after the STABLE sort of the selected (group, row) pairs by group the
+//     head of every group's run is its first row.
+// k_arch_flag: 16-byte loads, two rows per lane; `bits` is the qualifying-groups bitmap (n_users bits, zeroed by the caller)
+__global__ __launch_bounds__(256) void k_arch_flag(const long long* __restrict__ start, const long long* __restrict__ end,
+                                                   const int* __restrict__ user, long long n, int n_users, long long limit, bool none,
+                                                   unsigned int* __restrict__ bits)
 {
-    for (int k = blockIdx.x; k < n_groups; k += gridDim.x) {
-        const long long src = offsets[grp_user[k]], dst = grp_off[k], cnt = grp_off[k + 1] - dst;
-        for (long long i = threadIdx.x; i < cnt; i += 256)
-            if (dst + i < cap) queue[dst + i] = idx[src + i];
+    if (none) return; // now - window below every int64: no start can qualify
+    const long long pairs = n >> 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    auto mark = [&](long long r) {
+        const int g = user[r]; // late: only rows that pass the compare need their group
+        if ((unsigned)g >= (unsigned)n_users) return;
+        const unsigned bit = 1u << (g & 31);
+        if (!(bits[g >> 5] & bit)) atomicOr(&bits[g >> 5], bit); // the test reads through L1 (a stale line only repeats an idempotent OR)
+    };
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const ll2_t e = stream_load<true>(reinterpret_cast<const ll2_t*>(end) + i);
+        const ll2_t sv = stream_load<true>(reinterpret_cast<const ll2_t*>(start) + i);
+        if (e.x != INT64_MIN && sv.x <= limit) mark(2 * i);
+        if (e.y != INT64_MIN && sv.y <= limit) mark(2 * i + 1);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0 && end[n - 1] != INT64_MIN && start[n - 1] <= limit) mark(n - 1);
+}
+__global__ __launch_bounds__(256) void k_arch_popc(const unsigned int* __restrict__ bits, int words, unsigned int* __restrict__ n_qual)
+{
+    __shared__ int s_w[4];
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    int c = i < words ? __popc(bits[i]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_w[0] + s_w[1] + s_w[2] + s_w[3]) atomicAdd(n_qual, (unsigned)(s_w[0] + s_w[1] + s_w[2] + s_w[3]));
+}
+// The selection, order-preserving, twice over (end, user) = 12 B/row: WRITE = false counts per block, true writes (group, row)
+// pairs in table order behind the block's offset.  The bitmap sits in LDS (dynamic: `words` x 4 bytes) when it fits.
+template <bool WRITE, bool LDS_BITS>
+__global__ __launch_bounds__(256) void k_arch_select(const long long* __restrict__ end, const int* __restrict__ user, long long n, long long rows_per_block,
+                                                     const unsigned int* __restrict__ bits, int words, int n_users, int* __restrict__ blk_count,
+                                                     const long long* __restrict__ blk_off, unsigned int* __restrict__ keys, int* __restrict__ rows)
+{
+    extern __shared__ unsigned int l_bits[];
+    __shared__ int wcount[4];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (LDS_BITS) {
+        for (int i = threadIdx.x; i < words; i += 256) l_bits[i] = bits[i];
+    }
+    const long long c0 = (long long)blockIdx.x * rows_per_block; // rows_per_block is even
+    const long long c1 = min(n, c0 + rows_per_block);
+    if (threadIdx.x == 0) carry_s = WRITE ? blk_off[blockIdx.x] : 0;
+    __syncthreads();
+    const unsigned int* bt = LDS_BITS ? l_bits : bits;
+    long long total = 0;
+    for (long long r0 = c0; r0 < c1; r0 += 512) { // 256 threads x 2 rows
+        const long long r = r0 + 2 * threadIdx.x;
+        bool h0 = false, h1 = false;
+        int g0 = 0, g1 = 0;
+        if (r + 1 < c1) {
+            const ll2_t e = stream_load<true>(reinterpret_cast<const ll2_t*>(end + r));
+            const i2_t u = stream_load<true>(reinterpret_cast<const i2_t*>(user + r));
+            g0 = u.x; g1 = u.y;
+            h0 = e.x != INT64_MIN && (unsigned)g0 < (unsigned)n_users && ((bt[g0 >> 5] >> (g0 & 31)) & 1u);
+            h1 = e.y != INT64_MIN && (unsigned)g1 < (unsigned)n_users && ((bt[g1 >> 5] >> (g1 & 31)) & 1u);
+        } else if (r < c1) {
+            g0 = user[r];
+            h0 = end[r] != INT64_MIN && (unsigned)g0 < (unsigned)n_users && ((bt[g0 >> 5] >> (g0 & 31)) & 1u);
+        }
+        const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+        const int mine = (h0 ? 1 : 0) + (h1 ? 1 : 0);
+        // rows of a lane are consecutive: position inside the wave = both rows of every lane below + this lane's own
+        const int before = prefix_in_ballot(b0) + prefix_in_ballot(b1);
+        const int wtotal = __popcll(b0) + __popcll(b1);
+        if constexpr (WRITE) {
+            if (lane == 0) wcount[wave] = wtotal;
+            __syncthreads();
+            long long base = carry_s;
+            for (int w = 0; w < wave; ++w) base += wcount[w];
+            long long pos = base + before;
+            if (h0) { keys[pos] = (unsigned)g0; rows[pos] = (int)r; ++pos; }
+            if (h1) { keys[pos] = (unsigned)g1; rows[pos] = (int)(r + 1); }
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            __syncthreads();
+        } else {
+            (void)mine; (void)before;
+            total += wtotal; // wave-uniform
+        }
+    }
+    if constexpr (!WRITE) {
+        if (lane == 0) wcount[wave] = (int)total;
+        __syncthreads();
+        if (threadIdx.x == 0) blk_count[blockIdx.x] = wcount[0] + wcount[1] + wcount[2] + wcount[3];
     }
 }
+// after the stable sort by group: the head of a group's run is its first row, head and tail give its place and size
+__global__ __launch_bounds__(256) void k_arch_heads(const unsigned int* __restrict__ g_sorted, const int* __restrict__ r_sorted, long long m,
+                                                    int* __restrict__ ghead, int* __restrict__ gfirst, int* __restrict__ glast)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned g = g_sorted[i];
+        if (i == 0 || g_sorted[i - 1] != g) { ghead[g] = (int)i; gfirst[g] = r_sorted[i]; }
+        if (i == m - 1 || g_sorted[i + 1] != g) glast[g] = (int)i;
+    }
+}
+// sort key of every group: its first row if it qualifies (its bit is set and it has a run), else behind everything
+__global__ __launch_bounds__(256) void k_arch_group_keys(const unsigned int* __restrict__ bits, const int* __restrict__ gfirst, int n_users,
+                                                         unsigned int* __restrict__ key, int* __restrict__ val)
+{
+    const int g = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (g >= n_users) return;
+    const bool q = (bits[g >> 5] >> (g & 31)) & 1u;
+    key[g] = q ? (unsigned)gfirst[g] : 0xFFFFFFFFu;
+    val[g] = g;
+}
+// sizes of the qualifying groups in first-appearance order (entry k = group order[k])
+__global__ __launch_bounds__(256) void k_arch_sizes(const int* __restrict__ order, const unsigned int* __restrict__ n_qual, const int* __restrict__ ghead,
+                                                    const int* __restrict__ glast, unsigned int* __restrict__ size)
+{
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k < *n_qual) size[k] = (unsigned)(glast[order[k]] - ghead[order[k]] + 1);
+}
+// group k's run (sorted rows at ghead[order[k]]) -> the queue at off[k]: one block per group, coalesced
+__global__ __launch_bounds__(256) void k_arch_gather(const int* __restrict__ order, const unsigned int* __restrict__ n_qual, const int* __restrict__ ghead,
+                                                     const unsigned int* __restrict__ size, const unsigned int* __restrict__ off,
+                                                     const int* __restrict__ r_sorted, int* __restrict__ queue)
+{
+    const unsigned nq = *n_qual;
+    for (unsigned k = blockIdx.x; k < nq; k += gridDim.x) {
+        const unsigned src = (unsigned)ghead[order[k]], dst = off[k], cnt = size[k];
+        for (unsigned i = threadIdx.x; i < cnt; i += 256) queue[dst + i] = r_sorted[src + i];
+    }
+}
+
 
 } // namespace pie

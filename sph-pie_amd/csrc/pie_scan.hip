@@ -24,6 +24,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp> // the archive chain's two sorts and its scan (pie_archive_queue)
+#include <rocprim/device/device_scan.hpp>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -311,7 +315,12 @@ struct pie_ctx {
     int next_slot = 0;   // slot the next pie_scan_begin uses
     int n_flight = 0;    // scans begun and not finished (0..2)
     Slot* res = nullptr; // last finished scan (results)
-    const unsigned char* d_qual = nullptr; // group-qualified scan form (archive queue): per-user flag
+    const unsigned char* d_qual = nullptr; // group-qualified scan form (k_scan_compact<.., GQ>): per-user flag
+    char* d_arch = nullptr;                // pie_archive_queue: per-group scratch
+    size_t arch_bytes = 0;
+    unsigned long long arch_alg_bytes = 0; // algorithmic bytes of the last archive queue (32 B/row + 4 B per queued row)
+    double arch_ms_sum = 0;                // with profiling on: device time of the archive chains (first kernel -> last sort)
+    unsigned arch_calls = 0;
 
     // shared scratch
     long long* d_blk_off = nullptr;
@@ -455,6 +464,8 @@ void free_table(pie_ctx* c)
     ord_free(c);
     free_batch(c);
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
+    dfree(c->d_arch);
+    c->arch_bytes = 0;
     c->key_ok = false;
     dfree(c->d_blk_off);
     free_slots(c);
@@ -3474,6 +3485,19 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
 
 // The reference's archive chain on the device: group stats -> threshold on the host (U values) -> group-qualified
 // scan (buckets per group, rows in table order) -> groups laid out in first-appearance order.
+// The reference's archive chain entirely on the device (round 3; the threshold and the group order used to go through the
+// host, the selection through the general scan path with its histogram atomics and per-bucket order):
+//   1. k_arch_flag        one pass over (start, end): which groups hold a live row with start <= now - window            16 B/row
+//                         (<=> now - min(start) >= window, sqlProvider.js:798) — a bitmap; `user` only for rows that pass
+//   2. k_arch_select x 2  the selection, order-preserving (count per block, prefix, write): (group, row) pairs in table
+//                         order, the bitmap looked up in LDS                                                          2 x 12 B/row
+//   3. stable radix sort of the M pairs by group: the rows of a group stay in table order, and the head of its run IS its
+//      first row — the first-appearance order (Map insertion order, :769-789) costs no per-row work
+//   4. per group: key = first row; radix sort of the U (key, group) pairs; sizes in that order; exclusive scan; gather of
+//      every group's run into its place in the queue
+// The sorts and the scan are rocPRIM's (plain library primitives, as hipBLASLt would be for a plain GEMM); everything that
+// touches the table is above.  Algorithmic bytes: 20 B/row (start, end, user: the group statistics) + 12 B/row (end, user:
+// the selection) + 4 B per queued row.
 int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue_out, size_t cap, size_t* q_out)
 {
     if (!c) return PIE_E_INVAL;
@@ -3484,91 +3508,120 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = sync_all(c);
     if (rc) return rc;
+    rc = ensure_sel(c);
+    if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t U = (size_t)c->n_users;
-    // 1. per-group earliest start / first row
-    long long* d_min = nullptr;
-    int* d_first = nullptr;
-    unsigned char* d_qual = nullptr;
-    int* d_grp_user = nullptr;
-    long long* d_grp_off = nullptr;
-    std::vector<long long> h_min(U);
-    std::vector<int> h_first(U), h_counts(U);
-    std::vector<unsigned char> h_qual(U);
-    auto cleanup = [&]() {
-        if (d_min) (void)hipFree(d_min);
-        if (d_first) (void)hipFree(d_first);
-        if (d_qual) (void)hipFree(d_qual);
-        if (d_grp_user) (void)hipFree(d_grp_user);
-        if (d_grp_off) (void)hipFree(d_grp_off);
-        c->d_qual = nullptr;
-    };
-#define PIE_TRY(call)                                                                                 \
-    do {                                                                                              \
-        hipError_t e_ = (call);                                                                       \
-        if (e_ != hipSuccess) {                                                                       \
-            cleanup();                                                                                \
-            return fail(c, PIE_E_HIP, "%s: %s", #call, hipGetErrorString(e_));                        \
-        }                                                                                             \
-    } while (0)
-    PIE_TRY(hipMalloc(&d_min, U * 8));
-    PIE_TRY(hipMalloc(&d_first, U * 4));
-    PIE_TRY(hipMalloc(&d_qual, U));
-    hipLaunchKernelGGL(k_group_init, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, s, d_min, d_first, c->n_users);
-    hipLaunchKernelGGL(k_group_stats, dim3(c->n_cus * 16), dim3(256), 0, s, c->d_start, c->d_end, c->d_user, c->n, c->n_users,
-                       d_min, d_first);
-    PIE_TRY(hipGetLastError());
-    PIE_TRY(hipMemcpyAsync(h_min.data(), d_min, U * 8, hipMemcpyDeviceToHost, s));
-    PIE_TRY(hipMemcpyAsync(h_first.data(), d_first, U * 4, hipMemcpyDeviceToHost, s));
-    PIE_TRY(hipStreamSynchronize(s));
-    // 2. threshold (now - earliest >= window, sqlProvider.js:798) and first-appearance order, on the host: U values
-    const int kNone = INT32_MAX; // no row index can be INT32_MAX: n < 2^31 - 1 is enforced at load
-    std::vector<int> order;
-    for (size_t g = 0; g < U; ++g) {
-        h_qual[g] = 0;
-        if (h_first[g] == kNone) continue; // empty group
-        const __int128 diff = (__int128)now - (__int128)h_min[g];
-        if (diff >= (__int128)window_ms) {
-            h_qual[g] = 1;
-            order.push_back((int)g);
-        }
+    // per-group scratch: carved from one allocation kept with the context
+    const size_t u4 = ((U + 63) / 64) * 64;
+    const int words = (int)((U + 31) / 32);
+    const size_t grp_bytes = u4 * 4 * 9 + 256;
+    if (c->arch_bytes < grp_bytes) {
+        dfree(c->d_arch);
+        c->arch_bytes = 0;
+        PIE_HIP(c, hipMalloc(&c->d_arch, grp_bytes));
+        c->arch_bytes = grp_bytes;
     }
-    if (order.empty()) { cleanup(); return PIE_OK; }
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return h_first[a] < h_first[b]; });
-    // 3. group-qualified scan: one bucket per qualifying group, rows in table order
-    PIE_TRY(hipMemcpyAsync(d_qual, h_qual.data(), U, hipMemcpyHostToDevice, s));
-    c->d_qual = d_qual;
-    rc = run_scan(c, 0, 0);
-    c->d_qual = nullptr;
-    if (rc) { cleanup(); return rc; }
-    Slot& sl = *c->res;
-    PIE_TRY(hipMemcpyAsync(h_counts.data(), sl.counts_ord, U * 4, hipMemcpyDeviceToHost, s));
-    PIE_TRY(hipStreamSynchronize(s));
-    // 4. lay the groups out in first-appearance order
-    std::vector<long long> grp_off(order.size() + 1);
-    grp_off[0] = 0;
-    for (size_t k = 0; k < order.size(); ++k) grp_off[k + 1] = grp_off[k] + h_counts[order[k]];
-    const size_t q = (size_t)grp_off.back();
-    if (q_out) *q_out = q;
-    if (queue_out && q > cap) { cleanup(); return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, q); }
-    if (queue_out && q) {
-        Slot& other = c->slot[(&sl == &c->slot[0]) ? 1 : 0]; // its out_idx is free: the device-side queue
-        PIE_TRY(hipMalloc(&d_grp_user, order.size() * 4));
-        PIE_TRY(hipMalloc(&d_grp_off, grp_off.size() * 8));
-        PIE_TRY(hipMemcpyAsync(d_grp_user, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
-        PIE_TRY(hipMemcpyAsync(d_grp_off, grp_off.data(), grp_off.size() * 8, hipMemcpyHostToDevice, s));
-        const unsigned gb = order.size() < (size_t)c->n_cus * 16 ? (unsigned)order.size() : (unsigned)c->n_cus * 16;
-        hipLaunchKernelGGL(k_group_gather, dim3(gb), dim3(256), 0, s, d_grp_user, d_grp_off, (int)order.size(), sl.offsets,
-                           sl.out_idx, other.out_idx, c->cap_rows);
-        PIE_TRY(hipGetLastError());
-        PIE_TRY(hipMemcpyAsync(queue_out, other.out_idx, q * 4, hipMemcpyDeviceToHost, s));
-        PIE_TRY(hipStreamSynchronize(s));
-        other.have_result = false;
-    }
-#undef PIE_TRY
-    sl.have_result = false; // the scan above is an implementation detail, not a feed result
+    char* p = c->d_arch;
+    auto carve = [&](size_t bytes) { char* q = p; p += bytes; return q; };
+    unsigned int* d_bits = reinterpret_cast<unsigned int*>(carve(u4 * 4)); // (words <= u4)
+    int* d_ghead = reinterpret_cast<int*>(carve(u4 * 4));
+    int* d_gfirst = reinterpret_cast<int*>(carve(u4 * 4));
+    int* d_glast = reinterpret_cast<int*>(carve(u4 * 4));
+    unsigned int* d_key[2] = {reinterpret_cast<unsigned int*>(carve(u4 * 4)), reinterpret_cast<unsigned int*>(carve(u4 * 4))};
+    int* d_val[2] = {reinterpret_cast<int*>(carve(u4 * 4)), reinterpret_cast<int*>(carve(u4 * 4))};
+    unsigned int* d_size = reinterpret_cast<unsigned int*>(carve(u4 * 4));
+    unsigned int* d_nqual = reinterpret_cast<unsigned int*>(carve(256));
+    Slot& sl = c->slot[0];
+    Slot& other = c->slot[1];
+    sl.have_result = other.have_result = false;
     c->res = nullptr;
-    cleanup();
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->profiling) {
+        PIE_HIP(c, hipEventCreate(&ev0));
+        PIE_HIP(c, hipEventCreate(&ev1));
+        PIE_HIP(c, hipEventRecord(ev0, s));
+    }
+    // now - earliest >= window  <=>  earliest <= now - window, in 128 bits (JS numbers do not wrap)
+    const __int128 lim128 = (__int128)now - (__int128)window_ms;
+    const bool none = lim128 < (__int128)INT64_MIN;
+    const long long limit = lim128 > (__int128)INT64_MAX ? INT64_MAX : (none ? INT64_MIN : (long long)lim128);
+    PIE_HIP(c, hipMemsetAsync(d_bits, 0, (size_t)words * 4, s));
+    PIE_HIP(c, hipMemsetAsync(d_nqual, 0, 4, s));
+    hipLaunchKernelGGL(k_arch_flag, dim3(c->n_cus * 16), dim3(256), 0, s, c->d_start, c->d_end, c->d_user, c->n, c->n_users, limit, none, d_bits);
+    hipLaunchKernelGGL(k_arch_popc, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, d_bits, words, d_nqual);
+    // the selection: (group, row) pairs in table order
+    const int blocks = c->plan_blocks[0];
+    const long long rpb = c->plan_rows[0]; // a multiple of the streaming tile: even
+    const bool lds_bits = (size_t)words * 4 <= (size_t)48 * 1024; // up to 393 216 groups; beyond: the bitmap is read through the caches
+    const size_t lds = lds_bits ? (size_t)words * 4 : 0;
+    if (lds_bits) hipLaunchKernelGGL((k_arch_select<false, true>), dim3(blocks), dim3(256), lds, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, sl.blk_count, (const long long*)nullptr, (unsigned int*)nullptr, (int*)nullptr);
+    else hipLaunchKernelGGL((k_arch_select<false, false>), dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, sl.blk_count, (const long long*)nullptr, (unsigned int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, sl.blk_count, blocks, c->d_blk_off, &c->d_summary->m);
+    PIE_HIP(c, hipGetLastError());
+    unsigned int n_qual = 0;
+    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipMemcpyAsync(&n_qual, d_nqual, 4, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    const size_t q = (size_t)c->h_summary->m;
+    if (q_out) *q_out = q;
+    c->arch_alg_bytes = 32ull * (unsigned long long)c->n + 4ull * q;
+    if (queue_out && q > cap) return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, q);
+    if (q) {
+        // pair arrays in slot 0's record staging (16 B per row of capacity: four 4-byte arrays of q <= n entries); the
+        // sorts' temporary storage and the queue in slot 1's
+        unsigned int* k_in = reinterpret_cast<unsigned int*>(sl.sel);
+        unsigned int* k_out = k_in + q;
+        int* v_in = reinterpret_cast<int*>(k_out + q);
+        int* v_out = v_in + q;
+        int* d_queue = reinterpret_cast<int*>(other.sel);
+        void* tmp = reinterpret_cast<char*>(other.sel) + (((size_t)q * 4 + 255) / 256) * 256;
+        const size_t tmp_cap = (size_t)c->sel_cap * sizeof(SelRec) - (((size_t)q * 4 + 255) / 256) * 256;
+        size_t need = 0;
+        if (lds_bits) hipLaunchKernelGGL((k_arch_select<true, true>), dim3(blocks), dim3(256), lds, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, (int*)nullptr, c->d_blk_off, k_in, v_in);
+        else hipLaunchKernelGGL((k_arch_select<true, false>), dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, (int*)nullptr, c->d_blk_off, k_in, v_in);
+        unsigned g_bits = 1;
+        while (g_bits < 32 && (1ull << g_bits) < (unsigned long long)U) ++g_bits;
+        PIE_HIP(c, rocprim::radix_sort_pairs(nullptr, need, k_in, k_out, v_in, v_out, q, 0u, g_bits, s));
+        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "sort scratch %zu > %zu", need, tmp_cap);
+        PIE_HIP(c, rocprim::radix_sort_pairs(tmp, need, k_in, k_out, v_in, v_out, q, 0u, g_bits, s));
+        unsigned hb = (unsigned)((q + 255) / 256);
+        if (hb > (unsigned)c->n_cus * 16) hb = (unsigned)c->n_cus * 16;
+        hipLaunchKernelGGL(k_arch_heads, dim3(hb), dim3(256), 0, s, k_out, v_out, (long long)q, d_ghead, d_gfirst, d_glast);
+        hipLaunchKernelGGL(k_arch_group_keys, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, s, d_bits, d_gfirst, c->n_users, d_key[0], d_val[0]);
+        PIE_HIP(c, rocprim::radix_sort_pairs(nullptr, need, d_key[0], d_key[1], d_val[0], d_val[1], U, 0u, 32u, s));
+        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "sort scratch %zu > %zu", need, tmp_cap);
+        PIE_HIP(c, rocprim::radix_sort_pairs(tmp, need, d_key[0], d_key[1], d_val[0], d_val[1], U, 0u, 32u, s));
+        hipLaunchKernelGGL(k_arch_sizes, dim3((unsigned)((n_qual + 255) / 256)), dim3(256), 0, s, d_val[1], d_nqual, d_ghead, d_glast, d_size);
+        unsigned int* d_off = d_key[0]; // free again
+        PIE_HIP(c, rocprim::exclusive_scan(nullptr, need, d_size, d_off, 0u, (size_t)n_qual, rocprim::plus<unsigned int>(), s));
+        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "scan scratch %zu > %zu", need, tmp_cap);
+        PIE_HIP(c, rocprim::exclusive_scan(tmp, need, d_size, d_off, 0u, (size_t)n_qual, rocprim::plus<unsigned int>(), s));
+        const unsigned gb = n_qual < (unsigned)c->n_cus * 16 ? n_qual : (unsigned)c->n_cus * 16;
+        hipLaunchKernelGGL(k_arch_gather, dim3(gb ? gb : 1u), dim3(256), 0, s, d_val[1], d_nqual, d_ghead, d_size, d_off, v_out, d_queue);
+        PIE_HIP(c, hipGetLastError());
+        if (ev1) PIE_HIP(c, hipEventRecord(ev1, s));
+        if (queue_out) PIE_HIP(c, hipMemcpyAsync(queue_out, d_queue, q * 4, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    } else if (ev1) {
+        PIE_HIP(c, hipEventRecord(ev1, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    }
+    if (ev0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { c->arch_ms_sum += ms; c->arch_calls++; }
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return PIE_OK;
+}
+
+int pie_archive_stats(pie_ctx* c, double* ms_sum_out, uint32_t* calls_out, uint64_t* alg_bytes_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (ms_sum_out) *ms_sum_out = c->arch_ms_sum;
+    if (calls_out) *calls_out = c->arch_calls;
+    if (alg_bytes_out) *alg_bytes_out = c->arch_alg_bytes;
     return PIE_OK;
 }
 
@@ -3717,6 +3770,8 @@ int pie_stats_reset(pie_ctx* c)
     if (!c) return PIE_E_INVAL;
     int rc = resolve_events(c);
     c->k1_ms_sum = c->scan_ms_sum = 0;
+    c->arch_ms_sum = 0;
+    c->arch_calls = 0;
     c->n_profiled = 0;
     return rc;
 }

@@ -908,6 +908,9 @@ def test_full_size_properties_1e8(gpu_ctx, oracle, request):
     assert np.unique(grp[heads]).size == heads.size                           # each group is one contiguous run
     assert np.all(np.diff(first[grp[heads]]) > 0)                             # groups in order of first appearance
     assert np.all((np.diff(q_arch) > 0) | (np.diff(grp) != 0))                # table order inside a group
+    keep = np.nonzero(qual[u_col])[0]                                         # and row for row: the numpy restatement at full size
+    assert np.array_equal(q_arch, keep[np.lexsort((keep, first[u_col[keep]]))].astype(np.int32))
+    del keep
     # the ordered run at full size (sph-pie_amd/csrc/pie_ordered.h): the spec query (keyed form), a query that selects a
     # quarter of the table (dense form: 2.5 x 10^7 rows out) and the 16-query batch, each exact against the oracle
     gpu_ctx.set_ordered_run(2)
