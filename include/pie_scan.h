@@ -236,6 +236,14 @@ int pie_batch_pack_union_device(pie_ctx *ctx, void *dst_i32, size_t u_pad, size_
  * (two small copies + a filter on the host); no per-query list is built for it. */
 int pie_batch_read_user_feed(pie_ctx *ctx, int qi, int32_t user, int32_t *idx_out, size_t idx_cap, size_t *k_out);
 
+/* The requests of one event-loop turn, fetched together: request i asks for Feed(qi[i], user[i]) of the last finished batch.
+ * req_off_out[n_req + 1] (exclusive offsets into the arrays below), then for every request its rows in feed order and the
+ * columns the host serialises (start, end, disc: the event object of server/calendarFeed.js:66-79) — two device round trips
+ * for the whole batch instead of three small copies per request.  A user outside [0, U) has an empty feed.  PIE_E_CAPACITY if
+ * the feeds hold more than cap_rows rows (*total_out says how many). */
+int pie_batch_fetch_requests(pie_ctx *ctx, const int32_t *qi, const int32_t *user, size_t n_req, size_t cap_rows, int64_t *req_off_out,
+                             int32_t *idx_out, int64_t *start_out, int64_t *end_out, int32_t *disc_out, size_t *total_out);
+
 /* Copy the last finished scan's results to host arrays (what pie_scan does after scanning); any pointer may be NULL. */
 int pie_read_results(pie_ctx *ctx, int32_t *counts_out, int64_t *offsets_out, int32_t *idx_out, size_t idx_cap,
                      size_t *m_out);

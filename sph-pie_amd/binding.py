@@ -97,6 +97,7 @@ _SIGS = [
     ("pie_batch_read_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_batch_result_device_ptrs", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("pie_batch_read_user_feed", C.c_int, [_P, C.c_int, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("pie_batch_fetch_requests", C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, C.POINTER(C.c_size_t)]),
     ("pie_read_results", C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_read_user_feed", C.c_int, [_P, C.c_int32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("pie_result_device_ptrs", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
@@ -500,6 +501,21 @@ class PieScan:
         k = C.c_size_t(0)
         self._check(self._lib.pie_batch_read_user_feed(self._ctx, int(qi), int(user), _ptr(out), cap, C.byref(k)))
         return out[: k.value].copy()
+
+    def batch_fetch_requests(self, qis, users, cap_rows=None):
+        """Feeds of many (query, user) requests of the last finished batch in one call.
+        -> (off[n + 1] int64, idx, start, end, disc): request i's rows are idx[off[i]:off[i + 1]] (feed order) with their columns."""
+        qis, users = _col(qis, np.int32), _col(users, np.int32)
+        n = qis.shape[0]
+        cap = int(cap_rows) if cap_rows is not None else 64 * max(n, 1)
+        off = np.empty(n + 1, np.int64)
+        idx, disc = np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+        start, end = np.empty(max(cap, 1), np.int64), np.empty(max(cap, 1), np.int64)
+        total = C.c_size_t(0)
+        self._check(self._lib.pie_batch_fetch_requests(self._ctx, _ptr(qis), _ptr(users), n, cap, _ptr(off), _ptr(idx), _ptr(start), _ptr(end),
+                                                       _ptr(disc), C.byref(total)))
+        t = total.value
+        return off, idx[:t], start[:t], end[:t], disc[:t]
 
     def batch_result_device_ptrs(self, qi):
         a, b, c = _P(), _P(), _P()

@@ -2582,6 +2582,51 @@ __global__ __launch_bounds__(256) void k_mat_write(MatArgs a)
         if ((m[j] >> (q & 31)) & 1u) out[at++] = a.urows[j];
 }
 
+// ---- the requests of a batch, fetched together (pie_batch_fetch_requests): request i = (query qi[i], user usr[i]); its feed is
+// the rows of the user's union slice that carry the query's bit.  k_req_count: rows per request; after the prefix, k_req_write
+// writes every request's rows and their columns (start, end, disc) behind off[i] — what the host serialises, in ONE round trip
+// instead of three small copies per request.
+__global__ __launch_bounds__(256) void k_req_count(int n_req, const int* __restrict__ qi, const int* __restrict__ usr, int n_users,
+                                                   const long long* __restrict__ uoff, const unsigned* __restrict__ umlo,
+                                                   const unsigned* __restrict__ umhi, int* __restrict__ cnt)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n_req) return;
+    const int u = usr[i], q = qi[i];
+    int c = 0;
+    if ((unsigned)u < (unsigned)n_users) {
+        const unsigned* m = (q >= 32) ? umhi : umlo;
+        for (long long j = uoff[u]; j < uoff[u + 1]; ++j) c += (int)((m[j] >> (q & 31)) & 1u);
+    }
+    cnt[i] = c;
+}
+__global__ __launch_bounds__(256) void k_req_write(int n_req, const int* __restrict__ qi, const int* __restrict__ usr, int n_users,
+                                                   const long long* __restrict__ uoff, const int* __restrict__ urows,
+                                                   const unsigned* __restrict__ umlo, const unsigned* __restrict__ umhi,
+                                                   const long long* __restrict__ off, const PayRec* __restrict__ pay,
+                                                   const long long* __restrict__ end, long long cap, int* __restrict__ idx_out,
+                                                   long long* __restrict__ start_out, long long* __restrict__ end_out, int* __restrict__ disc_out)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n_req) return;
+    const int u = usr[i], q = qi[i];
+    if ((unsigned)u >= (unsigned)n_users) return;
+    const unsigned* m = (q >= 32) ? umhi : umlo;
+    long long at = off[i];
+    for (long long j = uoff[u]; j < uoff[u + 1]; ++j)
+        if ((m[j] >> (q & 31)) & 1u) {
+            if (at < cap) {
+                const int r = urows[j];
+                const PayRec p = pay[r];
+                idx_out[at] = r;
+                start_out[at] = p.start;
+                end_out[at] = end[r];
+                disc_out[at] = p.disc;
+            }
+            ++at;
+        }
+}
+
 // the union arrays as one int32 message in caller-owned device-visible memory (layout: UnionTailArgs::msg)
 __global__ __launch_bounds__(256) void k_union_pack(int n_users, int u_pad, const long long* __restrict__ uoff, const int* __restrict__ urows,
                                                     const unsigned* __restrict__ umlo, const unsigned* __restrict__ umhi, long long cap,

@@ -36,6 +36,7 @@
     X(int, pie_read_columns, (pie_ctx *, int64_t *, int64_t *, int32_t *, int32_t *, size_t))                       \
     X(int, pie_set_end, (pie_ctx *, const int32_t *, const int64_t *, size_t))                                      \
     X(int, pie_delete_user, (pie_ctx *, int32_t, int32_t *, size_t, size_t *))                                      \
+    X(int, pie_batch_fetch_requests, (pie_ctx *, const int32_t *, const int32_t *, size_t, size_t, int64_t *, int32_t *, int64_t *, int64_t *, int32_t *, size_t *)) \
     X(int, pie_retention_purge_tz, (pie_ctx *, int64_t, int32_t, const int64_t *, const int64_t *, int32_t, int32_t *, size_t, size_t *)) \
     X(int, pie_set_disciplines, (pie_ctx *, uint64_t, int32_t))                                                     \
     X(int, pie_scan, (pie_ctx *, int64_t, int64_t, int32_t *, int64_t *, int32_t *, size_t, size_t *))              \
@@ -451,6 +452,29 @@ static napi_value fn_retention_purge_tz(napi_env env, napi_callback_info info)
     int rc = p_pie_retention_purge_tz(ctx, now, months, tr, off, (int32_t)nt, rows, cap, &k);
     if (rc) return throw_pie(env, ctx, rc);
     return js_int(env, (int64_t)k);
+}
+
+/* batchFetchRequests(ctx, qi Int32Array[n], users Int32Array[n], off BigInt64Array[n + 1], idx Int32Array[cap], start BigInt64Array[cap],
+ * end BigInt64Array[cap], disc Int32Array[cap]) -> total rows: the feeds of n (query, user) requests of the last batch in one call;
+ * request i's rows are idx[off[i] .. off[i + 1]) with their columns.  Throws code -5 when cap is too small. */
+static napi_value fn_batch_fetch_requests(napi_env env, napi_callback_info info)
+{
+    ARGS(8)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    size_t nq = 0, nu = 0, no = 0, ci = 0, cs = 0, ce = 0, cd = 0, total = 0;
+    int32_t *qi = typed(env, argv[1], napi_int32_array, &nq), *us = typed(env, argv[2], napi_int32_array, &nu);
+    int64_t *off = typed(env, argv[3], napi_bigint64_array, &no);
+    int32_t *idx = typed(env, argv[4], napi_int32_array, &ci);
+    int64_t *st = typed(env, argv[5], napi_bigint64_array, &cs), *en = typed(env, argv[6], napi_bigint64_array, &ce);
+    int32_t *di = typed(env, argv[7], napi_int32_array, &cd);
+    if (!qi || !us || !off || !idx || !st || !en || !di || nq != nu || no < nq + 1 || cs < ci || ce < ci || cd < ci) {
+        napi_throw_type_error(env, NULL, "batchFetchRequests(ctx, Int32Array qi[n], Int32Array users[n], BigInt64Array off[n + 1], Int32Array idx[cap], BigInt64Array start[cap], BigInt64Array end[cap], Int32Array disc[cap])");
+        return NULL;
+    }
+    int rc = p_pie_batch_fetch_requests(ctx, qi, us, nq, ci, off, idx, st, en, di, &total);
+    if (rc) return throw_pie(env, ctx, rc);
+    return js_int(env, (int64_t)total);
 }
 
 /* setDisciplines(ctx, mask BigInt|Number, nDisc) */
@@ -1523,7 +1547,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
         {"setOrderedRun", fn_set_ordered_run},
-        {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed},
+        {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed}, {"batchFetchRequests", fn_batch_fetch_requests},
         {"commCreate", fn_comm_create}, {"commDestroy", fn_comm_destroy}, {"commWorld", fn_comm_world}, {"commCtx", fn_comm_ctx},
         {"commGenSyntheticSharded", fn_comm_gen}, {"commScanBatchGather", fn_comm_scan_gather}, {"commReadGathered", fn_comm_read}, {"commUPad", fn_comm_upad},
         {"commNeededCap", fn_comm_needed_cap}, {"commStepReserve", fn_comm_step_reserve}, {"commStepBegin", fn_comm_step_begin},

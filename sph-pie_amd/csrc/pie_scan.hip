@@ -3270,6 +3270,82 @@ int pie_batch_read_user_feed(pie_ctx* c, int qi, int32_t user, int32_t* idx_out,
     return PIE_OK;
 }
 
+int pie_batch_fetch_requests(pie_ctx* c, const int32_t* qi, const int32_t* user, size_t n_req, size_t cap_rows, int64_t* req_off_out,
+                             int32_t* idx_out, int64_t* start_out, int64_t* end_out, int32_t* disc_out, size_t* total_out)
+{
+    if (!c) return PIE_E_INVAL;
+    if (total_out) *total_out = 0;
+    if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (n_req == 0) return PIE_OK;
+    if (!qi || !user || !req_off_out || n_req > (size_t)1 << 24) return fail(c, PIE_E_INVAL, "bad request list");
+    BatchSlot& b = *c->bres;
+    for (size_t i = 0; i < n_req; ++i)
+        if (qi[i] < 0 || qi[i] >= b.n_q) return fail(c, PIE_E_INVAL, "request %zu: query %d outside the batch of %d", i, qi[i], b.n_q);
+    PIE_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!b.union_ok || !c->d_pay) {
+        // a batch without a union (queries fell back, the ordered run) or a table without the payload column: request by request
+        size_t total = 0;
+        std::vector<int32_t> tmp;
+        for (size_t i = 0; i < n_req; ++i) {
+            req_off_out[i] = (int64_t)total;
+            size_t k = 0;
+            int rc = pie_batch_read_user_feed(c, qi[i], user[i], nullptr, 0, &k);
+            if (rc != PIE_OK && rc != PIE_E_CAPACITY) return rc;
+            if (k && idx_out && total + k <= cap_rows) {
+                rc = pie_batch_read_user_feed(c, qi[i], user[i], idx_out + total, k, &k);
+                if (rc) return rc;
+                rc = pie_fetch_rows(c, idx_out + total, k, start_out ? start_out + total : nullptr, end_out ? end_out + total : nullptr, nullptr,
+                                    disc_out ? disc_out + total : nullptr);
+                if (rc) return rc;
+            }
+            total += k;
+        }
+        req_off_out[n_req] = (int64_t)total;
+        if (total_out) *total_out = total;
+        if (idx_out && total > cap_rows) return fail(c, PIE_E_CAPACITY, "cap_rows %zu < %zu rows", cap_rows, total);
+        return PIE_OK;
+    }
+    // device staging: [qi n | user n | cnt n | off (n + 1) x 8 | idx cap | disc cap | start cap x 8 | end cap x 8]
+    const size_t n4 = ((n_req + 3) / 4) * 4, cap4 = ((cap_rows + 3) / 4) * 4;
+    const size_t bytes = n4 * 12 + (n4 + 4) * 8 + cap4 * 24 + 64;
+    int rc = ensure_stage(c, bytes);
+    if (rc) return rc;
+    char* h = c->h_stage;
+    char* d = c->d_stage;
+    memcpy(h, qi, n_req * 4);
+    memcpy(h + n4 * 4, user, n_req * 4);
+    PIE_HIP(c, hipMemcpyAsync(d, h, n4 * 8, hipMemcpyHostToDevice, s));
+    int* d_qi = reinterpret_cast<int*>(d);
+    int* d_us = reinterpret_cast<int*>(d + n4 * 4);
+    int* d_cnt = reinterpret_cast<int*>(d + n4 * 8);
+    long long* d_off = reinterpret_cast<long long*>(d + n4 * 12);
+    int* d_idx = reinterpret_cast<int*>(d + n4 * 12 + (n4 + 4) * 8);
+    int* d_disc = d_idx + cap4;
+    long long* d_start = reinterpret_cast<long long*>(d_disc + cap4);
+    long long* d_end = d_start + cap4;
+    const unsigned blocks = (unsigned)((n_req + 255) / 256);
+    const unsigned* hi = b.n_q > 32 ? b.umhi : b.umlo;
+    hipLaunchKernelGGL(k_req_count, dim3(blocks), dim3(256), 0, s, (int)n_req, d_qi, d_us, c->n_users, b.uoff, b.umlo, hi, d_cnt);
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, s, d_cnt, (int)n_req, d_off, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_req_write, dim3(blocks), dim3(256), 0, s, (int)n_req, d_qi, d_us, c->n_users, b.uoff, b.urows, b.umlo, hi, d_off, c->d_pay,
+                       c->d_end, (long long)cap_rows, d_idx, d_start, d_end, d_disc);
+    PIE_HIP(c, hipGetLastError());
+    PIE_HIP(c, hipMemcpyAsync(req_off_out, d_off, (n_req + 1) * 8, hipMemcpyDeviceToHost, s));
+    PIE_HIP(c, hipStreamSynchronize(s));
+    const size_t total = (size_t)req_off_out[n_req];
+    if (total_out) *total_out = total;
+    if (idx_out && total > cap_rows) return fail(c, PIE_E_CAPACITY, "cap_rows %zu < %zu rows", cap_rows, total);
+    if (total && idx_out) {
+        PIE_HIP(c, hipMemcpyAsync(idx_out, d_idx, total * 4, hipMemcpyDeviceToHost, s));
+        if (disc_out) PIE_HIP(c, hipMemcpyAsync(disc_out, d_disc, total * 4, hipMemcpyDeviceToHost, s));
+        if (start_out) PIE_HIP(c, hipMemcpyAsync(start_out, d_start, total * 8, hipMemcpyDeviceToHost, s));
+        if (end_out) PIE_HIP(c, hipMemcpyAsync(end_out, d_end, total * 8, hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+    }
+    return PIE_OK;
+}
+
 int pie_batch_read_results(pie_ctx* c, int qi, int32_t* counts_out, int64_t* offsets_out, int32_t* idx_out, size_t idx_cap, size_t* m_out)
 {
     if (!c) return PIE_E_INVAL;

@@ -81,6 +81,20 @@ function createFeedService(store, options){
     return Buffer.from(JSON.stringify({events}));
   }
 
+  function eventsJsonFromColumns(idx, start, end, disc){
+    const table = nativeTable();
+    if(table && store.native && typeof store.native.serializeEvents === 'function'){
+      const buf = store.native.serializeEvents(idx, idx.length, start, end, disc, table);
+      if(buf !== null){ return buf; }
+    }
+    const events = [];
+    for(let i = 0; i < idx.length; i++){
+      const d = disciplineConfig.DISCIPLINES[disc[i]];
+      events.push(calendarFeed.eventFromRow(idx[i], start[i], end[i], d ? d.name : 'Session'));
+    }
+    return Buffer.from(JSON.stringify({events}));
+  }
+
   // the same slice as iCalendar text (new functionality, see calendarFeed.toICalendar): native writer when it covers
   // the rows, else the JS emitter over the event objects
   function icsFromRows(idx, dtstamp){
@@ -150,6 +164,7 @@ function createFeedService(store, options){
   // (pie_scan_batch: the key column is streamed once, every candidate row is evaluated against all the queries), each
   // request then reads its user's slice of its query's result.  Same bytes as eventsJsonForUser, request by request.
   let batchesRun = 0;
+  const timing = {scanNs: 0, fetchNs: 0, serializeNs: 0};   // host wall time spent in the three native stages of the batches
   function eventsJsonForRequests(requests){
     const bodies = new Array(requests.length);
     const groups = [];                 // {k, members: [request index]}
@@ -168,21 +183,37 @@ function createFeedService(store, options){
     const maxQ = store.BATCH_MAX || 16;
     for(let at = 0; at < groups.length; at += maxQ){
       const chunk = groups.slice(at, at + maxQ);
+      const ts = process.hrtime.bigint();
       store.scanBatchDevice(chunk.map(g => ({now: g.k.now, cutoff: g.k.cutoff, disciplines: g.k.disciplines})));
+      timing.scanNs += Number(process.hrtime.bigint() - ts);
       batchesRun++;
       last = null;                     // the device now holds a batch result, not a single scan's
-      chunk.forEach((g, qi) => {
-        for(const i of g.members){
-          const u = store.userIndexOf(requests[i].userId);
-          bodies[i] = u < 0 ? Buffer.from('{"events":[]}') : eventsJsonFromRows(store.batchUserFeed(qi, u));
+      // every request's rows and their columns in ONE native call (pie_batch_fetch_requests), then one serialiser call each
+      const members = [];
+      chunk.forEach((g, qi) => { for(const i of g.members){ members.push([i, qi, store.userIndexOf(requests[i].userId)]); } });
+      if(typeof store.batchFetch === 'function' && members.length > 1){
+        const qis = Int32Array.from(members, m => m[1]), us = Int32Array.from(members, m => m[2]);
+        const t0 = process.hrtime.bigint();
+        const f = store.batchFetch(qis, us);
+        const t1 = process.hrtime.bigint();
+        members.forEach((m, k) => {
+          const a = Number(f.off[k]), b = Number(f.off[k + 1]);
+          bodies[m[0]] = m[2] < 0 || b === a ? Buffer.from('{"events":[]}')
+            : eventsJsonFromColumns(f.idx.subarray(a, b), f.start.subarray(a, b), f.end.subarray(a, b), f.disc.subarray(a, b));
+        });
+        timing.fetchNs += Number(t1 - t0);
+        timing.serializeNs += Number(process.hrtime.bigint() - t1);
+      }else{
+        for(const m of members){
+          bodies[m[0]] = m[2] < 0 ? Buffer.from('{"events":[]}') : eventsJsonFromRows(store.batchUserFeed(m[1], m[2]));
         }
-      });
+      }
     }
     return bodies;
   }
 
   return {scan, eventsForUser, eventsJsonForUser, eventsJsonForRequests, icsForUser, allFeeds, scansRun: () => scansRun,
-    batchesRun: () => batchesRun};
+    batchesRun: () => batchesRun, timing: () => Object.assign({}, timing)};
 }
 
 module.exports = {createFeedService};

@@ -48,6 +48,20 @@ function createStore(options){
   let nGone = 0;                                   // rows that no scan, queue or lookup will ever need again
   let listBuf = new Int32Array(1024);              // reused row-list buffer of the device scans (grown, never per call)
   const compactMinRows = opts.compactMinRows === undefined ? 4096 : opts.compactMinRows;
+  // A resident BASE of anonymous rows (opts.base = {rows, users, disc, seed?, flags?}): the synthetic corpus of SURVEY.md 8d
+  // generated on the device (pie_gen_synthetic), users 'user-0' .. pre-registered — the way a 10^8-session table exists at all
+  // on one Node process (the host keeps a map entry per session it ISSUED, not per row of history).  Sessions created through
+  // this module are appended behind the base; device row = base + host row.  The full-table list operations that report rows
+  // back to the host map (deleteSessionsForUser, purges, compaction, save) are not offered on a based store.
+  let base = 0;
+  if(opts.base){
+    const b = opts.base;
+    for(let u = 0; u < b.users; u++){ denseUserEarly('user-' + u); }
+    native.genSynthetic(ctx, b.seed === undefined ? 0x5EED5EED : b.seed, b.rows, 0, b.rows, b.users, b.disc, b.flags || 0);
+    base = b.rows;
+  }
+  function denseUserEarly(userId){ userIndex.set(userId, userIds.length); userIds.push(userId); }
+  const noBase = what => { if(base > 0){ throw new Error(what + ' is not offered on a store with a synthetic base'); } };
 
   function rowList(){
     if(listBuf.length < rows.length){
@@ -69,11 +83,11 @@ function createStore(options){
   // push host-side mutations to the device: appended rows first, then end updates, so a row that was created
   // and touched in the same batch ends with the touched value
   function flush(){
-    if(rows.length >= compactMinRows && nGone * 2 > rows.length){
+    if(base === 0 && rows.length >= compactMinRows && nGone * 2 > rows.length){
       compact();
     }
     const k = rows.length - uploaded;
-    if(k > 0 || uploaded === 0){
+    if(k > 0 || (uploaded === 0 && base === 0)){
       const s = new BigInt64Array(k), e = new BigInt64Array(k);
       const u = new Int32Array(k), d = new Int32Array(k);
       for(let i = 0; i < k; i++){
@@ -85,7 +99,7 @@ function createStore(options){
         pendingEnd.delete(uploaded + i);
       }
       const nUsers = Math.max(userIds.length, 1);
-      if(uploaded === 0){
+      if(uploaded === 0 && base === 0){
         native.loadColumns(ctx, s, e, u, d, nUsers);
       }else{
         native.appendRows(ctx, s, e, u, d, nUsers);
@@ -95,7 +109,7 @@ function createStore(options){
     if(pendingEnd.size > 0){
       const r = new Int32Array(pendingEnd.size), v = new BigInt64Array(pendingEnd.size);
       let i = 0;
-      pendingEnd.forEach((val, row) => { r[i] = row; v[i] = val; i++; });
+      pendingEnd.forEach((val, row) => { r[i] = base + row; v[i] = val; i++; });
       native.setEnd(ctx, r, v);
       pendingEnd = new Map();
     }
@@ -212,6 +226,7 @@ function createStore(options){
     if(!userId){
       return;
     }
+    noBase('deleteSessionsForUser');
     const u = userIndex.get(userId);
     if(u === undefined){
       return;
@@ -229,6 +244,7 @@ function createStore(options){
   // full-table scan on the device; `now` is sampled once (:67).  The device returns the rows that died since the
   // previous purge (prev < end <= now); rows that died earlier were already dropped from the map.
   function purgeExpiredSessions(){
+    noBase('purgeExpiredSessions');
     const now = Date.now();
     flush();
     const list = rowList();
@@ -249,6 +265,7 @@ function createStore(options){
   // (tzTable.js: built from the engine's own zone rules, so daylight saving moves the result exactly as it does for the
   // reference's Date).  -> number of sessions dropped
   function purgeRetention(months, now){
+    noBase('purgeRetention');
     const tz = require('./tzTable').defaultTzTable();
     flush();
     const list = rowList();
@@ -264,6 +281,7 @@ function createStore(options){
   // ---- the batched feed scan (replaces the per-request loop) ------------------------------------------
   // -> {counts Int32Array[U], offsets BigInt64Array[U+1], idx Int32Array[M], m, userIds}
   function scanFeeds(query){
+    noBase('scanFeeds (the whole result on the host)');
     const q = query || {};
     const now = q.now === undefined ? Date.now() : q.now;
     const cutoff = q.cutoff === undefined ? END_NONE : q.cutoff;
@@ -289,8 +307,9 @@ function createStore(options){
   }
   var feedBuf = null;
   function userFeed(u){
-    if(feedBuf === null || feedBuf.length < rows.length){
-      feedBuf = new Int32Array(Math.max(rows.length, 1));
+    const want = Math.max(base > 0 ? 65536 : rows.length, 1);
+    if(feedBuf === null || feedBuf.length < want){
+      feedBuf = new Int32Array(want);
     }
     const k = native.userFeed(ctx, u, feedBuf);
     return feedBuf.slice(0, k);
@@ -298,6 +317,7 @@ function createStore(options){
 
   // ordered device queue of rows with prevNow < expiresAt <= now (no change to the host map: purgeExpiredSessions does that)
   function expiredRows(prevNow, now){
+    noBase('expiredRows');
     flush();
     const list = rowList();
     const prev = prevNow === null || prevNow === undefined ? END_NONE : prevNow;
@@ -309,6 +329,7 @@ function createStore(options){
   // the reference's archive chain on the session table (sqlProvider.js:758-816): rows of every user whose earliest
   // session is at least windowMs old, users in order of first appearance, rows in table order
   function archivedRows(now, windowMs){
+    noBase('archivedRows');
     flush();
     const list = rowList();
     const k = native.archiveQueue(ctx, now, windowMs === undefined ? SESSION_TTL_MS : windowMs, list);
@@ -335,11 +356,32 @@ function createStore(options){
     return native.scanBatch(ctx, nows, cutoffs, masks);
   }
   function batchUserFeed(qi, u){
-    if(feedBuf === null || feedBuf.length < rows.length){
-      feedBuf = new Int32Array(Math.max(rows.length, 1));
+    const want = Math.max(base > 0 ? 4096 : rows.length, 1);
+    if(feedBuf === null || feedBuf.length < want){
+      feedBuf = new Int32Array(want);
     }
     const k = native.batchUserFeed(ctx, qi, u, feedBuf);
     return feedBuf.slice(0, k);
+  }
+  // the feeds of MANY (query, user) requests of the last batch in one native call (pie_batch_fetch_requests): -> {off, idx,
+  // start, end, disc}; request i's rows are idx[off[i] .. off[i + 1]) in feed order with their columns, ready to serialise
+  let fetchBufs = null;
+  function batchFetch(qis, users){
+    const n = qis.length;
+    let cap = fetchBufs === null ? Math.max(1024, 8 * n) : fetchBufs.idx.length;
+    for(;;){
+      if(fetchBufs === null || fetchBufs.idx.length < cap || fetchBufs.off.length < n + 1){
+        fetchBufs = {off: new BigInt64Array(Math.max(n + 1, fetchBufs === null ? 0 : fetchBufs.off.length)), idx: new Int32Array(cap),
+          start: new BigInt64Array(cap), end: new BigInt64Array(cap), disc: new Int32Array(cap)};
+      }
+      try{
+        const total = native.batchFetchRequests(ctx, qis, users, fetchBufs.off, fetchBufs.idx, fetchBufs.start, fetchBufs.end, fetchBufs.disc);
+        return {off: fetchBufs.off, idx: fetchBufs.idx, start: fetchBufs.start, end: fetchBufs.end, disc: fetchBufs.disc, total};
+      }catch(err){
+        if(err.code !== -5){ throw err; }
+        cap *= 4;                                    // the feeds outgrew the buffers: larger ones, once more
+      }
+    }
   }
 
   function fetchRows(idx){
@@ -355,6 +397,7 @@ function createStore(options){
   // save(dir): the four column files of pie_save_columns + tokens.json {userIds, tokenHash per row (null = gone),
   // lastPurge}.  Tokens themselves are never stored, only their sha256 (as in the reference's Map keys, :8-10).
   function save(dir){
+    noBase('save');
     flush();
     native.saveColumns(ctx, dir);
     const doc = {format: 'pie-tokens', version: 1, rows: rows.length, userIds, tokenHash: rows.map(r => r.tokenHash), lastPurge};
@@ -392,8 +435,8 @@ function createStore(options){
   return {
     createSession, getSession, touchSession, deleteSession, deleteSessionsForUser, purgeExpiredSessions, purgeRetention,
     SESSION_TTL_MS, SESSION_COOKIE_NAME,
-    scanFeeds, scanDevice, userFeed, scanBatchDevice, batchUserFeed, BATCH_MAX, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
-    compact, compactions: () => compactions, tableRows: () => rows.length,
+    scanFeeds, scanDevice, userFeed, scanBatchDevice, batchUserFeed, batchFetch, BATCH_MAX, fetchRows, expiredRows, archivedRows, flush, close, save, restore,
+    compact, compactions: () => compactions, tableRows: () => base + rows.length, baseRows: () => base,
     userIds: () => userIds,
     userIndexOf: userId => (userIndex.has(userId) ? userIndex.get(userId) : -1),
     size: () => rowOfToken.size,

@@ -531,3 +531,36 @@ def test_union_message_written_by_the_batch(gpu_ctx, oracle, pie):
         assert ready and int(small[0][u_pad + 1]) == mu and np.array_equal(small[0][u_pad + 2: u_pad + 12], w_rows[:10])
         for _, _, addr in bufs + [small]:
             gpu_ctx.host_free(addr)
+
+
+def test_requests_of_a_batch_fetched_together(gpu_ctx, oracle):
+    """pie_batch_fetch_requests: many (query, user) requests of one batch in ONE call — every request's rows in feed order and
+    their start / end / disc columns — against the oracle; also for a batch without a union (a query fell back) and for users
+    outside the table."""
+    n, U, D = 400009, 3001, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 1)
+    s, e, u, d = cols
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    rng = np.random.default_rng(7)
+    for queries in (mixed_queries(oracle, 40), mixed_queries(oracle, 5) + [(oracle.T0_MS - 100 * DAY, oracle.T0_MS - 61 * DAY, ALL)]):
+        want = oracle_answers(oracle, cols, U, D, queries)
+        gpu_ctx.scan_batch_begin(queries)
+        gpu_ctx.scan_batch_finish()
+        nreq = 500
+        qis = rng.integers(0, len(queries), nreq).astype(np.int32)
+        users = rng.integers(-2, U + 3, nreq).astype(np.int32)
+        off, idx, st, en, di = gpu_ctx.batch_fetch_requests(qis, users)
+        assert off[0] == 0 and off[-1] == idx.size
+        for i in range(nreq):
+            uu, q = int(users[i]), int(qis[i])
+            rows = idx[off[i]:off[i + 1]]
+            if uu < 0 or uu >= U:
+                assert rows.size == 0
+                continue
+            c, o, ix = want[q]
+            assert np.array_equal(rows, ix[o[uu]:o[uu + 1]]), (i, q, uu)
+        assert np.array_equal(st, s[idx]) and np.array_equal(en, e[idx]) and np.array_equal(di, d[idx])
+    # too small a buffer: refused with the size it needs
+    with pytest.raises(Exception):
+        gpu_ctx.batch_fetch_requests(qis, users, cap_rows=3)
