@@ -318,6 +318,8 @@ struct pie_ctx {
     const unsigned char* d_qual = nullptr; // group-qualified scan form (k_scan_compact<.., GQ>): per-user flag
     char* d_arch = nullptr;                // pie_archive_queue: per-group scratch
     size_t arch_bytes = 0;
+    char* d_arch_tmp = nullptr;            // ... temporary storage of its sorts / scan
+    size_t arch_tmp_bytes = 0;
     unsigned long long arch_alg_bytes = 0; // algorithmic bytes of the last archive queue (32 B/row + 4 B per queued row)
     double arch_ms_sum = 0;                // with profiling on: device time of the archive chains (first kernel -> last sort)
     unsigned arch_calls = 0;
@@ -466,6 +468,8 @@ void free_table(pie_ctx* c)
     dfree(c->d_start); dfree(c->d_end); dfree(c->d_user); dfree(c->d_disc); dfree(c->d_key); dfree(c->d_pay); dfree(c->d_fkey);
     dfree(c->d_arch);
     c->arch_bytes = 0;
+    dfree(c->d_arch_tmp);
+    c->arch_tmp_bytes = 0;
     c->key_ok = false;
     dfree(c->d_blk_off);
     free_slots(c);
@@ -3651,27 +3655,38 @@ int pie_archive_queue(pie_ctx* c, int64_t now, int64_t window_ms, int32_t* queue
         int* v_in = reinterpret_cast<int*>(k_out + q);
         int* v_out = v_in + q;
         int* d_queue = reinterpret_cast<int*>(other.sel);
-        void* tmp = reinterpret_cast<char*>(other.sel) + (((size_t)q * 4 + 255) / 256) * 256;
-        const size_t tmp_cap = (size_t)c->sel_cap * sizeof(SelRec) - (((size_t)q * 4 + 255) / 256) * 256;
         size_t need = 0;
+        // temporary storage of the library primitives: a buffer of its own, grown to what they ask for (a table of a handful of
+        // rows and 600 000 users wants more for the per-group sort than the table's record staging holds: found by the fuzz)
+        auto tmp_for = [&](size_t bytes) -> void* {
+            if (bytes > c->arch_tmp_bytes) {
+                if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+                dfree(c->d_arch_tmp);
+                c->arch_tmp_bytes = 0;
+                if (hipMalloc(&c->d_arch_tmp, bytes + bytes / 4 + 4096) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                c->arch_tmp_bytes = bytes + bytes / 4 + 4096;
+            }
+            return c->d_arch_tmp;
+        };
+        void* tmp = nullptr;
         if (lds_bits) hipLaunchKernelGGL((k_arch_select<true, true>), dim3(blocks), dim3(256), lds, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, (int*)nullptr, c->d_blk_off, k_in, v_in);
         else hipLaunchKernelGGL((k_arch_select<true, false>), dim3(blocks), dim3(256), 0, s, c->d_end, c->d_user, c->n, rpb, d_bits, words, c->n_users, (int*)nullptr, c->d_blk_off, k_in, v_in);
         unsigned g_bits = 1;
         while (g_bits < 32 && (1ull << g_bits) < (unsigned long long)U) ++g_bits;
         PIE_HIP(c, rocprim::radix_sort_pairs(nullptr, need, k_in, k_out, v_in, v_out, q, 0u, g_bits, s));
-        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "sort scratch %zu > %zu", need, tmp_cap);
+        if (!(tmp = tmp_for(need))) return fail(c, PIE_E_NOMEM, "sort scratch of %zu bytes", need);
         PIE_HIP(c, rocprim::radix_sort_pairs(tmp, need, k_in, k_out, v_in, v_out, q, 0u, g_bits, s));
         unsigned hb = (unsigned)((q + 255) / 256);
         if (hb > (unsigned)c->n_cus * 16) hb = (unsigned)c->n_cus * 16;
         hipLaunchKernelGGL(k_arch_heads, dim3(hb), dim3(256), 0, s, k_out, v_out, (long long)q, d_ghead, d_gfirst, d_glast);
         hipLaunchKernelGGL(k_arch_group_keys, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, s, d_bits, d_gfirst, c->n_users, d_key[0], d_val[0]);
         PIE_HIP(c, rocprim::radix_sort_pairs(nullptr, need, d_key[0], d_key[1], d_val[0], d_val[1], U, 0u, 32u, s));
-        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "sort scratch %zu > %zu", need, tmp_cap);
+        if (!(tmp = tmp_for(need))) return fail(c, PIE_E_NOMEM, "sort scratch of %zu bytes", need);
         PIE_HIP(c, rocprim::radix_sort_pairs(tmp, need, d_key[0], d_key[1], d_val[0], d_val[1], U, 0u, 32u, s));
         hipLaunchKernelGGL(k_arch_sizes, dim3((unsigned)((n_qual + 255) / 256)), dim3(256), 0, s, d_val[1], d_nqual, d_ghead, d_glast, d_size);
         unsigned int* d_off = d_key[0]; // free again
         PIE_HIP(c, rocprim::exclusive_scan(nullptr, need, d_size, d_off, 0u, (size_t)n_qual, rocprim::plus<unsigned int>(), s));
-        if (need > tmp_cap) return fail(c, PIE_E_NOMEM, "scan scratch %zu > %zu", need, tmp_cap);
+        if (!(tmp = tmp_for(need))) return fail(c, PIE_E_NOMEM, "scan scratch of %zu bytes", need);
         PIE_HIP(c, rocprim::exclusive_scan(tmp, need, d_size, d_off, 0u, (size_t)n_qual, rocprim::plus<unsigned int>(), s));
         const unsigned gb = n_qual < (unsigned)c->n_cus * 16 ? n_qual : (unsigned)c->n_cus * 16;
         hipLaunchKernelGGL(k_arch_gather, dim3(gb ? gb : 1u), dim3(256), 0, s, d_val[1], d_nqual, d_ghead, d_size, d_off, v_out, d_queue);

@@ -135,20 +135,96 @@ while time.time() < t_end:
                         mk = int(rng.integers(0, 2 ** 63)) | (int(rng.integers(0, 2)) << 63) if rng.random() < 0.7 else 2 ** 64 - 1
                         return nw, ct, mk
                     lim = 2 ** 64 - 1 if D >= 64 else (1 << D) - 1
-                    batches = [[rand_query() for _ in range(int(rng.integers(1, 17)))] for _ in range(int(rng.integers(1, 4)))]
-                    ctx.scan_batch_begin(batches[0])
+                    def batch_size():   # 1 .. 64 queries; more than 16 and more than 32 are shapes of their own
+                        return int(rng.choice([int(rng.integers(1, 17)), int(rng.integers(17, 33)), int(rng.integers(33, 65))], p=[0.6, 0.2, 0.2]))
+                    batches = [[rand_query() for _ in range(batch_size())] for _ in range(int(rng.integers(1, 4)))]
+                    if rng.random() < 0.3:   # the requests of a few seconds: clocks a second apart, two cutoffs, three masks
+                        base_now = int(T0 - rng.integers(0, 20 * 3600 * 1000))
+                        mk3 = [int(rng.integers(0, 2 ** 63)), 2 ** 64 - 1, int(rng.integers(0, 2 ** 63))]
+                        batches[0] = [(base_now - 977 * q, T0 - (61 + q % 2) * DAY, mk3[q % 3]) for q in range(len(batches[0]))]
+                    # now and then the batch writes its union exchange message itself (pie_scan_batch_begin_union)
+                    direct = [rng.random() < 0.3 for _ in batches]
+                    dmsg = {}
+
+                    def begin(k):
+                        if direct[k]:
+                            up, cp = U + int(rng.integers(0, 3)), int(rng.choice([1 << 16, 40, 3]))
+                            t = torch.full((up + 2 + 3 * cp,), -7, dtype=torch.int32, device=dev)
+                            torch.cuda.synchronize()
+                            dmsg[k] = (t, up, cp)
+                            ctx.scan_batch_begin_union(batches[k], t.data_ptr(), up, cp)
+                        else:
+                            ctx.scan_batch_begin(batches[k])
+
+                    begin(0)
                     for k in range(len(batches)):
                         if k + 1 < len(batches):
-                            ctx.scan_batch_begin(batches[k + 1])
-                        ms = ctx.scan_batch_finish()
-                        for qi, (nw, ct, mk) in enumerate(batches[k]):
-                            w = oracle.scan(s, e, u, d, U, nw, ct, mk & lim)
+                            begin(k + 1)
+                        ms, ready = ctx.scan_batch_finish(packed=True)
+                        wants_k = [oracle.scan(s, e, u, d, U, nw, ct, mk & lim) for nw, ct, mk in batches[k]]
+                        nqk = len(batches[k])
+                        for qi, w in enumerate(wants_k):
                             if ms[qi] != w[2].size:
                                 raise AssertionError(what + " batch %d query %d: M differs" % (k, qi))
-                            same(ctx.batch_read_results(qi), w, what + " batch %d query %d now %d cutoff %d mask %x" % (k, qi, nw, ct, mk))
+                        un = ctx.batch_read_union()
+                        if un is not None:   # the primary result: every query's counts / offsets / rows are a filter of it, in order
+                            uoff_d, rows_d, masks_d = un
+                            for qi, w in enumerate(wants_k):
+                                sel = ((masks_d >> np.uint64(qi)) & np.uint64(1)) == 1
+                                csum = np.concatenate([[0], np.cumsum(sel)])
+                                if not (np.array_equal(rows_d[sel], w[2]) and np.array_equal(csum[uoff_d], w[1])):
+                                    raise AssertionError(what + " batch %d query %d: union result differs" % (k, qi))
+                            if np.any(masks_d == 0) or (nqk < 64 and np.any(masks_d >> np.uint64(nqk))):
+                                raise AssertionError(what + " batch %d: a union row without a query / with a query bit beyond the batch" % k)
+                        if k in dmsg:   # the message the batch wrote (or, without a union, the one packed from the lists)
+                            t, up, cp = dmsg.pop(k)
+                            ctx.synchronize()
+                            a = t.cpu().numpy()
+                            mu = int(a[up + 1])
+                            if un is not None and not ready:
+                                raise AssertionError(what + " batch %d: has a union but its message was not written by the batch" % k)
+                            if mu >= 0:
+                                kk = min(mu, cp)
+                                lo_w = a[up + 2 + cp: up + 2 + cp + kk].astype(np.uint32).astype(np.uint64)
+                                hi_w = a[up + 2 + 2 * cp: up + 2 + 2 * cp + kk].astype(np.uint32).astype(np.uint64) if nqk > 32 else np.zeros(kk, np.uint64)
+                                m64 = lo_w | (hi_w << np.uint64(32))
+                                uo, rw = a[: U + 1].astype(np.int64), a[up + 2: up + 2 + kk]
+                                if not np.all(a[U + 1: up + 1] == mu):
+                                    raise AssertionError(what + " batch %d: message padding offsets" % k)
+                                if un is not None and not (mu == un[1].size and np.array_equal(uo, un[0]) and np.array_equal(rw, un[1][:kk]) and np.array_equal(m64, un[2][:kk])):
+                                    raise AssertionError(what + " batch %d: union message differs from the union result (cap %d)" % (k, cp))
+                                if mu <= cp:
+                                    for qi, w in enumerate(wants_k):
+                                        sel = ((m64 >> np.uint64(qi)) & np.uint64(1)) == 1
+                                        if not np.array_equal(rw[sel], w[2]):
+                                            raise AssertionError(what + " batch %d query %d: union message rows differ" % (k, qi))
+                            elif un is not None:
+                                raise AssertionError(what + " batch %d: message says -1 although the batch has a union" % k)
+                        if rng.random() < 0.5:   # a handful of requests fetched together
+                            nreq = int(rng.integers(1, 40))
+                            rq, ru = rng.integers(0, nqk, nreq).astype(np.int32), rng.integers(-1, U + 1, nreq).astype(np.int32)
+                            off_r, idx_r, st_r, en_r, di_r = ctx.batch_fetch_requests(rq, ru, cap_rows=nreq * max(int(w[0].max()) if w[0].size else 0 for w in wants_k) + 8)
+                            for i in range(nreq):
+                                got_rows = idx_r[off_r[i]:off_r[i + 1]]
+                                uu = int(ru[i])
+                                exp = wants_k[int(rq[i])]
+                                exp_rows = exp[2][exp[1][uu]:exp[1][uu + 1]] if 0 <= uu < U else np.zeros(0, np.int32)
+                                if not np.array_equal(got_rows, exp_rows):
+                                    raise AssertionError(what + " batch %d request %d (query %d user %d): fetched rows differ" % (k, i, int(rq[i]), uu))
+                            if not (np.array_equal(st_r, s[idx_r]) and np.array_equal(en_r, e[idx_r]) and np.array_equal(di_r, d[idx_r])):
+                                raise AssertionError(what + " batch %d: fetched columns differ" % k)
+                        order_q = rng.permutation(nqk)[: int(rng.integers(1, min(nqk, 6) + 1))] if nqk > 16 else range(nqk)
+                        for qi in order_q:   # per-query results, materialised on request (all of them for small batches)
+                            qi = int(qi)
+                            nw, ct, mk = batches[k][qi]
+                            same(ctx.batch_read_results(qi), wants_k[qi], what + " batch %d query %d now %d cutoff %d mask %x" % (k, qi, nw, ct, mk))
                             scans += 1
-                        if rng.random() < 0.4:   # the union exchange message of this batch: every query's list is a filter of it, in order
-                            wants = [oracle.scan(s, e, u, d, U, nw, ct, mk & lim) for nw, ct, mk in batches[k]]
+                        uq = int(rng.integers(nqk))
+                        uu = int(rng.integers(U))
+                        if not np.array_equal(ctx.batch_read_user_feed(uq, uu), wants_k[uq][2][wants_k[uq][1][uu]:wants_k[uq][1][uu + 1]]):
+                            raise AssertionError(what + " batch %d: feed of user %d, query %d" % (k, uu, uq))
+                        if rng.random() < 0.4 and nqk <= 32:   # the union exchange message packed after the fact: every query's list is a filter of it
+                            wants = wants_k
                             per_user_max = max(int(np.max(sum((w[0] for w in wants), np.zeros(U, np.int64)))), 0)
                             u_pad, cap = U + int(rng.integers(0, 3)), int(sum(w[2].size for w in wants)) + 5
                             msg = torch.full((u_pad + 2 + 2 * cap,), -7, dtype=torch.int32, device=dev)
@@ -172,6 +248,11 @@ while time.time() < t_end:
                     prev = int(now - rng.integers(0, 3 * DAY)) if now > INT64_MIN + 4 * DAY else INT64_MIN
                     if not np.array_equal(ctx.expired_queue(prev, now), oracle.expired_queue(e, prev, now)):
                         raise AssertionError(what + " expired (%d, %d]" % (prev, now))
+                if rng.random() < 0.2 and n <= 300000:   # the archive chain (group min -> threshold -> whole groups in first-appearance order)
+                    a_now = int(rng.choice([T0, T0 - 100 * DAY, T0 - 119 * DAY, int(s[int(rng.integers(n))]), 2 ** 62, INT64_MIN + 5]))
+                    a_win = int(rng.choice([0, 3600 * 1000, 43200000, 30 * DAY, 2 ** 62]))
+                    if not np.array_equal(ctx.archive_queue(a_now, a_win), oracle.archive_queue_numpy(s, e, u, U, a_now, a_win)):
+                        raise AssertionError(what + " archive queue now %d window %d" % (a_now, a_win))
         cases += 1
     except Exception as exc:  # noqa: BLE001
         print("FAIL %s: %r" % (what, exc), flush=True)
