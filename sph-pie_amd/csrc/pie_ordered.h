@@ -1271,4 +1271,180 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
     }
 }
 
+// ---- the UNION form of a batch on the run (round 3; batches of <= 16 queries).  The staging records of k_ord_batch_scan — one per
+// position that ANY query selects, in position order, with the query bits — ARE the batch's union in (user, start, row) order.
+// So the chain behind the scan no longer works per query (round 2: a per-query count kernel, Q prefix scans, a per-query
+// compaction by ballot in the emit, Q summaries — six launches, 0.133 ms for 16 queries on the Zipf table):
+//   k_ord_prefix        ONE exclusive prefix, over the chunks' union counts (the single-scan form: one launch)
+//   k_ord_union_emit    copy role: every chunk's records -> urows / umlo behind the chunk's prefix (a lane per light chunk, heavy
+//                       chunks by whole waves, neighbours on different waves), per-query totals on the way;
+//                       user role: uoff[u] = prefix of the chunk that holds the user's segment start + the records before it
+//   k_ord_union_publish summary + per-query totals -> the batch's mapped host block
+// and the result is the same union (uoff / urows / umlo) the general batched pass returns: per-query lists, messages and request
+// fetches are produced from it by the same kernels.
+__global__ __launch_bounds__(256) void k_ord_union_emit(const long long* __restrict__ uoff_run, int n_users, long long n_ord, int chunk_shift,
+                                                        long long n_chunks, int n_q, const OrdUnion* __restrict__ ustage,
+                                                        const int* __restrict__ ucount, const int* __restrict__ unit_local,
+                                                        const long long* __restrict__ group_base, long long* __restrict__ uoff_out,
+                                                        int* __restrict__ urows, unsigned int* __restrict__ umlo, long long ucap,
+                                                        int copy_blocks, Summary* __restrict__ summary, unsigned int* __restrict__ mq_slots,
+                                                        int* __restrict__ zero_counts, long long zero_n)
+{
+    const int user_blocks = (int)gridDim.x - copy_blocks;
+    __shared__ long long soff[256];
+    __shared__ int wmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
+    if ((int)blockIdx.x >= user_blocks) {
+        const long long n_waves = (long long)copy_blocks * 4, wv = (long long)((int)blockIdx.x - user_blocks) * 4 + wave;
+        int tot[kOrdBatchMax]; // light chunks: this lane's count per query
+#pragma unroll
+        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
+        unsigned acc = 0;      // heavy chunks: lane q holds query q's count
+        // pass 1: a lane per chunk, 64 consecutive chunks per wave step: a chunk holds a handful of records
+        for (long long base = wv << 6; base < n_chunks; base += n_waves << 6) {
+            const long long ch = base + lane;
+            const int cnt = ch < n_chunks ? ucount[ch] : 0;
+            if (cnt > 0 && cnt <= kOrdChunkHeavy) {
+                const OrdUnion* rec = ustage + (ch << chunk_shift);
+                const long long dst = group_base[ch >> kOrdGroupShift] + unit_local[ch];
+                for (int j = 0; j < cnt; ++j) {
+                    const OrdUnion r = rec[j];
+                    if (dst + j < ucap) {
+                        urows[dst + j] = r.row;
+                        umlo[dst + j] = r.qsub & 0xFFFFu;
+                    }
+#pragma unroll
+                    for (int q = 0; q < kOrdBatchMax; ++q) tot[q] += (r.qsub >> q) & 1u;
+                }
+            }
+        }
+        // pass 2: the heavy chunks (a popular user's live rows: whole runs of full chunks), chunk ch by wave ch mod n_waves
+        for (long long c0 = wv; c0 < n_chunks; c0 += n_waves << 6) {
+            const long long ch = c0 + (long long)lane * n_waves;
+            const int cnt = ch < n_chunks ? ucount[ch] : 0;
+            unsigned long long todo = __ballot(cnt > kOrdChunkHeavy);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const long long lch = c0 + (long long)leader * n_waves;
+                const int lcnt = __shfl(cnt, leader, kWave);
+                const OrdUnion* lrec = ustage + (lch << chunk_shift);
+                const long long ldst = group_base[lch >> kOrdGroupShift] + unit_local[lch];
+                for (int j0 = 0; j0 < lcnt; j0 += 64) {
+                    unsigned qm = 0;
+                    if (j0 + lane < lcnt) {
+                        const OrdUnion r = lrec[j0 + lane];
+                        qm = r.qsub & 0xFFFFu;
+                        if (ldst + j0 + lane < ucap) {
+                            urows[ldst + j0 + lane] = r.row;
+                            umlo[ldst + j0 + lane] = qm;
+                        }
+                    }
+                    for (int q = 0; q < n_q; ++q) {
+                        const unsigned c = (unsigned)__popcll(__ballot((qm >> q) & 1u));
+                        if (lane == q) acc += c;
+                    }
+                }
+                todo &= todo - 1;
+            }
+        }
+        // the wave's per-query totals -> the spread counters
+#pragma unroll
+        for (int q = 0; q < kOrdBatchMax; ++q) {
+            int v = tot[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+            if (lane == q) acc += (unsigned)v;
+        }
+        if (lane < n_q && acc) atomicAdd(&mq_slots[(blockIdx.x & (kMqSlots - 1)) * kBatchMax + lane], acc);
+        return;
+    }
+    // user role: 255 users per block (thread 255 holds the next block's first user, for the bucket sizes)
+    const long long u = (long long)blockIdx.x * 255 + threadIdx.x;
+    long long my = 0;
+    if (u <= n_users) {
+        const long long qpos = uoff_run[u];
+        if (qpos >= n_ord) my = group_base[n_groups];
+        else {
+            const long long ch = qpos >> chunk_shift;
+            const OrdUnion* rec = ustage + (ch << chunk_shift);
+            int lo = 0, hi = ucount[ch];
+            while (lo < hi) { // staged in position order: the records before my segment start
+                const int mid = (lo + hi) >> 1;
+                if ((rec[mid].qsub >> 16) < ((unsigned)qpos & kOrdSubMask)) lo = mid + 1;
+                else hi = mid;
+            }
+            my = group_base[ch >> kOrdGroupShift] + unit_local[ch] + lo;
+        }
+        uoff_out[u] = my;
+    }
+    soff[threadIdx.x] = my;
+    __syncthreads();
+    int cnt = 0;
+    if (threadIdx.x < 255 && u < n_users) cnt = (int)(soff[threadIdx.x + 1] - soff[threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt = max(cnt, __shfl_xor(cnt, o, kWave));
+    if (lane == 0) wmax[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int bm = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (bm > 0) atomicMax(&stat_slots(summary)[blockIdx.x & (kStatSlots - 1)].max_count, (unsigned long long)bm);
+    }
+}
+
+// one block: the batch's summary (m = union rows, the largest union bucket, the pass's row statistics) and the per-query totals
+// into mapped host memory, seq last; the counters it read start the next batch clean
+__global__ __launch_bounds__(256) void k_ord_union_publish(Summary* __restrict__ summary, unsigned int* __restrict__ mq_slots, int n_q, long long ucap,
+                                                           BatchHost* __restrict__ host, unsigned long long seq)
+{
+    __shared__ unsigned int s_mq[4][kBatchMax];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        unsigned v[kMqSlots / 4];
+#pragma unroll
+        for (int i = 0; i < kMqSlots / 4; ++i) {
+            unsigned int* p = &mq_slots[(wave * (kMqSlots / 4) + i) * kBatchMax + lane];
+            v[i] = lane < n_q ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (lane < n_q) *p = 0;
+        }
+        unsigned tot = 0;
+#pragma unroll
+        for (int i = 0; i < kMqSlots / 4; ++i) tot += v[i];
+        s_mq[wave][lane] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    unsigned long long live = 0, amb = 0, cand = 0;
+    unsigned int chunk_max = 0;
+    sum_row_stats(summary, lane, live, amb, &cand, &chunk_max);
+    unsigned long long slot_max = stat_slots(summary)[lane].max_count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(slot_max, o, kWave);
+        slot_max = other > slot_max ? other : slot_max;
+    }
+    {
+        StatSlot* slot = stat_slots(summary) + lane;
+        slot->max_count = 0;
+        slot->live = 0;
+        slot->amb = 0;
+        slot->cand = 0;
+        slot->chunk_max = 0;
+    }
+    host->mq[lane] = (unsigned long long)s_mq[0][lane] + s_mq[1][lane] + s_mq[2][lane] + s_mq[3][lane];
+    if (lane == 0) {
+        Summary out{};
+        out.m = summary->m;
+        out.max_count = (unsigned int)slot_max;
+        out.cand = cand;
+        out.chunk_max = chunk_max;
+        out.bad_rows = 0;
+        out.n_over = (long long)out.m > ucap ? 1u : 0u; // the union outgrew the result arrays: the host reruns the queries
+        host->s = out;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 } // namespace pie

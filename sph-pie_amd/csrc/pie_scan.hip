@@ -109,6 +109,7 @@ struct BatchSlot {
     bool in_flight = false, k2_pending = false, have_result = false;
     int dshift = 4;                    // union bucket capacity (log2) the batch ran with
     bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no tail, nothing rides
+    bool ord_union = false;            // ... in its union form (<= 16 queries): the result is the union, as on the general pass
     bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
     bool fine_key = false;
     unsigned long long seq = 0;
@@ -303,6 +304,7 @@ struct pie_ctx {
                                 // live rows, the safe default), 3 = eight consecutive chunks per wave (live rows spread evenly: a few
                                 // per cent faster); follows the densest-chunk statistic of the last pass, see choose_run_shift
     bool batch_poor = false;    // union buckets overflowed at their largest capacity (skewed users): batches run as single scans
+    bool ord_lists_only = false; // a batch's union on the ordered run outgrew the result arrays: its batches take the per-query chain
     bool run_shift_pinned = false; // PIE_RUN_SHIFT=0..3 pins it (A/B runs)
     bool last_was_batch = false; // pie_stats_get describes the last finished batch rather than the last single scan
     unsigned long long bseq_counter = 0;
@@ -645,6 +647,7 @@ int ensure_capacity(pie_ctx* c, long long n, int n_users, long long keep_rows = 
         // clustering): a few new rows do not change the picture, and one scan corrects it if they do
         c->live_frac = -1;
         c->batch_poor = false;
+        c->ord_lists_only = false;
         if (!c->run_shift_pinned) c->run_shift = 0;
         c->hot_bucket = false;
         c->clustered = false;
@@ -1259,6 +1262,8 @@ int ord_respread(pie_ctx* c, size_t k, long long row0, int n_users)
 
 long long batch_users_stride(const pie_ctx* c);
 long long batch_out_stride(const pie_ctx* c);
+size_t batch_ucap(const pie_ctx* c);
+size_t batch_mq_bytes();
 
 // the batched form's per-query arrays (allocated at the first ordered batch)
 int ord_batch_alloc(pie_ctx* c)
@@ -1271,16 +1276,16 @@ int ord_batch_alloc(pie_ctx* c)
                     hipMalloc(&o.bq_gsum, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
                     hipMalloc(&o.bq_gbase, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
                     hipMalloc(&o.bq_ctl, (size_t)kOrdBatchMax * sizeof(OrdCtl)) == hipSuccess && hipMalloc(&o.bq_runflag, (units / 32 + 2) * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess &&
-                    hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes()) == hipSuccess;
+                    hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes()) == hipSuccess &&
+                    hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes()) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
         return PIE_E_NOMEM;
     }
     PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kOrdBatchMax * sizeof(OrdCtl), c->stream));
-    PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
-    PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, (size_t)kBatchMax * ord_sum_bytes(), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes(), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes(), c->stream));
     return PIE_OK;
 }
 
@@ -1350,6 +1355,55 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
                        b.offsets + (long long)q0 * batch_users_stride(c), b.counts_ord + (long long)q0 * batch_users_stride(c), batch_users_stride(c), copy_blocks,
                        sum0, sum_stride, uc_other, o.units_cap, o.bq_runflag, o.bq_count);
     hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)nq), dim3(64), 0, s, sum0, b.h_sum_dev + q0, b.seq, sum_stride);
+}
+
+// the union form (<= kOrdBatchMax queries): scan, ONE prefix, emit, publish — see pie_ordered.h
+void launch_ordered_union(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
+{
+    OrderedRun& o = c->ord;
+    const int bi = (int)(&b - c->bslot);
+    char* sums = o.bq_sum[bi];
+    int* uc = o.unit_count[o.uc_next];
+    int* uc_other = o.unit_count[o.uc_next ^ 1];
+    o.uc_next ^= 1;
+    OrdUnion* ustage = reinterpret_cast<OrdUnion*>(c->slot[bi].sel);
+    OrdBatchArgs a;
+    a.n_q = b.n_q;
+    const unsigned impossible = fine ? 0xFFu : 0xFFFFu;
+    unsigned mk = impossible;
+    for (int q = 0; q < b.n_q; ++q) {
+        a.q[q].now = qs[q].now;
+        a.q[q].cutoff = qs[q].cutoff;
+        a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));
+        a.q[q].now_key = b.fallback[q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
+        a.q[q].pad = 0;
+        if (a.q[q].now_key < mk) mk = a.q[q].now_key;
+    }
+    a.min_key = mk;
+    const int chunk_shift = 9;
+    const long long n_chunks = (o.n + (1 << chunk_shift) - 1) >> chunk_shift;
+    Summary* sum0 = reinterpret_cast<Summary*>(sums);
+    unsigned int* mq_slots = reinterpret_cast<unsigned int*>(sums + (size_t)kBatchMax * ord_sum_bytes()); // behind the per-query summaries: its own, zero between batches
+    if (fine) {
+        const int gm = o.grid_mult;
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * gm ? (n_chunks + 3) / 4 : (long long)c->n_cus * gm;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
+    } else {
+        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
+    }
+    if (b.ev_index >= 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
+    long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
+    if (n_groups < 1) n_groups = 1;
+    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
+    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, uc, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase, o.bq_ctl, sum0, 0LL, 0LL, 0LL);
+    const int copy_blocks = c->n_cus * 8;
+    const int user_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
+    hipLaunchKernelGGL(k_ord_union_emit, dim3((unsigned)(copy_blocks + user_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks, b.n_q,
+                       ustage, uc, o.bq_local, o.bq_gbase, b.uoff, b.urows, b.umlo, (long long)batch_ucap(c), copy_blocks, sum0, mq_slots, uc_other, o.units_cap);
+    hipLaunchKernelGGL(k_ord_union_publish, dim3(1), dim3(256), 0, s, sum0, mq_slots, b.n_q, (long long)batch_ucap(c), b.bh_dev, b.seq);
 }
 
 // should this query run on the ordered run?  (mode 1: where the general path is weak)
@@ -1949,16 +2003,25 @@ bool batch_supported(const pie_ctx* c)
 }
 
 // the arrays of the batched pass: union bucket slots + the union result per batch slot, three rotating spans
+// entries of the union result arrays: the bucket slots of the general pass, or a sixteenth of the rows (a batch on the ordered
+// run has no slot bound: a head user's union is as long as its live rows)
+size_t batch_ucap(const pie_ctx* c)
+{
+    const size_t slots = (size_t)c->cap_users << c->bdshift, rows16 = (size_t)c->cap_rows / 16 + 4096;
+    return slots > rows16 ? slots : rows16;
+}
+
 int ensure_batch(pie_ctx* c)
 {
     if (c->batch_alloc) return PIE_OK;
     const size_t slots = (size_t)c->cap_users << c->bdshift;
+    const size_t ucap = batch_ucap(c);
     for (BatchSlot& b : c->bslot) {
         PIE_HIP(c, hipMalloc(&b.direct, slots * sizeof(BktRec)));
         PIE_HIP(c, hipMalloc(&b.direct_hi, slots * 4));
         PIE_HIP(c, hipMalloc(&b.uoff, ((size_t)c->cap_users + 2) * 8));
-        PIE_HIP(c, hipMalloc(&b.urows, slots * 4));
-        PIE_HIP(c, hipMalloc(&b.umlo, slots * 4));
+        PIE_HIP(c, hipMalloc(&b.urows, ucap * 4));
+        PIE_HIP(c, hipMalloc(&b.umlo, ucap * 4));
         PIE_HIP(c, hipMalloc(&b.umhi, slots * 4));
     }
     for (char*& sp : c->bspan) {
@@ -2084,6 +2147,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; b.list_ok[q] = false; }
     b.ev_index = -1;
     b.ordered = false;
+    b.ord_union = false;
     const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c);
     b.unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
     // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
@@ -2160,15 +2224,18 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column per 16 queries
         rc = ord_batch_alloc(c);
         if (rc) return rc;
-        rc = ensure_lists(c, b, n_q);
+        b.ord_union = n_q <= kOrdBatchMax && !c->ord_lists_only;
+        rc = b.ord_union ? ensure_batch(c) : ensure_lists(c, b, n_q);
         if (rc) return rc;
         BatchSlot& prev = c->bslot[c->b_next ^ 1];
         if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
         b.seq = ++c->bseq_counter;
         c->scans_begun++;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
-        for (int q0 = 0; q0 < n_q; q0 += kOrdBatchMax)
-            launch_ordered_batch(c, b, s, qs, fine, q0, n_q - q0 < kOrdBatchMax ? n_q - q0 : kOrdBatchMax);
+        if (b.ord_union) launch_ordered_union(c, b, s, qs, fine);
+        else
+            for (int q0 = 0; q0 < n_q; q0 += kOrdBatchMax)
+                launch_ordered_batch(c, b, s, qs, fine, q0, n_q - q0 < kOrdBatchMax ? n_q - q0 : kOrdBatchMax);
         PIE_HIP(c, hipGetLastError());
         b.ordered = true;
         b.k2_pending = false;
@@ -2386,9 +2453,10 @@ int batch_finish(pie_ctx* c, int* ready_out)
         // ONE summary for the batch; the ordered run's batched form one per query.
         timespec t0{};
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const int n_wait = b.ordered ? b.n_q : 1;
+        const bool per_query = b.ordered && !b.ord_union;
+        const int n_wait = per_query ? b.n_q : 1;
         for (int q = 0; q < n_wait; ++q) {
-            volatile unsigned long long* seq = b.ordered ? &b.h_sum[q].seq : &b.bh->seq;
+            volatile unsigned long long* seq = per_query ? &b.h_sum[q].seq : &b.bh->seq;
             unsigned long long spins = 0;
             while (*seq != b.seq) {
                 __builtin_ia32_pause();
@@ -2409,7 +2477,7 @@ int batch_finish(pie_ctx* c, int* ready_out)
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         bool overflow = false;
-        if (b.ordered) {
+        if (per_query) {
             for (int q = 0; q < b.n_q; ++q) {
                 b.last[q] = b.h_sum[q].s;
                 if (b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
@@ -2427,17 +2495,18 @@ int batch_finish(pie_ctx* c, int* ready_out)
                 b.last[q].m = b.bh->mq[q];
                 if (overflow) b.fallback[q] = true;
             }
-            if (us.n_over > 0) {
+            if (us.n_over > 0 && b.ordered) c->ord_lists_only = true; // the union outgrew its arrays on the run: such batches take the per-query chain
+            else if (us.n_over > 0) {
                 if (c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
                 else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
             }
             b.union_part = !overflow;
             b.union_ok = !overflow;
             for (int q = 0; q < b.n_q; ++q) b.union_ok = b.union_ok && !b.fallback[q];
-            choose_run_shift(c, us.cand, us.chunk_max, b.fine_key);
+            if (!b.ordered) choose_run_shift(c, us.cand, us.chunk_max, b.fine_key);
         }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
-        if (b.ordered && (b.msg_kind == 1 || b.msg_counts)) {
+        if (per_query && (b.msg_kind == 1 || b.msg_counts)) {
             // the ordered chain writes no messages: pack them from the finished lists (the queries that fall back pack their own)
             all_ready = false;
             for (int q = 0; q < b.n_q; ++q) {
@@ -2469,7 +2538,7 @@ int batch_finish(pie_ctx* c, int* ready_out)
     c->last_was_batch = true;
     for (int q = 0; q < b.n_q; ++q)
         if (b.last[q].bad_rows) return fail(c, PIE_E_INVAL, "query %d: %u selected rows carry a user id outside [0, %d)", q, b.last[q].bad_rows, c->n_users);
-    if (!b.ordered && (b.msg_kind == 1 || b.msg_counts)) {
+    if ((!b.ordered || b.ord_union) && (b.msg_kind == 1 || b.msg_counts)) {
         // per-query messages of a batch on the general pass: the lists are materialised from the union, then packed
         all_ready = false;
         int list[kBatchMax], n_list = 0;
@@ -2486,8 +2555,8 @@ int batch_finish(pie_ctx* c, int* ready_out)
         }
         PIE_HIP(c, hipGetLastError());
     }
-    if (b.msg_kind == 2 && !b.union_ok) {
-        // the tail could not write the whole union (queries fell back, or the batch ran on the ordered run): merged from the lists
+    if (b.msg_kind == 2 && (!b.union_ok || b.ordered)) {
+        // no tail wrote the message (the batch ran on the ordered run: copied from its union; or queries fell back: merged from the lists)
         all_ready = false;
         int rc = batch_pack_union(c, b, b.msg, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
         if (rc) return rc;
@@ -3243,9 +3312,18 @@ int pie_batch_read_user_feed(pie_ctx* c, int qi, int32_t user, int32_t* idx_out,
         PIE_HIP(c, hipStreamSynchronize(c->stream));
         const size_t ku = (size_t)(off[1] - off[0]);
         if (ku == 0) return PIE_OK;
-        int rows[1 << kUnionShiftMax];
-        unsigned masks[1 << kUnionShiftMax];
-        if (ku > (size_t)(1 << kUnionShiftMax)) return fail(c, PIE_E_STATE, "union bucket of %zu rows", ku);
+        int rows_s[1 << kUnionShiftMax];
+        unsigned masks_s[1 << kUnionShiftMax];
+        std::vector<int> rows_h;
+        std::vector<unsigned> masks_h;
+        int* rows = rows_s;
+        unsigned* masks = masks_s;
+        if (ku > (size_t)(1 << kUnionShiftMax)) { // a batch on the ordered run: a head user's union is as long as its live rows
+            rows_h.resize(ku);
+            masks_h.resize(ku);
+            rows = rows_h.data();
+            masks = masks_h.data();
+        }
         PIE_HIP(c, hipMemcpyAsync(rows, b.urows + off[0], ku * 4, hipMemcpyDeviceToHost, c->stream));
         PIE_HIP(c, hipMemcpyAsync(masks, (qi >= 32 ? b.umhi : b.umlo) + off[0], ku * 4, hipMemcpyDeviceToHost, c->stream));
         PIE_HIP(c, hipStreamSynchronize(c->stream));

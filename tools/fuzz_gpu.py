@@ -181,7 +181,7 @@ while time.time() < t_end:
                             ctx.synchronize()
                             a = t.cpu().numpy()
                             mu = int(a[up + 1])
-                            if un is not None and not ready:
+                            if un is not None and not ready and not (ctx.stats()["k1_variant"] & 0x2000):   # (on the ordered run it is copied from the union)
                                 raise AssertionError(what + " batch %d: has a union but its message was not written by the batch" % k)
                             if mu >= 0:
                                 kk = min(mu, cp)
