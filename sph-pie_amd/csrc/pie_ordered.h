@@ -53,6 +53,13 @@ struct OrdCtl {
     unsigned int pad[3];
 };
 
+// spare slots of the run carry end = PIE_END_NONE (never live, key 0 under every key base — a memset 0 would read as a live row
+// once the table's `end` values are all <= 0: ADVICE r02)
+__global__ __launch_bounds__(256) void k_fill_ll(long long* __restrict__ p, long long n, long long v)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // out_idx of the all-selecting scan -> the run's columns.  Entry i of the sorted list belongs to user u = pay[row].user and is
 // its (i - off[u])-th row; it goes to position uoff[u] + that rank: every user's segment starts at uoff[u] and ends in spare
 // slots (see k_ord_append).

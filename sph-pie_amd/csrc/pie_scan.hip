@@ -1150,7 +1150,7 @@ int build_ordered(pie_ctx* c)
     PIE_HIP(c, hipMemsetAsync(o.bhead, 0xFF, ((size_t)seg_users + 1) * 4, s));
     PIE_HIP(c, hipMemsetAsync(o.pos, 0xFF, (size_t)o.cap * 4, s));
     PIE_HIP(c, hipMemsetAsync(o.pay, 0xFF, padded * sizeof(OrdRec), s)); // filler: discipline -1, never selected
-    PIE_HIP(c, hipMemsetAsync(o.end, 0, padded * 8, s));
+    hipLaunchKernelGGL(k_fill_ll, dim3(c->n_cus * 8), dim3(256), 0, s, o.end, (long long)padded, (long long)INT64_MIN);
     PIE_HIP(c, hipMemsetAsync(o.key, 0, padded * sizeof(lkey_t), s));
     PIE_HIP(c, hipMemsetAsync(o.fkey, 0, padded * sizeof(fkey_t), s));
     PIE_HIP(c, hipMemsetAsync(o.unit_count[0], 0, (size_t)o.units_cap * 4, s));
@@ -1236,7 +1236,7 @@ int ord_respread(pie_ctx* c, size_t k, long long row0, int n_users)
     }
     PIE_HIP(c, hipMemcpyAsync(o.alt_uoff, seg.data(), ((size_t)seg_users + 1) * 8, hipMemcpyHostToDevice, s));
     PIE_HIP(c, hipMemsetAsync(o.alt_pay, 0xFF, padded * sizeof(OrdRec), s));
-    PIE_HIP(c, hipMemsetAsync(o.alt_end, 0, padded * 8, s));
+    hipLaunchKernelGGL(k_fill_ll, dim3(c->n_cus * 8), dim3(256), 0, s, o.alt_end, (long long)padded, (long long)INT64_MIN);
     PIE_HIP(c, hipMemsetAsync(o.alt_key, 0, padded * sizeof(lkey_t), s));
     PIE_HIP(c, hipMemsetAsync(o.alt_fkey, 0, padded * sizeof(fkey_t), s));
     hipLaunchKernelGGL(k_ord_respread, dim3(c->n_cus * 16), dim3(256), 0, s, o.n, seg_users, o.uoff, o.ufill, o.alt_uoff, o.pay, o.end, o.key,

@@ -488,3 +488,35 @@ def test_ordered_batch_pipelined_with_messages_and_changes(pie, oracle):
             got = ctx.scan_batch(qs)
             for qi, (nw, ct, mk) in enumerate(qs):
                 assert_same(got[qi], oracle.scan(s, e, u, d, U, nw, ct, mk & lim), f"changed step {step} q{qi}")
+
+
+def test_ordered_run_spare_slots_are_never_live(pie, oracle):
+    """a table whose `end` values are all <= 0 puts the key base below zero; the run's spare slots (a sixteenth of
+    the positions + a few per user) must still read as dead — they carry PIE_END_NONE, not 0 — so the live rows a scan reports
+    are exactly the table's, before and after a key refit, and the answers equal the oracle's."""
+    n, U, D = 200000, 700, 8
+    s, e, u, d = oracle.gen(SEED + 99, n, 0, n, U, D, 1)
+    shift = int(e.max()) + 5 * DAY
+    s, e = s - shift, e - shift           # every end below zero
+    assert e.max() < 0
+    cols = (s, e, u, d)
+    with pie.PieScan(0) as ctx:
+        ctx.load_columns(*cols, U)
+        ctx.set_ordered_run(2)
+        ctx.set_disciplines(ALL, D)
+        now = int(np.sort(e)[int(n * 0.97)])
+        for rnd in range(3):
+            got = ctx.scan(now, INT64_MIN)
+            assert_same(got, oracle.scan(s, e, u, d, U, now, INT64_MIN, (1 << D) - 1))
+            st = ctx.stats()
+            assert st["k1_variant"] & 0x2000
+            assert st["live"] == int(np.count_nonzero(e > now)), (rnd, st["live"])
+            if rnd == 0:   # re-end some rows far below everything: the key column is refitted from the run's own `end`
+                rows = np.arange(0, n, 97, dtype=np.int32)
+                e = e.copy()
+                e[rows] = e[rows] - 400 * DAY
+                ctx.set_end(rows, e[rows])
+        # a `now` below every end: every position is a candidate, spare slots included; still only the table's rows are live
+        got = ctx.scan(int(e.min()) - 1, INT64_MIN)
+        assert_same(got, oracle.scan(s, e, u, d, U, int(e.min()) - 1, INT64_MIN, (1 << D) - 1))
+        assert ctx.stats()["live"] == n
