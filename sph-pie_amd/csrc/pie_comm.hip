@@ -106,7 +106,8 @@ struct pie_comm {
     std::vector<hipStream_t> xstream;                 // local index -> exchange stream
     std::vector<int*> umsg[kSets], ugath[kSets];      // [set][local index]: this rank's union message / the gathered ones [world][UL]
     std::vector<hipEvent_t> ev_ready[kSets], ev_done[kSets];
-    int* h_mu[kSets] = {nullptr, nullptr, nullptr, nullptr}; // pinned: [local index][world] the Mu word of every gathered message
+    int* h_mu[kSets] = {nullptr, nullptr, nullptr, nullptr}; // mapped pinned: [local index][world] the Mu word of every gathered message
+    int* h_mu_dev[kSets] = {nullptr, nullptr, nullptr, nullptr};
     long long u_cap = 0, UL = 0;   // union rows per message, words per message (u_pad + 2 + mask_words' share)
     int u_words = 2;               // words per union row in a message: row + one or two mask words
     long long begun = 0, finished = 0, collected = 0;  // steps begun / exchanges issued / exchanges collected
@@ -259,7 +260,7 @@ int pie_comm_create_rank(const void* id_128, int32_t rank, int32_t world, int32_
 {
     if (!comm_out) return cfail(nullptr, PIE_E_INVAL, "comm_out is NULL");
     *comm_out = nullptr;
-    if (!id_128 || world < 1 || rank < 0 || rank >= world) return cfail(nullptr, PIE_E_INVAL, "bad id / rank %d of %d", rank, world);
+    if (!id_128 || world < 1 || world > 64 || rank < 0 || rank >= world) return cfail(nullptr, PIE_E_INVAL, "bad id / rank %d of %d (1..64 ranks)", rank, world);
     char why[200];
     if (!load_rccl(why, sizeof why)) return cfail(nullptr, PIE_E_NODEVICE, "%s", why);
     pie_comm* c = new_comm(world, 1);
@@ -347,24 +348,34 @@ int pie_comm_gen_synthetic_sharded(pie_comm* c, uint64_t seed, int64_t n_total, 
 
 namespace {
 
+// the Mu word of every gathered message (world of them, rank_stride words apart) into mapped host memory: no copy node behind
+// the exchange (a 2-D copy call cost more host time than the whole step's launches)
+__global__ void k_pick_words(const int* __restrict__ gath, long long rank_stride, long long word, int world, int* __restrict__ out)
+{
+    const int r = (int)threadIdx.x;
+    if (r < world) __hip_atomic_store(&out[r], gath[(long long)r * rank_stride + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the direct exchange of one fixed-length message per rank: inside one group every local rank posts one send and one
 // receive per peer (each message crosses its own xGMI link once); its own message is a local copy on the same stream
 int exchange(pie_comm* c, const std::vector<int*>& msg, const std::vector<int*>& gath, size_t count, size_t rank_stride, const std::vector<hipStream_t>& streams)
 {
-    PIE_CNCCL(c, g_rccl.GroupStart());
-    for (int k = 0; k < c->n_local; ++k) {
-        const int me = c->rank_of[k];
-        for (int p = 0; p < c->world; ++p) {
-            if (p == me) continue;
-            ncclResult_t r1 = g_rccl.Send(msg[k], count, kNcclInt32, p, c->comm[k], streams[k]);
-            ncclResult_t r2 = g_rccl.Recv(gath[k] + (size_t)p * rank_stride, count, kNcclInt32, p, c->comm[k], streams[k]);
-            if (r1 != 0 || r2 != 0) {
-                (void)g_rccl.GroupEnd();
-                return cfail(c, PIE_E_HIP, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(r1 != 0 ? r1 : r2));
+    if (c->world > 1) {
+        PIE_CNCCL(c, g_rccl.GroupStart());
+        for (int k = 0; k < c->n_local; ++k) {
+            const int me = c->rank_of[k];
+            for (int p = 0; p < c->world; ++p) {
+                if (p == me) continue;
+                ncclResult_t r1 = g_rccl.Send(msg[k], count, kNcclInt32, p, c->comm[k], streams[k]);
+                ncclResult_t r2 = g_rccl.Recv(gath[k] + (size_t)p * rank_stride, count, kNcclInt32, p, c->comm[k], streams[k]);
+                if (r1 != 0 || r2 != 0) {
+                    (void)g_rccl.GroupEnd();
+                    return cfail(c, PIE_E_HIP, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(r1 != 0 ? r1 : r2));
+                }
             }
         }
+        PIE_CNCCL(c, g_rccl.GroupEnd());
     }
-    PIE_CNCCL(c, g_rccl.GroupEnd());
     for (int k = 0; k < c->n_local; ++k) {
         PIE_CHIP(c, hipSetDevice(c->device[k]));
         PIE_CHIP(c, hipMemcpyAsync(gath[k] + (size_t)c->rank_of[k] * rank_stride, msg[k], count * 4, hipMemcpyDeviceToDevice, streams[k]));
@@ -418,7 +429,8 @@ int ensure_step_buffers(pie_comm* c, int n_q, long long u_pad, long long cap)
     if (c->xstream.size() != (size_t)c->n_local) c->xstream.assign((size_t)c->n_local, nullptr);
     for (int s = 0; s < pie_comm::kSets; ++s) {
         if (c->ev_ready[s].size() != (size_t)c->n_local) { c->ev_ready[s].assign((size_t)c->n_local, nullptr); c->ev_done[s].assign((size_t)c->n_local, nullptr); }
-        PIE_CHIP(c, hipHostMalloc(&c->h_mu[s], (size_t)c->n_local * (size_t)c->world * 4, hipHostMallocDefault));
+        PIE_CHIP(c, hipHostMalloc(&c->h_mu[s], (size_t)c->n_local * (size_t)c->world * 4, hipHostMallocMapped));
+        PIE_CHIP(c, hipHostGetDevicePointer((void**)&c->h_mu_dev[s], c->h_mu[s], 0));
     }
     for (int k = 0; k < c->n_local; ++k) {
         PIE_CHIP(c, hipSetDevice(c->device[k]));
@@ -565,8 +577,8 @@ int pie_comm_step_finish(pie_comm* c, size_t* m_out)
     if (rc) return rc;
     for (int k = 0; k < c->n_local; ++k) {
         PIE_CHIP(c, hipSetDevice(c->device[k]));
-        PIE_CHIP(c, hipMemcpy2DAsync(c->h_mu[s] + (size_t)k * (size_t)c->world, 4, c->ugath[s][k] + (size_t)c->u_pad + 1, (size_t)c->UL * 4, 4,
-                                     (size_t)c->world, hipMemcpyDeviceToHost, c->xstream[k]));
+        hipLaunchKernelGGL(k_pick_words, dim3(1), dim3(64), 0, c->xstream[k], c->ugath[s][k], (long long)c->UL, (long long)c->u_pad + 1, c->world,
+                           c->h_mu_dev[s] + (size_t)k * (size_t)c->world);
         PIE_CHIP(c, hipEventRecord(c->ev_done[s][k], c->xstream[k]));
     }
     if (m_out) memcpy(m_out, m.data(), m.size() * sizeof(size_t));
