@@ -178,8 +178,9 @@ int pie_host_free(pie_ctx *ctx, void *host_ptr);
 /* ---- batched scan: many feed requests, one table pass (SURVEY.md section 7 "batch many queries per launch"; the
  * north_star's "calendarFeed per-request loop -> batched GPU scan").  Every query has its own `now` (the request's clock,
  * server/sessionStore.js:67 samples one per scan), `cutoff` (server/calendarFeed.js:33-38) and discipline mask
- * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Up to two batches may be in flight
- * (begin(i+1) before finish(i)), like two scans; single scans and batches do not mix in flight.
+ * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Up to three batches may be in
+ * flight (begin(i+1), begin(i+2) before finish(i): the tail of batch i rides in the launch of batch i+1, and with a third batch
+ * queued the GPU never waits for the host to react to a summary); single scans and batches do not mix in flight.
  *
  * The PRIMARY result of a batch is the UNION of its queries' selections: per user the rows that ANY query selected, in
  * (start, row) order, with a query mask per row —
@@ -202,7 +203,7 @@ int pie_scan_batch_begin(pie_ctx *ctx, const pie_query *queries, int n_q);
 int pie_scan_batch_finish(pie_ctx *ctx, size_t *m_out);
 /* begin + finish */
 int pie_scan_batch(pie_ctx *ctx, const pie_query *queries, int n_q, size_t *m_out);
-/* The union of the last finished batch: device pointers (valid until the batch after the next begins; NULL when the batch has
+/* The union of the last finished batch: device pointers (valid until three more batches have begun; NULL when the batch has
  * no union, see above), or host copies (masks_out: one 64-bit mask per union row; PIE_E_CAPACITY if cap < Mu, PIE_E_STATE if
  * the batch has no union). */
 int pie_batch_union_device_ptrs(pie_ctx *ctx, void **uoff_dev /* int64[U+1] */, void **rows_dev /* int32[Mu] */,

@@ -421,7 +421,7 @@ class PieScan:
         return arr
 
     def scan_batch_begin(self, queries):
-        """queries: sequence of (now, cutoff, mask), at most PIE_BATCH_MAX.  Up to two batches may be in flight."""
+        """queries: sequence of (now, cutoff, mask), at most PIE_BATCH_MAX.  Up to three batches may be in flight."""
         arr = self._queries(queries)
         self._check(self._lib.pie_scan_batch_begin(self._ctx, arr, len(queries)))
         self._batches = getattr(self, "_batches", [])
@@ -522,16 +522,16 @@ class PieScan:
         self._check(self._lib.pie_batch_result_device_ptrs(self._ctx, int(qi), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def scan_batch_pipelined(self, k, queries):
-        """k batches of the same queries with two in flight.  -> list of M of the last batch."""
-        ms = []
-        if k <= 0:
-            return ms
-        self.scan_batch_begin(queries)
-        for i in range(k):
-            if i + 1 < k:
+    def scan_batch_pipelined(self, k, queries, depth=3):
+        """k batches of the same queries with up to `depth` (<= 3) in flight: the next launch is queued before the host waits for
+        a summary.  -> list of M of the last batch."""
+        ms, begun, done = [], 0, 0
+        while done < k:
+            while begun < k and begun - done < depth:
                 self.scan_batch_begin(queries)
+                begun += 1
             ms = self.scan_batch_finish()
+            done += 1
         return ms
 
     def result_device_ptrs(self):

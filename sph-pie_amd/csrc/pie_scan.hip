@@ -101,6 +101,12 @@ struct Slot {
     int ev_index = -1; // index into the event ring, -1 = not profiled
 };
 
+// Batches in flight: three.  With two, begin(i + 2) has to wait for finish(i), whose summary arrives half-way through launch i + 1
+// (the tail of batch i rides there): the host then has the second half of ONE launch to prepare and queue the next, and every
+// microsecond it is late the GPU idles (8 - 12 us per 54 us launch at 64 queries per batch, rocprofv3 timeline).  With three
+// the next launch is always queued before the host waits.
+constexpr int kBatchSlots = 3;
+
 // everything one batch of queries owns (see pie_kernels.h "batched scan").  The primary result of a batch on the general pass
 // is the UNION (uoff / urows / umlo / umhi); per-query lists are materialised from it on request, or produced directly by the
 // paths that work per query (fallback scans on the general path, a batch on the ordered run).
@@ -288,7 +294,7 @@ struct pie_ctx {
     OrderedRun ord;
     bool ord_building = false;  // the scan being begun is the ordered run's build
     Slot slot[2];
-    BatchSlot bslot[2];         // batched scans (pie_scan_batch_begin): two batches may be in flight, like two scans
+    BatchSlot bslot[kBatchSlots]; // batched scans (pie_scan_batch_begin): up to three batches may be in flight
     char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating batch spans (batch_span_bytes each)
     long long* d_mat_tile = nullptr;   // materialisation scratch: [kBatchMax][tiles + 1] tile sums / prefixes
     unsigned int* d_mat_qmax = nullptr; // ... [kBatchMax] largest per-user count
@@ -1306,7 +1312,7 @@ bool ordered_batch_wanted(const pie_ctx* c)
 void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs_all, bool fine, int q0, int nq)
 {
     OrderedRun& o = c->ord;
-    const int bi = (int)(&b - c->bslot);
+    const int bi = (int)(&b - c->bslot) & 1; // scratch (staging, device summaries) of two sets: chains run one after the other in the stream
     char* sums = o.bq_sum[bi] + (size_t)q0 * ord_sum_bytes();
     const pie_query* qs = qs_all + q0;
     int* uc = o.unit_count[o.uc_next];
@@ -1361,7 +1367,7 @@ void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
 void launch_ordered_union(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
 {
     OrderedRun& o = c->ord;
-    const int bi = (int)(&b - c->bslot);
+    const int bi = (int)(&b - c->bslot) & 1;
     char* sums = o.bq_sum[bi];
     int* uc = o.unit_count[o.uc_next];
     int* uc_other = o.unit_count[o.uc_next ^ 1];
@@ -2054,7 +2060,7 @@ int ensure_lists(pie_ctx* c, BatchSlot& b, int n_q)
 BatchSlot* oldest_batch(pie_ctx* c)
 {
     if (c->b_flight == 0) return nullptr;
-    return &c->bslot[c->b_flight == 2 ? c->b_next : (c->b_next ^ 1)];
+    return &c->bslot[(c->b_next + kBatchSlots - c->b_flight) % kBatchSlots];
 }
 
 void fill_tail_args(pie_ctx* c, BatchSlot& b, UnionTailArgs& t)
@@ -2129,7 +2135,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (!qs || n_q < 1 || n_q > kBatchMax) return fail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", kBatchMax, n_q);
     if (c->n_flight) return fail(c, PIE_E_STATE, "a single scan is in flight: finish it before beginning a batch");
-    if (c->b_flight >= 2) return fail(c, PIE_E_STATE, "two batches are already in flight: call pie_scan_batch_finish first");
+    if (c->b_flight >= kBatchSlots) return fail(c, PIE_E_STATE, "%d batches are already in flight: call pie_scan_batch_finish first", kBatchSlots);
     if (c->key_rebuild && c->b_flight == 0) {
         int rc = build_keys(c, 0, true);
         if (rc) return rc;
@@ -2178,7 +2184,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         b.in_flight = true;
         b.k2_pending = false;
         c->b_flight++;
-        c->b_next ^= 1;
+        c->b_next = (c->b_next + 1) % kBatchSlots;
         return PIE_OK;
     }
     if (c->bdshift_want > c->bdshift && c->b_flight == 0 && c->batch_alloc) {
@@ -2227,8 +2233,8 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         b.ord_union = n_q <= kOrdBatchMax && !c->ord_lists_only;
         rc = b.ord_union ? ensure_batch(c) : ensure_lists(c, b, n_q);
         if (rc) return rc;
-        BatchSlot& prev = c->bslot[c->b_next ^ 1];
-        if (c->b_flight == 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
+        BatchSlot& prev = c->bslot[(c->b_next + kBatchSlots - 1) % kBatchSlots];
+        if (c->b_flight >= 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
         b.seq = ++c->bseq_counter;
         c->scans_begun++;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
@@ -2241,7 +2247,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         b.k2_pending = false;
         b.in_flight = true;
         c->b_flight++;
-        c->b_next ^= 1;
+        c->b_next = (c->b_next + 1) % kBatchSlots;
         return PIE_OK;
     }
     // spans: this batch's and the one its tail zeroes
@@ -2252,8 +2258,8 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     const int plan = fine ? 3 : 2;
     b.k1_blocks = c->plan_blocks[plan];
     c->scans_begun++;
-    BatchSlot& other = c->bslot[c->b_next ^ 1];
-    const bool tail_waits = c->b_flight == 1 && other.in_flight && other.k2_pending && !other.ordered;
+    BatchSlot& other = c->bslot[(c->b_next + kBatchSlots - 1) % kBatchSlots]; // the batch begun just before this one
+    const bool tail_waits = c->b_flight >= 1 && other.in_flight && other.k2_pending && !other.ordered;
     const bool ride = tail_waits && !c->no_ride;
     if (tail_waits && !ride) launch_batch_k2(c, other, s);
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
@@ -2295,7 +2301,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     b.k2_pending = true;
     b.in_flight = true;
     c->b_flight++;
-    c->b_next ^= 1;
+    c->b_next = (c->b_next + 1) % kBatchSlots;
     return PIE_OK;
 }
 

@@ -564,3 +564,30 @@ def test_requests_of_a_batch_fetched_together(gpu_ctx, oracle):
     # too small a buffer: refused with the size it needs
     with pytest.raises(Exception):
         gpu_ctx.batch_fetch_requests(qis, users, cap_rows=3)
+
+
+def test_three_batches_in_flight(gpu_ctx, oracle, pie):
+    """Up to three batches may be begun before the first is finished (the next launch is queued before the host waits for a
+    summary); a fourth is refused; every batch's results are exact and stay readable until three more have begun."""
+    n, U, D = 700001, 4001, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    sets = [mixed_queries(oracle, k) for k in (5, 40, 16, 64, 3, 33)]
+    wants = [oracle_answers(oracle, cols, U, D, qs) for qs in sets]
+    begun = done = 0
+    while done < len(sets):
+        while begun < len(sets) and begun - done < 3:
+            gpu_ctx.scan_batch_begin(sets[begun])
+            begun += 1
+        if begun - done == 3:
+            with pytest.raises(pie.PieError) as ei:
+                gpu_ctx.scan_batch_begin(sets[0])
+            assert ei.value.code == -6
+        ms = gpu_ctx.scan_batch_finish()
+        assert ms == [int(w[2].size) for w in wants[done]]
+        for q in (0, len(sets[done]) - 1, len(sets[done]) // 2):
+            assert_same(gpu_ctx.batch_read_results(q), wants[done][q], "batch %d query %d" % (done, q))
+        un = gpu_ctx.batch_read_union()
+        assert un is not None and un[1].size >= max(ms)
+        done += 1

@@ -137,7 +137,7 @@ while time.time() < t_end:
                     lim = 2 ** 64 - 1 if D >= 64 else (1 << D) - 1
                     def batch_size():   # 1 .. 64 queries; more than 16 and more than 32 are shapes of their own
                         return int(rng.choice([int(rng.integers(1, 17)), int(rng.integers(17, 33)), int(rng.integers(33, 65))], p=[0.6, 0.2, 0.2]))
-                    batches = [[rand_query() for _ in range(batch_size())] for _ in range(int(rng.integers(1, 4)))]
+                    batches = [[rand_query() for _ in range(batch_size())] for _ in range(int(rng.integers(1, 6)))]
                     if rng.random() < 0.3:   # the requests of a few seconds: clocks a second apart, two cutoffs, three masks
                         base_now = int(T0 - rng.integers(0, 20 * 3600 * 1000))
                         mk3 = [int(rng.integers(0, 2 ** 63)), 2 ** 64 - 1, int(rng.integers(0, 2 ** 63))]
@@ -156,10 +156,12 @@ while time.time() < t_end:
                         else:
                             ctx.scan_batch_begin(batches[k])
 
-                    begin(0)
+                    depth = int(rng.integers(1, 4))   # one, two or three batches in flight
+                    begun_b = 0
                     for k in range(len(batches)):
-                        if k + 1 < len(batches):
-                            begin(k + 1)
+                        while begun_b < len(batches) and begun_b - k < depth:
+                            begin(begun_b)
+                            begun_b += 1
                         ms, ready = ctx.scan_batch_finish(packed=True)
                         wants_k = [oracle.scan(s, e, u, d, U, nw, ct, mk & lim) for nw, ct, mk in batches[k]]
                         nqk = len(batches[k])
