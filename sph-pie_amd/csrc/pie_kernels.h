@@ -2128,6 +2128,29 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v, int lane)
     return v;
 }
 
+// value of the lane R places to the right inside the caller's row of 16 lanes (DPP row_ror: no LDS, no bpermute)
+template <int R>
+__device__ __forceinline__ int ror16(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x120 + R, 0xF, 0xF, false);
+}
+// how many of the (up to 16) records held by the lanes of my row of 16 sort before mine by (start, idx); lanes without a record
+// hold (INT64_MAX, INT32_MAX) and never count
+template <int R>
+__device__ __forceinline__ int rank16_step(long long s, int i)
+{
+    const int lo = ror16<R>((int)(unsigned)(unsigned long long)s), hi = ror16<R>((int)((unsigned long long)s >> 32));
+    const long long so = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    const int io = ror16<R>(i);
+    return key_less(so, io, s, i) ? 1 : 0;
+}
+__device__ __forceinline__ int rank_in_row16(long long s, int i)
+{
+    return rank16_step<1>(s, i) + rank16_step<2>(s, i) + rank16_step<3>(s, i) + rank16_step<4>(s, i) + rank16_step<5>(s, i) +
+           rank16_step<6>(s, i) + rank16_step<7>(s, i) + rank16_step<8>(s, i) + rank16_step<9>(s, i) + rank16_step<10>(s, i) +
+           rank16_step<11>(s, i) + rank16_step<12>(s, i) + rank16_step<13>(s, i) + rank16_step<14>(s, i) + rank16_step<15>(s, i);
+}
+
 // HI = the batch holds more than 32 queries (a second mask word per row)
 template <bool HI>
 __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid)
@@ -2334,9 +2357,67 @@ __device__ __forceinline__ void union_tail_body(const UnionTailArgs& t, int gbid
                 }
         }
     }
-    // larger buckets: lane i < n holds record i and counts the records that sort before it
+    // buckets of 9 .. 16 rows, FOUR at a time: each takes a row of 16 lanes, lane l of the row holds record l and finds its place
+    // by comparing against the other fifteen through DPP row rotations (a heterogeneous batch — several role masks — doubles the
+    // union: a fifth of the users land here, and one at a time by the whole wave they cost more than the rest of the kernel)
     {
-        unsigned long long todo = __ballot(mid && in_u);
+        unsigned long long todo = __ballot(mid && in_u && nn <= 16);
+        const int row = lane >> 4, l = lane & 15;
+        while (todo) {
+            // the row-th pending bucket of this round (rows without one idle)
+            unsigned long long t2 = todo;
+            int mine = -1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int sl = t2 ? __ffsll((long long)t2) - 1 : -1;
+                if (g == row) mine = sl;
+                t2 &= t2 - 1;      // (0 & anything stays 0)
+            }
+            todo = t2;
+            const int srcl = mine < 0 ? 0 : mine;
+            int nb = __shfl(nn, srcl, kWave); // (every lane takes part in every shuffle: a source lane must be active)
+            if (mine < 0) nb = 0;
+            const int ub = __shfl(u, srcl, kWave);
+            const long long rq = __shfl(run, srcl, kWave);
+            BktRec r;
+            r.start = INT64_MAX;
+            r.idx = INT32_MAX;
+            r.pad = 0;
+            unsigned hi = 0;
+            if (l < nb) {
+                r = (t.direct + ((long long)ub << t.dshift))[l];
+                if constexpr (HI) hi = t.direct_hi[((long long)ub << t.dshift) + l];
+            }
+            const int rank = rank_in_row16(r.start, r.idx);
+            if (l < nb) {
+                const long long pos = rq + rank;
+                t.urows[pos] = r.idx;
+                t.umlo[pos] = (unsigned)r.pad;
+                if constexpr (HI) t.umhi[pos] = hi;
+                if (t.msg && pos < t.msg_cap) {
+                    msg_store(msg_rows + pos, r.idx);
+                    msg_store(msg_lo + pos, r.pad);
+                    if constexpr (HI) msg_store(msg_hi + pos, (int)hi);
+                }
+            }
+            // per-query totals of these (up to 64) records: lane q collects query q's
+#pragma unroll 4
+            for (int q = 0; q < (nq < 32 ? nq : 32); ++q) {
+                const unsigned c = (unsigned)__popcll(__ballot(((unsigned)r.pad >> q) & 1u));
+                if (lane == q) acc += c;
+            }
+            if constexpr (HI) {
+#pragma unroll 4
+                for (int q = 32; q < nq; ++q) {
+                    const unsigned c = (unsigned)__popcll(__ballot((hi >> (q - 32)) & 1u));
+                    if (lane == q) acc += c;
+                }
+            }
+        }
+    }
+    // still larger buckets (17 .. 64 rows: slot capacities 32 / 64): lane i < n holds record i and counts the records that sort before it
+    {
+        unsigned long long todo = __ballot(mid && in_u && nn > 16);
         while (todo) {
             const int src_lane = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
