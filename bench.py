@@ -550,7 +550,7 @@ def main():
         if batch_ms is not None:
             kname = "k_scan_batch_with_tail<8, true, %s, %s>" % ("unsigned char" if variant & 0x800 else "unsigned short", "true" if Q > 32 else "false")
             if variant & 0x2000:
-                kname = "k_ord_batch_scan<%s, 4>" % ("unsigned char" if variant & 0x800 else "unsigned short")
+                kname = "k_ord_batch_scan_t<%s, 4>" % ("unsigned char" if variant & 0x800 else "unsigned short")
         default_workload = (N, U, D, args.order, args.variant, args.query, args.mode, args.users_dist, world) == \
             (10 ** 8, 10 ** 5, 32, "random", "auth", "spec", "scan", "uniform", 1)
         alg = (8.0 if args.mode == "expired" else 24.0) * n_local

@@ -86,7 +86,7 @@ struct HostSummary {
 struct alignas(128) StatSlot {
     unsigned long long live, amb, cand;
     unsigned long long chunk_max; // max over the blocks of this slot
-    unsigned long long max_count; // largest per-user count the blocks of this slot saw (k_ord_batch_emit; k_ord_publish folds it in)
+    unsigned long long max_count; // largest per-user count the blocks of this slot saw (k_ord_emit / k_ord_union_emit; k_ord_publish folds it in)
     unsigned long long pad[11];
 };
 constexpr int kStatSlots = 64;
@@ -3227,7 +3227,7 @@ __global__ __launch_bounds__(kUnionThreads) void k_union_collect(int n_q, int n_
     if (overflow) atomicOr(over, 1);
 }
 
-// uoff[u] = group_base[u >> 10] + unit_local[u]: the two-level prefix of the union counts (k_ord_prefix + k_ord_prefix_groups,
+// uoff[u] = group_base[u >> 10] + unit_local[u]: the two-level prefix of the union counts (k_ord_prefix,
 // the kernels the ordered run uses for its unit counts)
 __global__ __launch_bounds__(256) void k_union_write(int n_users, int u_pad, const int* __restrict__ unit_local,
                                                      const long long* __restrict__ group_base, const int* __restrict__ ucnt,

@@ -615,39 +615,6 @@ __global__ __launch_bounds__(256) void k_ord_prefix(const int* __restrict__ unit
 }
 
 // second kernel of the two-kernel form: block q scans query q's group sums
-__global__ __launch_bounds__(256) void k_ord_prefix_groups(long long n_units, const long long* __restrict__ group_sum,
-                                                           long long* __restrict__ group_base, Summary* __restrict__ summary,
-                                                           long long group_stride, long long sum_stride_bytes)
-{
-    __shared__ long long wsum64[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    group_sum += (long long)blockIdx.x * group_stride;
-    group_base += (long long)blockIdx.x * group_stride;
-    summary = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)blockIdx.x * sum_stride_bytes);
-    const long long n_groups = (n_units + kOrdGroup - 1) >> kOrdGroupShift;
-    long long carry = 0;
-    for (long long g0 = 0; g0 < n_groups; g0 += 256) {
-        const long long g = g0 + threadIdx.x;
-        const long long v = g < n_groups ? group_sum[g] : 0;
-        const long long incl = wave_incl_scan(v, lane);
-        if (lane == 63) wsum64[wave] = incl;
-        __syncthreads();
-        long long wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const long long sw = wsum64[w];
-            if (w < wave) wbase += sw;
-            total += sw;
-        }
-        if (g < n_groups) group_base[g] = carry + wbase + incl - v;
-        carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        group_base[n_groups] = carry;
-        summary->m = (unsigned long long)carry;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ emit: row list, offsets, counts, summary
 
@@ -799,46 +766,36 @@ __global__ __launch_bounds__(64) void k_ord_publish(Summary* __restrict__ summar
 // ------------------------------------------------------------------------------------------------ batched form: Q queries, one pass over the key column
 
 // A table whose users are skewed cannot run the general batched pass (a head user's rows do not fit any union bucket), so
-// its batches used to run as Q single scans, each streaming the key column again.  On the run a batch is ONE pass: the
-// candidates are the positions whose key reaches the smallest key(now) of the batch, every candidate is evaluated against
-// all queries (one 16-byte gather, `end` only where some query's key cannot decide), and a position that any query selects
-// is staged once, in position order, as {row id, query mask + position inside the chunk}.
-//   k_ord_batch_scan    key stream -> union staging records + per-chunk union counts
-//   k_ord_batch_count   per chunk and query: how many of the chunk's records carry the query's bit (a lane per chunk; heavy
-//                       chunks by whole waves); which runs of 32 chunks are too heavy for one wave
-//   k_ord_prefix        (gridDim.y = Q) per-query exclusive prefix of those counts
-//   k_ord_batch_emit    per run of 32 chunks (heavy runs: per chunk): every query's row list (the row id comes with the record, compacted per query
-//                       by ballot); per user: every query's offset and count
-//   k_ord_publish       (gridDim.x = Q) summaries
-constexpr int kOrdBatchMax = 16; // queries per pass over the run (a larger batch runs as consecutive passes of 16)
-struct OrdBatchQuery {
-    long long now, cutoff;
-    unsigned long long mask;
-    unsigned now_key;
-    unsigned pad;
-};
-struct OrdBatchArgs {
-    int n_q;
-    unsigned min_key;
-    OrdBatchQuery q[kOrdBatchMax];
-};
-// A union staging record lives in its chunk's 512 slots, so its position is the chunk + 9 bits; with the 16 query bits that
-// leaves a whole word for the row id: the emit kernel reads the row where it reads the mask, not through a second, dependent
-// gather at the position (the copy role's 33 us were two such round trips per record).
+// its batches used to run as Q single scans, each streaming the key column again.  On the run a batch of up to 64 queries
+// is ONE pass: the candidates are the positions whose key reaches the smallest key(now) of the batch, every candidate's
+// 64-bit query mask comes from the three lookups of BatchTables (one 16-byte gather, `end` only where the key cannot decide),
+// and a position that any query selects is staged once, in position order.  The result is the union, as on the general pass:
+//   k_ord_batch_scan_t   key stream -> union staging records + per-chunk union counts
+//   k_ord_prefix         exclusive prefix of the per-chunk counts (one launch; it also yields the per-unit bases)
+//   k_ord_union_emit     copy role: staging record -> urows / umlo / umhi at its union position; user role: uoff from the
+//                        run's per-user offsets, per-query totals (bit-sliced counting), the largest union bucket
+//   k_ord_union_publish  the batch's summary + per-query totals to mapped host memory
+// Per-query lists, where a caller asks for them, are cut from the union by the kernels the general pass uses (k_mat_*).
+// A union staging record lives in its chunk's 512 slots, so its position is the chunk + 9 bits; the rest of the word carries the
+// three table ranks the record's 64-bit query mask is rebuilt from (BatchTables): [place : 9 | liveness rank : 7 | window rank :
+// 7 | discipline : 6].  The row id rides in the record: the emit reads the row where it reads the ranks, not through a second,
+// dependent gather at the position.
 struct alignas(8) OrdUnion {
     int row;
-    unsigned qsub; // bits 0..15: the queries that select the row; bits 16..24: its position inside the chunk
+    unsigned qsub;
 };
-static_assert(kOrdBatchMax <= 16, "OrdUnion keeps the query mask in 16 bits");
 constexpr unsigned kOrdSubMask = 511u; // k_ord_batch_scan's chunk: 512 positions for both key widths
 
 // A chunk is 512 positions for both key widths: 8 one-byte keys (one 8-byte load) or 8 two-byte keys (one 16-byte load) per
 // lane.  The candidate ring then takes 5 / 6 KiB per wave instead of 10, and two to three times as many waves fit a CU —
 // the pass is latency-bound (34 chunks and a handful of candidate batches per wave), so that is what counts: 141 -> 9x us.
+// The table-lookup form (round 3): up to 64 queries per pass.  Identical streaming, candidate ring and position-ordered staging;
+// the per-candidate loop over the queries is replaced by the three lookups of BatchTables (pie_kernels.h) and the staging word
+// carries [place in chunk : 9 | liveness rank : 7 | window rank : 7 | discipline : 6] instead of 16 query bits.
 template <class KT, int UNROLL = 4>
-__global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
-                                                        const KT* __restrict__ key, long long n_ord, long long n_chunks, OrdBatchArgs a,
-                                                        OrdUnion* __restrict__ ustage, int* __restrict__ ucount,
+__global__ __launch_bounds__(256) void k_ord_batch_scan_t(const OrdRec* __restrict__ pay, const long long* __restrict__ end,
+                                                        const KT* __restrict__ key, long long n_ord, long long n_chunks, unsigned min_key,
+                                                        BatchTables tabs, OrdUnion* __restrict__ ustage, int* __restrict__ ucount,
                                                         Summary* __restrict__ summary)
 {
     constexpr int kPerLane = 8;
@@ -849,8 +806,14 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
     __shared__ int ring_s[4][kRing];
     __shared__ KT ringk_s[4][kRing];
     __shared__ int blk_cand, blk_chunk_max;
+    __shared__ BatchTables tab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { blk_cand = 0; blk_chunk_max = 0; }
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&tabs);
+        unsigned* dst = reinterpret_cast<unsigned*>(&tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(BatchTables) / 4); i += 256) dst[i] = src[i];
+    }
     __syncthreads();
     int* ring = ring_s[wave];
     KT* ringk = ringk_s[wave];
@@ -858,9 +821,8 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
     int cur_chunk = -1, cur_cnt = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    const int nq = a.n_q;
-
     bool a_have = false, a_valid = false, a_amb = false;
+    int a_r = 0; // queries whose key(now) lies below the candidate's key (see BatchTables)
     int a_pos = 0x7FFFFFFF;
     unsigned a_key = 0;
     OrdRec a_pay;
@@ -870,19 +832,22 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
     auto step_b = [&]() {
         if (!a_have) return;
         a_have = false;
-        unsigned qmask = 0;
+        // the Q predicates by table lookup (BatchTables): liveness rank (by the 8-byte `end` where a key cannot decide), window
+        // rank, discipline; the record keeps the three ranks — 7 + 7 + 6 bits beside the 9 of its place in the chunk — and the
+        // emit rebuilds the 64-bit query mask from them
+        unsigned code = 0;
+        bool sel = false;
         if (a_valid) {
             const int dv = a_pay.disc;
-            const bool disc_ok = (unsigned)dv < 64u;
-            for (int q = 0; q < nq; ++q) { // wave-uniform loop over the queries' scalars
-                const OrdBatchQuery& Q = a.q[q];
-                const bool live = a_key > Q.now_key || (a_key == Q.now_key && a_end > Q.now);
-                const bool p = live & (a_pay.start >= Q.cutoff) & disc_ok & (((Q.mask >> (dv & 63)) & 1ull) != 0);
-                qmask |= (p ? 1u : 0u) << q;
+            int r = a_r;
+            if (a_amb) r = rank_in_64<true>(tab.now, a_end);
+            const int w = rank_in_64<false>(tab.cutoff, a_pay.start);
+            if ((unsigned)dv < 64u) {
+                sel = (tab.live[r] & tab.win[w] & tab.disc[dv]) != 0ull;
+                code = ((unsigned)r << 9) | ((unsigned)w << 16) | ((unsigned)dv << 23);
             }
         }
         ncand += __popcll(__ballot(a_valid));
-        const bool sel = qmask != 0;
         const unsigned long long sb = __ballot(sel);
         if (sb == 0) return;
         const int ch = a_pos >> kChunkShift;
@@ -901,7 +866,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
         if (sel) {
             OrdUnion r;
             r.row = a_pay.row;
-            r.qsub = qmask | (((unsigned)a_pos & kOrdSubMask) << 16);
+            r.qsub = code | ((unsigned)a_pos & kOrdSubMask);
             ustage[((long long)ch << kChunkShift) + rank] = r;
             if (last_of_seg && ch != new_chunk) ucount[ch] = rank + 1;
         }
@@ -920,7 +885,8 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
             if (a_pos < n_ord) {
                 a_valid = true;
                 a_pay = pay[a_pos];
-                for (int q = 0; q < nq; ++q) a_amb |= a_key == a.q[q].now_key;
+                a_r = rank_in_64<true>(tab.nk, a_key);
+                a_amb = a_r < kBatchMax && tab.nk[a_r < kBatchMax ? a_r : 0] == a_key;
                 if (a_amb) a_end = end[a_pos];
             }
         }
@@ -931,7 +897,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
 
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     constexpr unsigned kTop = sizeof(KT) == 2 ? 0x80008000u : 0x80808080u;
-    const unsigned mk = a.min_key;
+    const unsigned mk = min_key;
     const unsigned nk_ge = sizeof(KT) == 2 ? (mk | (mk << 16)) : mk * 0x01010101u;
     auto row_bits = [&](unsigned g0, unsigned g1, unsigned g2, unsigned g3) -> unsigned {
         if constexpr (sizeof(KT) == 1) {
@@ -1009,274 +975,7 @@ __global__ __launch_bounds__(256) void k_ord_batch_scan(const OrdRec* __restrict
     if (threadIdx.x == 0) add_row_stats(summary, 0, 0, (int)blockIdx.x, blk_cand, blk_chunk_max);
 }
 
-// cq[q][chunk] = records of the chunk that carry query q's bit (zeros for empty chunks: every entry written).
-// Pass 1, one LANE per chunk: a chunk holds a handful of records (one 32..64-byte sector of the staging array), so 64 chunks per
-// wave are 64 sectors in flight where one wave per chunk had one.  Pass 2, the chunks with more than kOrdChunkHeavy records (a
-// popular user's live rows: they lie together, whole runs of full chunks): chunk ch belongs to wave ch mod n_waves, which
-// counts it with all its lanes — neighbouring heavy chunks go to different waves.
-// run_flag[run] (run = 32 chunks) = the run holds more than kOrdRunHeavy records: k_ord_batch_emit then writes its rows chunk by
-// chunk, spread over the waves the same way, instead of as one flat list in one wave.
-constexpr int kOrdChunkHeavy = 8;
-constexpr int kOrdRunShift = 5;
-constexpr int kOrdRun = 1 << kOrdRunShift;
-constexpr int kOrdRunHeavy = 192;
-
-__global__ __launch_bounds__(256) void k_ord_batch_count(const OrdUnion* __restrict__ ustage, const int* __restrict__ ucount,
-                                                         long long n_chunks, int chunk_shift, int n_q, int* __restrict__ cq,
-                                                         long long unit_stride, int* __restrict__ run_flag)
-{
-    const int lane = threadIdx.x & 63;
-    const long long wv = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const long long padded = ((n_chunks + kOrdGroup - 1) >> kOrdGroupShift) << kOrdGroupShift; // the prefix reads whole groups
-    for (long long base = wv << 6; base < padded; base += n_waves << 6) {
-        const long long ch = base + lane; // < padded: a multiple of 64
-        const int cnt = ch < n_chunks ? ucount[ch] : 0;
-        int tot[kOrdBatchMax];
-#pragma unroll
-        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
-        if (cnt <= kOrdChunkHeavy) {
-            const OrdUnion* rec = ustage + (ch << chunk_shift);
-            for (int j = 0; j < cnt; ++j) {
-                const unsigned qm = rec[j].qsub;
-#pragma unroll
-                for (int q = 0; q < kOrdBatchMax; ++q) tot[q] += (qm >> q) & 1u;
-            }
-#pragma unroll
-            for (int q = 0; q < kOrdBatchMax; ++q) {
-                if (q >= n_q) break;
-                cq[(long long)q * unit_stride + ch] = tot[q];
-            }
-        }
-        const int incl = wave_incl_scan_i32(cnt, lane);
-        const int first = __shfl(incl, kOrdRun - 1, kWave), both = __shfl(incl, 63, kWave); // the wave's 64 chunks are two runs
-        if (lane == 0) {
-            run_flag[base >> kOrdRunShift] = first > kOrdRunHeavy;
-            run_flag[(base >> kOrdRunShift) + 1] = both - first > kOrdRunHeavy;
-        }
-    }
-    for (long long c0 = wv; c0 < n_chunks; c0 += n_waves << 6) {
-        const long long ch = c0 + (long long)lane * n_waves;
-        const int cnt = ch < n_chunks ? ucount[ch] : 0;
-        unsigned long long todo = __ballot(cnt > kOrdChunkHeavy);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const long long lch = c0 + (long long)leader * n_waves;
-            const int lcnt = __shfl(cnt, leader, kWave);
-            const OrdUnion* lrec = ustage + (lch << chunk_shift);
-            int tot = 0; // lane q < n_q ends up with query q's count
-            for (int j0 = 0; j0 < lcnt; j0 += 64) {
-                const unsigned qm = j0 + lane < lcnt ? lrec[j0 + lane].qsub : 0u;
-                for (int q = 0; q < n_q; ++q) {
-                    const int c = __popcll(__ballot((qm >> q) & 1u));
-                    if (lane == q) tot += c;
-                }
-            }
-            if (lane < n_q) cq[(long long)lane * unit_stride + lch] = tot;
-            todo &= todo - 1;
-        }
-    }
-}
-
-// The first blocks (one per 255 users; first, so that they run beside the copy blocks and not behind them): thread t of
-// user-block b has user b * 255 + t and computes every query's offset of that user.  The copy_blocks blocks behind them: a wave
-// writes every query's rows of 32 chunks at a time.
-__global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restrict__ uoff, int n_users, long long n_ord, int chunk_shift,
-                                                        long long n_chunks, int n_q, const OrdUnion* __restrict__ ustage,
-                                                        const int* __restrict__ ucount, const int* __restrict__ unit_local,
-                                                        const long long* __restrict__ group_base, long long unit_stride,
-                                                        long long group_stride, const OrdRec* __restrict__ pay, int* __restrict__ out_idx,
-                                                        long long out_stride, long long* __restrict__ offsets, int* __restrict__ counts_ord,
-                                                        long long users_stride, int copy_blocks, Summary* __restrict__ summary,
-                                                        long long sum_stride_bytes, int* __restrict__ zero_counts, long long zero_n,
-                                                        const int* __restrict__ run_flag, const int* __restrict__ cq)
-{
-    const int user_blocks = (int)gridDim.x - copy_blocks;
-    __shared__ int soff[kOrdBatchMax][256];
-    __shared__ int sincl[4][kWave];
-    __shared__ int wmax[kOrdBatchMax][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
-    if ((int)blockIdx.x >= user_blocks) {
-        // Pass 1: a wave takes a run of 32 consecutive chunks at a time (one group of the prefix holds 1024, so they share a group
-        // base): their records, a handful per chunk, are read as one flat list — lane j finds its chunk in the wave's prefix of
-        // the 32 counts — and every query's rows of the run follow one another in its list, so one write position per query
-        // carries through.  Runs of more than kOrdRunHeavy records (a popular user's live rows) are left to pass 2.
-        int* incl_s = sincl[wave];
-        const long long n_waves = (long long)copy_blocks * 4, wv = (long long)((int)blockIdx.x - user_blocks) * 4 + wave;
-        const long long n_runs = (n_chunks + kOrdRun - 1) >> kOrdRunShift;
-        auto put = [&](const OrdUnion& r, int row, long long& next) { // one round of up to 64 records: each query's rows, compacted by ballot
-#pragma unroll
-            for (int q = 0; q < kOrdBatchMax; ++q) {
-                if (q >= n_q) break; // wave-uniform
-                const bool sel = (r.qsub >> q) & 1u;
-                const unsigned long long b = __ballot(sel);
-                if (b == 0) continue;
-                const long long base_q = __shfl(next, q, kWave);
-                if (sel) {
-                    const long long at = base_q + prefix_in_ballot(b);
-                    if (at < out_stride) out_idx[(long long)q * out_stride + at] = row; // a list beyond the batch's row capacity is rerun
-                }
-                if (lane == q) next += __popcll(b);
-            }
-        };
-        for (long long run = wv; run < n_runs; run += n_waves) {
-            const long long ch0 = run << kOrdRunShift;
-            const int cnt = (lane < kOrdRun && ch0 + lane < n_chunks) ? ucount[ch0 + lane] : 0;
-            const int incl = wave_incl_scan_i32(cnt, lane);
-            const int total = __shfl(incl, 63, kWave);
-            if (total == 0 || total > kOrdRunHeavy) continue; // wave-uniform
-            long long next = 0; // lane q < n_q: where query q's next row of this run goes (one load pair per lane, not 16 per wave)
-            if (lane < n_q) next = group_base[(long long)lane * group_stride + (ch0 >> kOrdGroupShift)] + unit_local[(long long)lane * unit_stride + ch0];
-            __builtin_amdgcn_wave_barrier();
-            incl_s[lane] = incl;
-            __builtin_amdgcn_wave_barrier();
-            for (int j0 = 0; j0 < total; j0 += 64) {
-                OrdUnion r;
-                r.row = 0; r.qsub = 0;
-                const int j = j0 + lane;
-                if (j < total) {
-                    int lo = 0, hi = kOrdRun - 1; // the first chunk whose inclusive prefix is above j
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (incl_s[mid] > j) hi = mid;
-                        else lo = mid + 1;
-                    }
-                    const int before = lo ? incl_s[lo - 1] : 0;
-                    r = ustage[((ch0 + lo) << chunk_shift) + (j - before)];
-                }
-                put(r, r.row, next);
-            }
-        }
-        // Pass 2: the chunks of the heavy runs, chunk ch by wave ch mod n_waves (neighbouring chunks go to different waves)
-        for (long long c0 = wv; c0 < n_chunks; c0 += n_waves << 6) {
-            const long long ch = c0 + (long long)lane * n_waves;
-            const int cnt = (ch < n_chunks && run_flag[ch >> kOrdRunShift]) ? ucount[ch] : 0;
-            unsigned long long todo = __ballot(cnt > 0);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const long long lch = c0 + (long long)leader * n_waves;
-                const int lcnt = __shfl(cnt, leader, kWave);
-                long long next = 0;
-                if (lane < n_q) next = group_base[(long long)lane * group_stride + (lch >> kOrdGroupShift)] + unit_local[(long long)lane * unit_stride + lch];
-                for (int j0 = 0; j0 < lcnt; j0 += 64) {
-                    OrdUnion r;
-                    r.row = 0; r.qsub = 0;
-                    if (j0 + lane < lcnt) r = ustage[(lch << chunk_shift) + j0 + lane];
-                    put(r, r.row, next);
-                }
-                todo &= todo - 1;
-            }
-        }
-        return;
-    }
-    const long long u = (long long)blockIdx.x * 255 + threadIdx.x;
-    int below[kOrdBatchMax]; // records of my chunk before my segment start, per query
-#pragma unroll
-    for (int q = 0; q < kOrdBatchMax; ++q) below[q] = 0;
-    long long ch = -1;
-    bool at_end = true;
-    int jb = 0; // records of my chunk that lie before my segment start (staged in position order: a binary search)
-    int j_lo = 0, j_hi = 0; // the records I count: those before my segment start, or — when they are fewer — those behind it
-    bool from_end = false;
-    if (u <= n_users) {
-        const long long qpos = uoff[u];
-        at_end = qpos >= n_ord;
-        if (!at_end) {
-            ch = qpos >> chunk_shift;
-            const OrdUnion* rec = ustage + (ch << chunk_shift);
-            const int cnt = ucount[ch];
-            int lo = 0, hi = cnt;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((rec[mid].qsub >> 16) < ((unsigned)qpos & kOrdSubMask)) lo = mid + 1; // same chunk: compare inside it
-                else hi = mid;
-            }
-            jb = lo;
-            // A user who follows a popular one starts inside a chunk full of that user's live rows (a segment is in start order:
-            // the live rows are its last), and its own first rows are old: hundreds of records before the boundary, none or a
-            // few behind it.  The chunk's count per query is known (cq), so the shorter side is counted.
-            from_end = cnt - jb < jb;
-            j_lo = from_end ? jb : 0;
-            j_hi = from_end ? cnt : jb;
-        }
-    }
-    // A few records a lane counts itself; a long stretch is counted by the whole wave, one such lane at a time.
-    const bool heavy = j_hi - j_lo > 16;
-    if (!heavy && j_hi > j_lo) {
-        const OrdUnion* rec = ustage + (ch << chunk_shift);
-        for (int j = j_lo; j < j_hi; ++j) {
-            const unsigned qm = rec[j].qsub;
-#pragma unroll
-            for (int q = 0; q < kOrdBatchMax; ++q) below[q] += (qm >> q) & 1u;
-        }
-    }
-    unsigned long long todo = __ballot(heavy);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const long long lch = __shfl(ch, leader, kWave);
-        const int l_lo = __shfl(j_lo, leader, kWave), l_hi = __shfl(j_hi, leader, kWave);
-        const OrdUnion* lrec = ustage + (lch << chunk_shift);
-        int tot[kOrdBatchMax];
-#pragma unroll
-        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
-        for (int j0 = l_lo; j0 < l_hi; j0 += 64) {
-            const unsigned qm = j0 + lane < l_hi ? lrec[j0 + lane].qsub : 0u;
-#pragma unroll
-            for (int q = 0; q < kOrdBatchMax; ++q) {
-                if (q >= n_q) break;
-                tot[q] += __popcll(__ballot((qm >> q) & 1u));
-            }
-        }
-        if (lane == leader) {
-#pragma unroll
-            for (int q = 0; q < kOrdBatchMax; ++q) below[q] = tot[q];
-        }
-        todo &= todo - 1;
-    }
-    if (from_end) {
-#pragma unroll
-        for (int q = 0; q < kOrdBatchMax; ++q) {
-            if (q >= n_q) break;
-            below[q] = cq[(long long)q * unit_stride + ch] - below[q];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < kOrdBatchMax; ++q) {
-        if (q >= n_q) break;
-        long long my = 0;
-        if (u <= n_users) {
-            const long long* gb = group_base + (long long)q * group_stride;
-            my = at_end ? gb[n_groups] : gb[ch >> kOrdGroupShift] + unit_local[(long long)q * unit_stride + ch] + below[q];
-            offsets[(long long)q * users_stride + u] = my;
-        }
-        soff[q][threadIdx.x] = (int)my;
-    }
-    __syncthreads();
-    for (int q = 0; q < n_q; ++q) {
-        int cnt = 0;
-        if (threadIdx.x < 255 && u < n_users) {
-            cnt = soff[q][threadIdx.x + 1] - soff[q][threadIdx.x];
-            counts_ord[(long long)q * users_stride + u] = cnt;
-        }
-        int mx = cnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, kWave));
-        if (lane == 0) wmax[q][wave] = mx;
-    }
-    __syncthreads();
-    // one atomic per block and query, on the block's statistics slot: an atomic per wave on the query's one max_count made
-    // 25 000 of them queue on 16 addresses — 20 of the kernel's 58 us
-    if ((int)threadIdx.x < n_q) {
-        const int q = threadIdx.x;
-        const int bm = max(max(wmax[q][0], wmax[q][1]), max(wmax[q][2], wmax[q][3]));
-        if (bm > 0) {
-            Summary* sq = reinterpret_cast<Summary*>(reinterpret_cast<char*>(summary) + (long long)q * sum_stride_bytes);
-            atomicMax(&stat_slots(sq)[blockIdx.x & (kStatSlots - 1)].max_count, (unsigned long long)bm);
-        }
-    }
-}
+constexpr int kOrdChunkHeavy = 8; // a chunk with more staged records than this is copied by a whole wave
 
 // ---- the UNION form of a batch on the run (round 3; batches of <= 16 queries).  The staging records of k_ord_batch_scan — one per
 // position that ANY query selects, in position order, with the query bits — ARE the batch's union in (user, start, row) order.
@@ -1289,42 +988,91 @@ __global__ __launch_bounds__(256) void k_ord_batch_emit(const long long* __restr
 //   k_ord_union_publish summary + per-query totals -> the batch's mapped host block
 // and the result is the same union (uoff / urows / umlo) the general batched pass returns: per-query lists, messages and request
 // fetches are produced from it by the same kernels.
+// bit-sliced count of up to 8 mask words: plane i, bit q = bit i of "how many of the 8 words have bit q"
+__device__ __forceinline__ void csa8(const unsigned (&m)[8], unsigned (&pl)[4])
+{
+    auto fa = [](unsigned a, unsigned b, unsigned c, unsigned& carry) { const unsigned x = a ^ b; carry = (a & b) | (c & x); return x ^ c; };
+    unsigned c1, c2, c3, c4, c5, c6;
+    const unsigned s1 = fa(m[0], m[1], m[2], c1), s2 = fa(m[3], m[4], m[5], c2);
+    const unsigned s3 = m[6] ^ m[7];
+    c3 = m[6] & m[7];
+    pl[0] = fa(s1, s2, s3, c4);
+    const unsigned tw = fa(c1, c2, c3, c5);
+    pl[1] = tw ^ c4;
+    c6 = tw & c4;
+    pl[2] = c5 ^ c6;
+    pl[3] = c5 & c6;
+}
+
+// HI: the batch holds more than 32 queries (a second mask word per union row)
+template <bool HI>
 __global__ __launch_bounds__(256) void k_ord_union_emit(const long long* __restrict__ uoff_run, int n_users, long long n_ord, int chunk_shift,
-                                                        long long n_chunks, int n_q, const OrdUnion* __restrict__ ustage,
+                                                        long long n_chunks, int n_q, BatchTables tabs, const OrdUnion* __restrict__ ustage,
                                                         const int* __restrict__ ucount, const int* __restrict__ unit_local,
                                                         const long long* __restrict__ group_base, long long* __restrict__ uoff_out,
-                                                        int* __restrict__ urows, unsigned int* __restrict__ umlo, long long ucap,
-                                                        int copy_blocks, Summary* __restrict__ summary, unsigned int* __restrict__ mq_slots,
-                                                        int* __restrict__ zero_counts, long long zero_n)
+                                                        int* __restrict__ urows, unsigned int* __restrict__ umlo, unsigned int* __restrict__ umhi,
+                                                        long long ucap, int copy_blocks, Summary* __restrict__ summary,
+                                                        unsigned int* __restrict__ mq_slots, int* __restrict__ zero_counts, long long zero_n)
 {
     const int user_blocks = (int)gridDim.x - copy_blocks;
     __shared__ long long soff[256];
     __shared__ int wmax[4];
+    __shared__ BatchTables tab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_counts[i] = 0;
     if ((int)blockIdx.x >= user_blocks) {
+        {
+            const unsigned* src = reinterpret_cast<const unsigned*>(&tabs);
+            unsigned* dst = reinterpret_cast<unsigned*>(&tab);
+            for (int i = threadIdx.x; i < (int)(sizeof(BatchTables) / 4); i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        // the 64-bit query mask of a staging record, from its three ranks
+        auto mask_of = [&](unsigned qsub) { return tab.live[(qsub >> 9) & 127u] & tab.win[(qsub >> 16) & 127u] & tab.disc[(qsub >> 23) & 63u]; };
         const long long n_waves = (long long)copy_blocks * 4, wv = (long long)((int)blockIdx.x - user_blocks) * 4 + wave;
-        int tot[kOrdBatchMax]; // light chunks: this lane's count per query
-#pragma unroll
-        for (int q = 0; q < kOrdBatchMax; ++q) tot[q] = 0;
-        unsigned acc = 0;      // heavy chunks: lane q holds query q's count
+        const int nq_lo = n_q < 32 ? n_q : 32;
+        unsigned acc = 0; // lane q holds query q's count
+        auto count_planes = [&](const unsigned (&pl)[4], int q0, int q1) { // four ballots per query: the wave's total of bit q - q0 of the planes
+#pragma unroll 4
+            for (int q = q0; q < q1; ++q) {
+                const int sh = q - q0;
+                const unsigned c = (unsigned)__popcll(__ballot((pl[0] >> sh) & 1u)) + 2u * (unsigned)__popcll(__ballot((pl[1] >> sh) & 1u)) +
+                                   4u * (unsigned)__popcll(__ballot((pl[2] >> sh) & 1u)) + 8u * (unsigned)__popcll(__ballot((pl[3] >> sh) & 1u));
+                if (lane == q) acc += c;
+            }
+        };
         // pass 1: a lane per chunk, 64 consecutive chunks per wave step: a chunk holds a handful of records
         for (long long base = wv << 6; base < n_chunks; base += n_waves << 6) {
             const long long ch = base + lane;
             const int cnt = ch < n_chunks ? ucount[ch] : 0;
+            unsigned mlo[8], mhi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mlo[j] = 0; mhi[j] = 0; }
             if (cnt > 0 && cnt <= kOrdChunkHeavy) {
                 const OrdUnion* rec = ustage + (ch << chunk_shift);
                 const long long dst = group_base[ch >> kOrdGroupShift] + unit_local[ch];
-                for (int j = 0; j < cnt; ++j) {
-                    const OrdUnion r = rec[j];
-                    if (dst + j < ucap) {
-                        urows[dst + j] = r.row;
-                        umlo[dst + j] = r.qsub & 0xFFFFu;
-                    }
 #pragma unroll
-                    for (int q = 0; q < kOrdBatchMax; ++q) tot[q] += (r.qsub >> q) & 1u;
+                for (int j = 0; j < kOrdChunkHeavy; ++j) {
+                    if (j < cnt) {
+                        const OrdUnion r = rec[j];
+                        const unsigned long long m = mask_of(r.qsub);
+                        mlo[j] = (unsigned)m;
+                        mhi[j] = (unsigned)(m >> 32);
+                        if (dst + j < ucap) {
+                            urows[dst + j] = r.row;
+                            umlo[dst + j] = (unsigned)m;
+                            if constexpr (HI) umhi[dst + j] = (unsigned)(m >> 32);
+                        }
+                    }
                 }
+            }
+            unsigned pl[4];
+            csa8(mlo, pl);
+            count_planes(pl, 0, nq_lo);
+            if constexpr (HI) {
+                csa8(mhi, pl);
+                count_planes(pl, 32, n_q);
             }
         }
         // pass 2: the heavy chunks (a popular user's live rows: whole runs of full chunks), chunk ch by wave ch mod n_waves
@@ -1339,30 +1087,31 @@ __global__ __launch_bounds__(256) void k_ord_union_emit(const long long* __restr
                 const OrdUnion* lrec = ustage + (lch << chunk_shift);
                 const long long ldst = group_base[lch >> kOrdGroupShift] + unit_local[lch];
                 for (int j0 = 0; j0 < lcnt; j0 += 64) {
-                    unsigned qm = 0;
+                    unsigned long long m = 0;
                     if (j0 + lane < lcnt) {
                         const OrdUnion r = lrec[j0 + lane];
-                        qm = r.qsub & 0xFFFFu;
+                        m = mask_of(r.qsub);
                         if (ldst + j0 + lane < ucap) {
                             urows[ldst + j0 + lane] = r.row;
-                            umlo[ldst + j0 + lane] = qm;
+                            umlo[ldst + j0 + lane] = (unsigned)m;
+                            if constexpr (HI) umhi[ldst + j0 + lane] = (unsigned)(m >> 32);
                         }
                     }
-                    for (int q = 0; q < n_q; ++q) {
-                        const unsigned c = (unsigned)__popcll(__ballot((qm >> q) & 1u));
+#pragma unroll 4
+                    for (int q = 0; q < nq_lo; ++q) {
+                        const unsigned c = (unsigned)__popcll(__ballot(((unsigned)m >> q) & 1u));
                         if (lane == q) acc += c;
+                    }
+                    if constexpr (HI) {
+#pragma unroll 4
+                        for (int q = 32; q < n_q; ++q) {
+                            const unsigned c = (unsigned)__popcll(__ballot(((unsigned)(m >> 32) >> (q - 32)) & 1u));
+                            if (lane == q) acc += c;
+                        }
                     }
                 }
                 todo &= todo - 1;
             }
-        }
-        // the wave's per-query totals -> the spread counters
-#pragma unroll
-        for (int q = 0; q < kOrdBatchMax; ++q) {
-            int v = tot[q];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-            if (lane == q) acc += (unsigned)v;
         }
         if (lane < n_q && acc) atomicAdd(&mq_slots[(blockIdx.x & (kMqSlots - 1)) * kBatchMax + lane], acc);
         return;
@@ -1379,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_ord_union_emit(const long long* __restr
             int lo = 0, hi = ucount[ch];
             while (lo < hi) { // staged in position order: the records before my segment start
                 const int mid = (lo + hi) >> 1;
-                if ((rec[mid].qsub >> 16) < ((unsigned)qpos & kOrdSubMask)) lo = mid + 1;
+                if ((rec[mid].qsub & kOrdSubMask) < ((unsigned)qpos & kOrdSubMask)) lo = mid + 1;
                 else hi = mid;
             }
             my = group_base[ch >> kOrdGroupShift] + unit_local[ch] + lo;

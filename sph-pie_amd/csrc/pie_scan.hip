@@ -115,7 +115,6 @@ struct BatchSlot {
     bool in_flight = false, k2_pending = false, have_result = false;
     int dshift = 4;                    // union bucket capacity (log2) the batch ran with
     bool ordered = false;              // this batch ran on the ordered run (pie_ordered.h "batched form"): no tail, nothing rides
-    bool ord_union = false;            // ... in its union form (<= 16 queries): the result is the union, as on the general pass
     bool unsupported = false;          // this table cannot run the batched pass (no key columns / no direct slots): every query falls back
     bool fine_key = false;
     unsigned long long seq = 0;
@@ -137,8 +136,6 @@ struct BatchSlot {
     long long* offsets = nullptr;      // [lists_q][users_stride]
     int* out_idx = nullptr;            // [lists_q][out_stride]
     bool list_ok[kBatchMax];           // query q's counts / offsets / row list are in the list storage
-    HostSummary* h_sum = nullptr;      // [kBatchMax] mapped pinned (the ordered run's batched form publishes per query)
-    HostSummary* h_sum_dev = nullptr;
     pie_query q[kBatchMax];
     bool fallback[kBatchMax];          // rerun on the general path (dense query, outgrown bucket, bad rows)
     Summary last[kBatchMax];
@@ -185,12 +182,10 @@ struct OrderedRun {
     long long* alt_uoff = nullptr;
     unsigned long long respreads = 0;
     // batched form: per query unit counts / prefixes / group sums, one summary set per batch slot
-    int* bq_count = nullptr;
     int* bq_local = nullptr;
     long long* bq_gsum = nullptr;
     long long* bq_gbase = nullptr;
     OrdCtl* bq_ctl = nullptr;
-    int* bq_runflag = nullptr;               // [units / 32] the run of 32 chunks holds too many records for one wave (k_ord_batch_count -> k_ord_batch_emit)
     char* bq_sum[2] = {nullptr, nullptr};
     int users = 0;                           // users that have a segment (>= n_users: room for users yet to come)
     long long pos_cap = 0;                   // positions the arrays hold
@@ -423,7 +418,7 @@ void ord_free(pie_ctx* c)
     OrderedRun& o = c->ord;
     dfree(o.pay); dfree(o.end); dfree(o.key); dfree(o.fkey); dfree(o.pos); dfree(o.uoff); dfree(o.ufill); dfree(o.pend); dfree(o.placed); dfree(o.bhead); dfree(o.bnext);
     dfree(o.alt_pay); dfree(o.alt_end); dfree(o.alt_key); dfree(o.alt_fkey); dfree(o.alt_uoff);
-    dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
+    dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
     dfree(o.unit_count[0]); dfree(o.unit_count[1]); dfree(o.unit_local); dfree(o.group_sum); dfree(o.group_base); dfree(o.tile_ballot); dfree(o.tile_prefix);
     dfree(o.sum[0]); dfree(o.sum[1]);
     o.valid = false;
@@ -1275,23 +1270,20 @@ size_t batch_mq_bytes();
 int ord_batch_alloc(pie_ctx* c)
 {
     OrderedRun& o = c->ord;
-    if (o.bq_count) return PIE_OK;
+    if (o.bq_local) return PIE_OK;
     const size_t units = (size_t)o.units_cap, groups = units / 1024 + 2;
-    const bool ok = hipMalloc(&o.bq_count, (size_t)kOrdBatchMax * units * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_local, (size_t)kOrdBatchMax * units * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_gsum, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
-                    hipMalloc(&o.bq_gbase, (size_t)kOrdBatchMax * groups * 8) == hipSuccess &&
-                    hipMalloc(&o.bq_ctl, (size_t)kOrdBatchMax * sizeof(OrdCtl)) == hipSuccess && hipMalloc(&o.bq_runflag, (units / 32 + 2) * 4) == hipSuccess &&
-                    hipMalloc(&o.bq_sum[0], (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes()) == hipSuccess &&
-                    hipMalloc(&o.bq_sum[1], (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes()) == hipSuccess;
+    const bool ok = hipMalloc(&o.bq_local, units * 4) == hipSuccess && hipMalloc(&o.bq_gsum, groups * 8) == hipSuccess &&
+                    hipMalloc(&o.bq_gbase, groups * 8) == hipSuccess && hipMalloc(&o.bq_ctl, sizeof(OrdCtl)) == hipSuccess &&
+                    hipMalloc(&o.bq_sum[0], ord_sum_bytes() + batch_mq_bytes()) == hipSuccess &&
+                    hipMalloc(&o.bq_sum[1], ord_sum_bytes() + batch_mq_bytes()) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
-        dfree(o.bq_count); dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_runflag); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
+        dfree(o.bq_local); dfree(o.bq_gsum); dfree(o.bq_gbase); dfree(o.bq_ctl); dfree(o.bq_sum[0]); dfree(o.bq_sum[1]);
         return PIE_E_NOMEM;
     }
-    PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, (size_t)kOrdBatchMax * sizeof(OrdCtl), c->stream));
-    PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes(), c->stream));
-    PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, (size_t)kBatchMax * ord_sum_bytes() + batch_mq_bytes(), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_ctl, 0, sizeof(OrdCtl), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[0], 0, ord_sum_bytes() + batch_mq_bytes(), c->stream));
+    PIE_HIP(c, hipMemsetAsync(o.bq_sum[1], 0, ord_sum_bytes() + batch_mq_bytes(), c->stream));
     return PIE_OK;
 }
 
@@ -1306,99 +1298,39 @@ bool ordered_batch_wanted(const pie_ctx* c)
     return (padded + kOrdTile) * sizeof(OrdUnion) <= (size_t)c->sel_cap * sizeof(SelRec);
 }
 
-// six launches: key stream -> union records; per-query chunk counts; per-query prefix (two kernels); row lists + offsets; summaries
-// (a batch of more than kOrdBatchMax = 16 queries runs as consecutive sub-batches of 16 in the same stream: the staging record
-// keeps 16 query bits; the scratch arrays are reused in stream order, every query has its own result arrays and summary)
-void launch_ordered_batch(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs_all, bool fine, int q0, int nq)
-{
-    OrderedRun& o = c->ord;
-    const int bi = (int)(&b - c->bslot) & 1; // scratch (staging, device summaries) of two sets: chains run one after the other in the stream
-    char* sums = o.bq_sum[bi] + (size_t)q0 * ord_sum_bytes();
-    const pie_query* qs = qs_all + q0;
-    int* uc = o.unit_count[o.uc_next];
-    int* uc_other = o.unit_count[o.uc_next ^ 1];
-    o.uc_next ^= 1;
-    OrdUnion* ustage = reinterpret_cast<OrdUnion*>(c->slot[bi].sel);
-    OrdBatchArgs a;
-    a.n_q = nq;
-    const unsigned impossible = fine ? 0xFFu : 0xFFFFu; // a query that falls back carries a key no row can reach
-    unsigned mk = impossible;
-    for (int q = 0; q < nq; ++q) {
-        a.q[q].now = qs[q].now;
-        a.q[q].cutoff = qs[q].cutoff;
-        a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));
-        a.q[q].now_key = b.fallback[q0 + q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
-        a.q[q].pad = 0;
-        if (a.q[q].now_key < mk) mk = a.q[q].now_key;
-    }
-    a.min_key = mk;
-    const int chunk_shift = 9; // 512 positions per chunk for both key widths (see k_ord_batch_scan)
-    const long long n_chunks = (o.n + (1 << chunk_shift) - 1) >> chunk_shift;
-    const long long units_stride = o.units_cap, group_stride = o.units_cap / 1024 + 2, sum_stride = (long long)ord_sum_bytes();
-    Summary* sum0 = reinterpret_cast<Summary*>(sums);
-    if (fine) {
-        const int gm = o.grid_mult;
-        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * gm ? (n_chunks + 3) / 4 : (long long)c->n_cus * gm;
-        if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
-    } else {
-        long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
-        if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
-    }
-    if (b.ev_index >= 0 && q0 == 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
-    hipLaunchKernelGGL(k_ord_batch_count, dim3((unsigned)c->n_cus * 8), dim3(256), 0, s, ustage, uc, n_chunks, chunk_shift, nq, o.bq_count, units_stride, o.bq_runflag);
-    long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
-    if (n_groups < 1) n_groups = 1;
-    const unsigned pre_grid = (unsigned)(n_groups < (long long)c->n_cus ? n_groups : (long long)c->n_cus);
-    hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid, (unsigned)nq), dim3(256), 0, s, o.bq_count, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase,
-                       (OrdCtl*)nullptr, sum0, units_stride, group_stride, sum_stride);
-    hipLaunchKernelGGL(k_ord_prefix_groups, dim3((unsigned)nq), dim3(256), 0, s, n_chunks, o.bq_gsum, o.bq_gbase, sum0, group_stride, sum_stride);
-    const int copy_blocks = c->n_cus * 8;
-    const int fin_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
-    hipLaunchKernelGGL(k_ord_batch_emit, dim3((unsigned)(copy_blocks + fin_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks,
-                       nq, ustage, uc, o.bq_local, o.bq_gbase, units_stride, group_stride, o.pay, b.out_idx + (long long)q0 * batch_out_stride(c), batch_out_stride(c),
-                       b.offsets + (long long)q0 * batch_users_stride(c), b.counts_ord + (long long)q0 * batch_users_stride(c), batch_users_stride(c), copy_blocks,
-                       sum0, sum_stride, uc_other, o.units_cap, o.bq_runflag, o.bq_count);
-    hipLaunchKernelGGL(k_ord_publish, dim3((unsigned)nq), dim3(64), 0, s, sum0, b.h_sum_dev + q0, b.seq, sum_stride);
-}
+void fill_batch_tables(const pie_ctx* c, const BatchSlot& b, const pie_query* qs, const unsigned* nk, BatchTables& t);
 
-// the union form (<= kOrdBatchMax queries): scan, ONE prefix, emit, publish — see pie_ordered.h
+// a batch on the ordered run (up to 64 queries): scan, ONE prefix, emit, publish — see pie_ordered.h "the UNION form"
 void launch_ordered_union(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_query* qs, bool fine)
 {
     OrderedRun& o = c->ord;
-    const int bi = (int)(&b - c->bslot) & 1;
+    const int bi = (int)(&b - c->bslot) & 1; // scratch (staging, device summary) of two sets: chains run one after the other in the stream
     char* sums = o.bq_sum[bi];
     int* uc = o.unit_count[o.uc_next];
     int* uc_other = o.unit_count[o.uc_next ^ 1];
     o.uc_next ^= 1;
     OrdUnion* ustage = reinterpret_cast<OrdUnion*>(c->slot[bi].sel);
-    OrdBatchArgs a;
-    a.n_q = b.n_q;
-    const unsigned impossible = fine ? 0xFFu : 0xFFFFu;
-    unsigned mk = impossible;
+    const unsigned impossible = fine ? 0xFFu : 0xFFFFu; // (a query that falls back is not in the tables)
+    unsigned mk = impossible, nk[kBatchMax];
     for (int q = 0; q < b.n_q; ++q) {
-        a.q[q].now = qs[q].now;
-        a.q[q].cutoff = qs[q].cutoff;
-        a.q[q].mask = c->n_disc >= 64 ? qs[q].mask : (qs[q].mask & ((1ull << c->n_disc) - 1ull));
-        a.q[q].now_key = b.fallback[q] ? impossible : (fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now));
-        a.q[q].pad = 0;
-        if (a.q[q].now_key < mk) mk = a.q[q].now_key;
+        nk[q] = fine ? host_fine_key_of(c, qs[q].now) : host_key_of(c, qs[q].now);
+        if (!b.fallback[q] && nk[q] < mk) mk = nk[q];
     }
-    a.min_key = mk;
+    BatchTables tab;
+    fill_batch_tables(c, b, qs, nk, tab);
     const int chunk_shift = 9;
     const long long n_chunks = (o.n + (1 << chunk_shift) - 1) >> chunk_shift;
     Summary* sum0 = reinterpret_cast<Summary*>(sums);
-    unsigned int* mq_slots = reinterpret_cast<unsigned int*>(sums + (size_t)kBatchMax * ord_sum_bytes()); // behind the per-query summaries: its own, zero between batches
+    unsigned int* mq_slots = reinterpret_cast<unsigned int*>(sums + ord_sum_bytes()); // behind the summary: its own, zero between batches
     if (fine) {
         const int gm = o.grid_mult;
         long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * gm ? (n_chunks + 3) / 4 : (long long)c->n_cus * gm;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((k_ord_batch_scan<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, a, ustage, uc, sum0);
+        hipLaunchKernelGGL((k_ord_batch_scan_t<fkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.fkey, o.n, n_chunks, mk, tab, ustage, uc, sum0);
     } else {
         long long grid = (n_chunks + 3) / 4 < (long long)c->n_cus * 6 ? (n_chunks + 3) / 4 : (long long)c->n_cus * 6;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL((k_ord_batch_scan<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, a, ustage, uc, sum0);
+        hipLaunchKernelGGL((k_ord_batch_scan_t<lkey_t>), dim3((unsigned)grid), dim3(256), 0, s, o.pay, o.end, o.key, o.n, n_chunks, mk, tab, ustage, uc, sum0);
     }
     if (b.ev_index >= 0) (void)hipEventRecord(c->ring[b.ev_index].e1, s);
     long long n_groups = (n_chunks + kOrdGroup - 1) >> kOrdGroupShift;
@@ -1407,8 +1339,13 @@ void launch_ordered_union(pie_ctx* c, BatchSlot& b, hipStream_t s, const pie_que
     hipLaunchKernelGGL(k_ord_prefix, dim3(pre_grid), dim3(256), 0, s, uc, n_chunks, o.bq_local, o.bq_gsum, o.bq_gbase, o.bq_ctl, sum0, 0LL, 0LL, 0LL);
     const int copy_blocks = c->n_cus * 8;
     const int user_blocks = (int)(((long long)c->n_users + 1 + 254) / 255);
-    hipLaunchKernelGGL(k_ord_union_emit, dim3((unsigned)(copy_blocks + user_blocks)), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks, b.n_q,
-                       ustage, uc, o.bq_local, o.bq_gbase, b.uoff, b.urows, b.umlo, (long long)batch_ucap(c), copy_blocks, sum0, mq_slots, uc_other, o.units_cap);
+    const unsigned egrid = (unsigned)(copy_blocks + user_blocks);
+    if (b.n_q > 32)
+        hipLaunchKernelGGL((k_ord_union_emit<true>), dim3(egrid), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks, b.n_q, tab, ustage, uc, o.bq_local,
+                           o.bq_gbase, b.uoff, b.urows, b.umlo, b.umhi, (long long)batch_ucap(c), copy_blocks, sum0, mq_slots, uc_other, o.units_cap);
+    else
+        hipLaunchKernelGGL((k_ord_union_emit<false>), dim3(egrid), dim3(256), 0, s, o.uoff, c->n_users, o.n, chunk_shift, n_chunks, b.n_q, tab, ustage, uc, o.bq_local,
+                           o.bq_gbase, b.uoff, b.urows, b.umlo, b.umhi, (long long)batch_ucap(c), copy_blocks, sum0, mq_slots, uc_other, o.units_cap);
     hipLaunchKernelGGL(k_ord_union_publish, dim3(1), dim3(256), 0, s, sum0, mq_slots, b.n_q, (long long)batch_ucap(c), b.bh_dev, b.seq);
 }
 
@@ -2028,7 +1965,7 @@ int ensure_batch(pie_ctx* c)
         PIE_HIP(c, hipMalloc(&b.uoff, ((size_t)c->cap_users + 2) * 8));
         PIE_HIP(c, hipMalloc(&b.urows, ucap * 4));
         PIE_HIP(c, hipMalloc(&b.umlo, ucap * 4));
-        PIE_HIP(c, hipMalloc(&b.umhi, slots * 4));
+        PIE_HIP(c, hipMalloc(&b.umhi, ucap * 4));
     }
     for (char*& sp : c->bspan) {
         PIE_HIP(c, hipMalloc(&sp, batch_span_bytes(c)));
@@ -2153,8 +2090,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; b.list_ok[q] = false; }
     b.ev_index = -1;
     b.ordered = false;
-    b.ord_union = false;
-    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c);
+    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c) && !c->ord_lists_only;
     b.unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
     // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
     // they would make every row a candidate for all queries; they run on the general path
@@ -2227,21 +2163,17 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         }
     }
     if (ord_batch) {
-        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column per 16 queries
+        // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for the batch (pie_ordered.h, the batched union form)
         rc = ord_batch_alloc(c);
         if (rc) return rc;
-        b.ord_union = n_q <= kOrdBatchMax && !c->ord_lists_only;
-        rc = b.ord_union ? ensure_batch(c) : ensure_lists(c, b, n_q);
+        rc = ensure_batch(c);
         if (rc) return rc;
         BatchSlot& prev = c->bslot[(c->b_next + kBatchSlots - 1) % kBatchSlots];
         if (c->b_flight >= 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
         b.seq = ++c->bseq_counter;
         c->scans_begun++;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
-        if (b.ord_union) launch_ordered_union(c, b, s, qs, fine);
-        else
-            for (int q0 = 0; q0 < n_q; q0 += kOrdBatchMax)
-                launch_ordered_batch(c, b, s, qs, fine, q0, n_q - q0 < kOrdBatchMax ? n_q - q0 : kOrdBatchMax);
+        launch_ordered_union(c, b, s, qs, fine);
         PIE_HIP(c, hipGetLastError());
         b.ordered = true;
         b.k2_pending = false;
@@ -2455,14 +2387,11 @@ int batch_finish(pie_ctx* c, int* ready_out)
             launch_batch_k2(c, b, s);
             PIE_HIP(c, hipGetLastError());
         }
-        // wait for the summary (mapped host memory, seq last); bounded like the single-scan wait.  The union tail publishes
-        // ONE summary for the batch; the ordered run's batched form one per query.
+        // wait for the batch's summary (mapped host memory, seq last); bounded like the single-scan wait
         timespec t0{};
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        const bool per_query = b.ordered && !b.ord_union;
-        const int n_wait = per_query ? b.n_q : 1;
-        for (int q = 0; q < n_wait; ++q) {
-            volatile unsigned long long* seq = per_query ? &b.h_sum[q].seq : &b.bh->seq;
+        {
+            volatile unsigned long long* seq = &b.bh->seq;
             unsigned long long spins = 0;
             while (*seq != b.seq) {
                 __builtin_ia32_pause();
@@ -2476,32 +2405,25 @@ int batch_finish(pie_ctx* c, int* ready_out)
                         b.in_flight = false;
                         c->b_flight--;
                         if (bad) return fail(c, PIE_E_HIP, "batched scan failed: %s", hipGetErrorString(e));
-                        return fail(c, PIE_E_HIP, "batch summary %d not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", q, waited_ms);
+                        return fail(c, PIE_E_HIP, "batch summary not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", waited_ms);
                     }
                 }
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         bool overflow = false;
-        if (per_query) {
-            for (int q = 0; q < b.n_q; ++q) {
-                b.last[q] = b.h_sum[q].s;
-                if (b.last[q].bad_rows > 0 || (long long)b.last[q].m > batch_out_stride(c)) b.fallback[q] = true;
-                b.idx_of[q] = b.out_idx + (long long)q * batch_out_stride(c);
-                b.list_ok[q] = !b.fallback[q];
-            }
-        } else {
+        {
             const Summary us = b.bh->s;
             b.mu = us.m;
-            // a union bucket outgrew its slots: rows were dropped, and nothing says which queries they belonged to, so every
-            // query of the batch is rerun on the general path
+            // a union bucket outgrew its slots (the general pass) / the union its arrays (the ordered run): rows were dropped, and
+            // nothing says which queries they belonged to, so every query of the batch is rerun on the general path
             overflow = us.n_over > 0 || us.bad_rows > 0;
             for (int q = 0; q < b.n_q; ++q) {
                 b.last[q] = us;                       // cand, chunk_max, bad_rows, n_over: the pass's; max_count: the union's
                 b.last[q].m = b.bh->mq[q];
                 if (overflow) b.fallback[q] = true;
             }
-            if (us.n_over > 0 && b.ordered) c->ord_lists_only = true; // the union outgrew its arrays on the run: such batches take the per-query chain
+            if (us.n_over > 0 && b.ordered) c->ord_lists_only = true; // the union outgrew its arrays on the run: its batches run as single scans from now on
             else if (us.n_over > 0) {
                 if (c->bdshift < kUnionShiftMax) c->bdshift_want = c->bdshift + 1;
                 else c->batch_poor = true; // a user's rows do not fit 64 slots: this table's batches go straight to the general path
@@ -2512,18 +2434,6 @@ int batch_finish(pie_ctx* c, int* ready_out)
             if (!b.ordered) choose_run_shift(c, us.cand, us.chunk_max, b.fine_key);
         }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
-        if (per_query && (b.msg_kind == 1 || b.msg_counts)) {
-            // the ordered chain writes no messages: pack them from the finished lists (the queries that fall back pack their own)
-            all_ready = false;
-            for (int q = 0; q < b.n_q; ++q) {
-                if (b.fallback[q]) continue;
-                if (b.msg_kind == 1) batch_pack_list_msg(c, b, q);
-                if (b.msg_counts)
-                    PIE_HIP(c, hipMemcpyAsync(b.msg_counts + (long long)q * b.msg_counts_stride, b.counts_ord + (long long)q * batch_users_stride(c),
-                                              (size_t)c->n_users * 4, hipMemcpyDefault, s));
-            }
-            PIE_HIP(c, hipGetLastError());
-        }
     }
     b.in_flight = false;
     c->b_flight--;
@@ -2544,7 +2454,7 @@ int batch_finish(pie_ctx* c, int* ready_out)
     c->last_was_batch = true;
     for (int q = 0; q < b.n_q; ++q)
         if (b.last[q].bad_rows) return fail(c, PIE_E_INVAL, "query %d: %u selected rows carry a user id outside [0, %d)", q, b.last[q].bad_rows, c->n_users);
-    if ((!b.ordered || b.ord_union) && (b.msg_kind == 1 || b.msg_counts)) {
+    if (b.msg_kind == 1 || b.msg_counts) {
         // per-query messages of a batch on the general pass: the lists are materialised from the union, then packed
         all_ready = false;
         int list[kBatchMax], n_list = 0;
@@ -2687,9 +2597,6 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
          (e = hipHostGetDevicePointer((void**)&c->ord.stale, c->ord.h_stale, 0)) == hipSuccess;
     if (ok) memset(c->ord.h_stale, 0, 64);
     for (BatchSlot& b : c->bslot) {
-        ok = ok && (e = hipHostMalloc(&b.h_sum, sizeof(HostSummary) * kBatchMax, hipHostMallocMapped)) == hipSuccess &&
-             (e = hipHostGetDevicePointer((void**)&b.h_sum_dev, b.h_sum, 0)) == hipSuccess;
-        if (ok) memset(b.h_sum, 0, sizeof(HostSummary) * kBatchMax);
         ok = ok && (e = hipHostMalloc(&b.bh, sizeof(BatchHost), hipHostMallocMapped)) == hipSuccess &&
              (e = hipHostGetDevicePointer((void**)&b.bh_dev, b.bh, 0)) == hipSuccess;
         if (ok) memset(b.bh, 0, sizeof(BatchHost));
@@ -2736,7 +2643,6 @@ int pie_ctx_destroy(pie_ctx* c)
         if (s.h_sum) (void)hipHostFree(s.h_sum);
     }
     for (BatchSlot& b : c->bslot) {
-        if (b.h_sum) (void)hipHostFree(b.h_sum);
         if (b.bh) (void)hipHostFree(b.bh);
     }
     if (c->ord.h_stale) (void)hipHostFree(c->ord.h_stale);
