@@ -178,9 +178,10 @@ int pie_host_free(pie_ctx *ctx, void *host_ptr);
 /* ---- batched scan: many feed requests, one table pass (SURVEY.md section 7 "batch many queries per launch"; the
  * north_star's "calendarFeed per-request loop -> batched GPU scan").  Every query has its own `now` (the request's clock,
  * server/sessionStore.js:67 samples one per scan), `cutoff` (server/calendarFeed.js:33-38) and discipline mask
- * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Up to three batches may be in
- * flight (begin(i+1), begin(i+2) before finish(i): the tail of batch i rides in the launch of batch i+1, and with a third batch
- * queued the GPU never waits for the host to react to a summary); single scans and batches do not mix in flight.
+ * (server/disciplineConfig.js:88-97; bits >= n_disc of pie_set_disciplines are ignored).  Up to three batches per lane (see
+ * pie_set_batch_lanes) may be in flight (begin(i+1), begin(i+2) before finish(i): the tail of batch i rides in the launch of the
+ * next batch of its lane, and with a third batch queued the GPU never waits for the host to react to a summary); single scans
+ * and batches do not mix in flight.
  *
  * The PRIMARY result of a batch is the UNION of its queries' selections: per user the rows that ANY query selected, in
  * (start, row) order, with a query mask per row —
@@ -210,6 +211,18 @@ int pie_batch_union_device_ptrs(pie_ctx *ctx, void **uoff_dev /* int64[U+1] */, 
                                 void **mask_lo_dev /* uint32[Mu]: queries 0..31 */, void **mask_hi_dev /* uint32[Mu]: 32..63, NULL for n_q <= 32 */,
                                 size_t *mu_out);
 int pie_batch_read_union(pie_ctx *ctx, int64_t *uoff_out, int32_t *rows_out, uint64_t *masks_out, size_t cap, size_t *mu_out);
+/* Batch LANES.  A batch over a shard-sized table (a tenth of 10^8 rows) is one launch of ~20 us that occupies a fraction of
+ * the chip: its time is latency, not bytes, and that floor is what would cap an 8-GPU split of the table at 2.5x.  A context
+ * therefore deals its batches to up to four lanes — independent pipelines, each with its own HIP stream, three batch slots and
+ * spans — whose launches run SIDE BY SIDE on the chip; pie_scan_batch_begin picks the lane (round robin),
+ * pie_scan_batch_finish returns batches in the order they were begun, so callers do not change: with n lanes up to 3 n batches
+ * may be in flight.  n_lanes 1..4 pins the number, 0 (default; PIE_BATCH_LANES) chooses by table size: 4 up to 2^25 rows, 3
+ * above.  Batches on the ordered run and batches that only fall back stay on lane 0.  Reading a finished batch's arrays
+ * on the context's stream is ordered behind the lane by the library; the messages of pie_scan_batch_begin_union are complete
+ * when finish says ready, as before.  There is no counterpart in the reference (one request at a time,
+ * server/index.js:293-302). */
+int pie_set_batch_lanes(pie_ctx *ctx, int n_lanes);
+int pie_batch_lanes(pie_ctx *ctx); /* lanes in use now */
 /* A batch that also writes the multi-GPU exchange message as it goes — ONE union message for the whole batch:
  *   msg (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | mask_lo[0..cap) | mask_hi[0..cap) (only when n_q > 32) ]
  * u_pad + 2 + 2 * cap words (3 * cap for n_q > 32); uoff[u] = Mu for u >= users; rows beyond cap are dropped (Mu says how many
@@ -377,8 +390,8 @@ int pie_comm_read_gathered(pie_comm *comm, int32_t at_rank, int32_t src_rank, in
 /* ---- the pipelined exchange: ONE union message per step (layout: pie_scan_batch_begin_union), written by each shard's own
  * batch kernels; the exchange of step i runs on a side stream while the shards scan steps i+1, i+2.  Order of calls:
  *     step_reserve;  begin(0); begin(1); finish(0); begin(2); collect(0); finish(1); begin(3); collect(1); ...
- * at most two steps begun and unfinished, at most four uncollected (rotating buffer sets).  Every rank of a
- * process-per-GPU communicator makes the same calls in the same order.
+ * at most three steps per batch lane of the shards (pie_set_batch_lanes: 3 .. 12) begun and unfinished, at most sixteen
+ * uncollected (rotating buffer sets).  Every rank of a process-per-GPU communicator makes the same calls in the same order.
  * step_reserve: u_pad as in pie_comm_scan_batch_gather; union_cap = rows per message.
  * step_finish:  waits for the oldest begun step's summaries on every local shard (m_out: local_ranks x n_q, may be NULL),
  *               then queues its exchange; does not wait for it.

@@ -84,6 +84,8 @@ _SIGS = [
     ("pie_host_free", C.c_int, [_P, _P]),
     ("pie_set_scan_form", C.c_int, [_P, C.c_int]),
     ("pie_set_ordered_run", C.c_int, [_P, C.c_int]),
+    ("pie_set_batch_lanes", C.c_int, [_P, C.c_int]),
+    ("pie_batch_lanes", C.c_int, [_P]),
     ("pie_batch_pack_union_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
@@ -522,10 +524,18 @@ class PieScan:
         self._check(self._lib.pie_batch_result_device_ptrs(self._ctx, int(qi), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def set_batch_lanes(self, n_lanes):
+        """Lanes of the batched scan (independent streams, three batches in flight on each): 1..4, 0 = by table size."""
+        self._check(self._lib.pie_set_batch_lanes(self._ctx, int(n_lanes)))
+
+    def batch_lanes(self):
+        return int(self._lib.pie_batch_lanes(self._ctx))
+
     def scan_batch_pipelined(self, k, queries, depth=3):
-        """k batches of the same queries with up to `depth` (<= 3) in flight: the next launch is queued before the host waits for
-        a summary.  -> list of M of the last batch."""
+        """k batches of the same queries with up to `depth` (<= 3) in flight PER LANE: the next launch is queued before the host
+        waits for a summary.  -> list of M of the last batch."""
         ms, begun, done = [], 0, 0
+        depth = depth * self.batch_lanes()
         while done < k:
             while begun < k and begun - done < depth:
                 self.scan_batch_begin(queries)

@@ -102,17 +102,17 @@ struct pie_comm {
     int last_nq = 0;
     long long need = 0;            // row capacity the last exchange called for (the largest list / union any rank reported)
     // pipelined union exchange (pie_comm_step_*): kSets rotating buffer sets per local rank, a side stream per local rank
-    static constexpr int kSets = 4;
+    static constexpr int kSets = 16;  // (twelve steps begun on four batch lanes + the exchanges queued and being read)
     std::vector<hipStream_t> xstream;                 // local index -> exchange stream
     std::vector<int*> umsg[kSets], ugath[kSets];      // [set][local index]: this rank's union message / the gathered ones [world][UL]
     std::vector<hipEvent_t> ev_ready[kSets], ev_done[kSets];
-    int* h_mu[kSets] = {nullptr, nullptr, nullptr, nullptr}; // mapped pinned: [local index][world] the Mu word of every gathered message
-    int* h_mu_dev[kSets] = {nullptr, nullptr, nullptr, nullptr};
+    int* h_mu[kSets] = {}; // mapped pinned: [local index][world] the Mu word of every gathered message
+    int* h_mu_dev[kSets] = {};
     long long u_cap = 0, UL = 0;   // union rows per message, words per message (u_pad + 2 + mask_words' share)
     int u_words = 2;               // words per union row in a message: row + one or two mask words
     long long begun = 0, finished = 0, collected = 0;  // steps begun / exchanges issued / exchanges collected
-    int step_nq[kSets] = {0, 0, 0, 0};
-    int step_rc[kSets] = {0, 0, 0, 0};   // a step whose finish failed on this process: its collect reports it
+    int step_nq[kSets] = {};
+    int step_rc[kSets] = {};   // a step whose finish failed on this process: its collect reports it
     char err[512] = "";
 };
 
@@ -523,13 +523,26 @@ int pie_comm_step_reserve(pie_comm* c, int32_t n_q, int32_t u_pad_in, size_t uni
     return ensure_step_buffers(c, n_q, u_pad, (long long)(union_cap > 0 ? union_cap : 1024));
 }
 
+constexpr int kMaxLanesOfAShard = 4;
+
 int pie_comm_step_begin(pie_comm* c, const pie_query* queries, int32_t n_q)
 {
     if (!c) return PIE_E_INVAL;
     if (!queries || n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", PIE_BATCH_MAX, n_q);
     if (c->UL <= 0) return cfail(c, PIE_E_STATE, "pie_comm_step_reserve first");
     if ((n_q > 32 ? 3 : 2) > c->u_words) return cfail(c, PIE_E_STATE, "reserved for batches of at most 32 queries: pie_comm_step_reserve again");
-    if (c->begun - c->finished >= 2) return cfail(c, PIE_E_STATE, "two steps are already begun: pie_comm_step_finish first");
+    {
+        // steps begun and unfinished: what the shards' batch lanes hold (three batches per lane, pie_set_batch_lanes), at least two
+        int depth = 3 * kMaxLanesOfAShard;
+        for (int k = 0; k < c->n_local; ++k) {
+            const int d = 3 * pie_batch_lanes(c->ctx[k]);
+            if (d < depth) depth = d;
+        }
+        if (depth > pie_comm::kSets - 4) depth = pie_comm::kSets - 4;
+        if (depth < 2) depth = 2;
+        if (c->begun - c->finished >= depth)
+            return cfail(c, PIE_E_STATE, "%d steps are already begun (three per batch lane of the shards): pie_comm_step_finish first", depth);
+    }
     if (c->begun - c->collected >= pie_comm::kSets) return cfail(c, PIE_E_STATE, "%d steps are uncollected: pie_comm_step_collect first", pie_comm::kSets);
     const int s = (int)(c->begun % pie_comm::kSets);
     int begun = 0, rc = PIE_OK;

@@ -106,6 +106,7 @@ struct Slot {
 // microsecond it is late the GPU idles (8 - 12 us per 54 us launch at 64 queries per batch, rocprofv3 timeline).  With three
 // the next launch is always queued before the host waits.
 constexpr int kBatchSlots = 3;
+constexpr int kLaneMax = 4;     // batch lanes of a context (pie_set_batch_lanes): independent streams, kBatchSlots batches in flight on each
 
 // everything one batch of queries owns (see pie_kernels.h "batched scan").  The primary result of a batch on the general pass
 // is the UNION (uoff / urows / umlo / umhi); per-query lists are materialised from it on request, or produced directly by the
@@ -150,6 +151,9 @@ struct BatchSlot {
     long long msg_counts_stride = 0;
     int k1_blocks = 0;
     int ev_index = -1;
+    int lane = 0;                      // the lane (stream) the batch ran on
+    hipStream_t stream = nullptr;
+    bool main_ordered = true;          // the context's main stream is ordered behind the batch's kernels (see order_after_batch)
 };
 
 // the ordered run of the resident table (pie_ordered.h)
@@ -235,6 +239,7 @@ struct pie_ctx {
     bool fkey_poor = false;     // a fine-keyed scan found too many ambiguous rows: use the 15-bit key
     unsigned int* d_hist = nullptr;
     std::vector<unsigned int> key_hist;  // host copy of the key histogram of the last full key build (8 keys per bin)
+    std::vector<unsigned long long> key_hist_above; // key_hist_above[b] = rows in bins b .. end (what every begin asks for, per query)
     long long key_hist_rows = 0;         // rows it covers
     long long key_base = 0;
     int key_shift = 0;
@@ -289,16 +294,34 @@ struct pie_ctx {
     OrderedRun ord;
     bool ord_building = false;  // the scan being begun is the ordered run's build
     Slot slot[2];
-    BatchSlot bslot[kBatchSlots]; // batched scans (pie_scan_batch_begin): up to three batches may be in flight
-    char* bspan[3] = {nullptr, nullptr, nullptr}; // rotating batch spans (batch_span_bytes each)
+    // Batch lanes.  A batch over a SHARD-sized table (a tenth of cfg3) is one launch of ~20 us that fills a fraction of the chip:
+    // its time is latency (key load -> candidate gather -> atomic -> store; then the tail's prefix chain), not bytes.  Lanes are
+    // independent pipelines — own stream, own three slots, own spans — so batches of different lanes run SIDE BY SIDE on the chip;
+    // begin deals batches to the lanes round robin, finish returns them in the order they were begun (profiles/r03_zg_lanes.txt:
+    // 1.25 x 10^7 rows, 64 queries: 20.9 us per batch on one lane, 7.8 on four).  Lane 0 is the context's main stream.
+    BatchSlot bslot[kLaneMax * kBatchSlots]; // lane l: slots [l * kBatchSlots, (l + 1) * kBatchSlots)
+    char* bspan[kLaneMax * 3] = {};          // lane l: rotating batch spans [3 l, 3 l + 3) (batch_span_bytes each)
+    hipStream_t lane_stream[kLaneMax] = {};  // [0] unused (= stream); the others are created with the lane
+    hipEvent_t lane_event[kLaneMax][2] = {}; // per lane: [0] orders the lane behind the main stream (idle_epoch), [1] the main stream behind the lane (order_after_batch)
+    int n_lanes = 1;                         // lanes begin deals to (pie_set_batch_lanes / PIE_BATCH_LANES; 0 there = by table size)
+    int lanes_want = 0;                      // what the caller asked for (0: automatic)
+    int lane_rr = 0;                         // lane the next begin tries first
+    int lane_flight[kLaneMax] = {};          // batches in flight per lane
+    int lane_next[kLaneMax] = {};            // slot (0..kBatchSlots) the lane's next begin uses
+    int lane_span_next[kLaneMax] = {};
+    bool lane_alloc[kLaneMax] = {};          // the lane's slot arrays and spans exist
+    unsigned char fifo[kLaneMax * kBatchSlots] = {}; // lanes of the batches in flight, in the order they were begun
+    int fifo_head = 0;
+    // Table changes (loads, appends, touches, key builds) are queued on the MAIN stream and only happen while no batch is in
+    // flight; some return with kernels still queued (the fine key of a load).  A lane's stream knows nothing of the main
+    // stream, so the first batch a lane begins after the context was idle waits for what the main stream holds.
+    unsigned long long idle_epoch = 1;                // bumped whenever the last batch in flight leaves
+    unsigned long long lane_epoch[kLaneMax] = {};     // the idle epoch the lane's stream was last ordered behind the main stream in
     long long* d_mat_tile = nullptr;   // materialisation scratch: [kBatchMax][tiles + 1] tile sums / prefixes
     unsigned int* d_mat_qmax = nullptr; // ... [kBatchMax] largest per-user count
     int mat_tiles = 0;
-    int bspan_next = 0;
-    int b_next = 0;             // batch slot the next begin uses
-    int b_flight = 0;           // batches begun and not finished (0..2)
+    int b_flight = 0;           // batches begun and not finished, all lanes
     BatchSlot* bres = nullptr;  // last finished batch
-    bool batch_alloc = false;
     int bdshift = 4;            // log2 of the union bucket capacity of the batched pass (16 .. 64 slots per user)
     int bdshift_want = 4;       // capacity the last finished batch asked for (applied at the next begin with nothing in flight)
     int run_shift = 0;          // chunk interleave of the keyed / batched table pass: 0 = fully interleaved (dense stretches of
@@ -351,6 +374,38 @@ int fail(pie_ctx* c, int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+
+// Host-time profile of the batched begin / finish (builds with -DPIE_HOST_PROF only: tools/host_prof.sh); totals go to stderr
+// when a context is destroyed.
+#ifdef PIE_HOST_PROF
+struct HostProf {
+    double acc[16] = {0};
+    unsigned long long n[16] = {0};
+    timespec last{};
+    void start() { clock_gettime(CLOCK_MONOTONIC, &last); }
+    void tick(int i)
+    {
+        timespec t{};
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        acc[i] += (double)(t.tv_sec - last.tv_sec) * 1e6 + (double)(t.tv_nsec - last.tv_nsec) * 1e-3;
+        n[i]++;
+        last = t;
+    }
+    void report() const
+    {
+        static const char* names[16] = {"begin: checks + dense test", "begin: slot / span set-up", "begin: tables", "begin: launch", "begin: rest",
+                                        "finish: k2 launch", "finish: wait", "finish: rest", "", "", "", "", "", "", "", ""};
+        for (int i = 0; i < 8; ++i)
+            if (n[i]) fprintf(stderr, "[pie host prof] %-28s %8.3f us x %llu\n", names[i], acc[i] / (double)n[i], n[i]);
+    }
+};
+HostProf g_prof;
+#define PIE_PROF_START() g_prof.start()
+#define PIE_PROF_TICK(i) g_prof.tick(i)
+#else
+#define PIE_PROF_START() ((void)0)
+#define PIE_PROF_TICK(i) ((void)0)
+#endif
 
 #define PIE_HIP(c, call)                                                                              \
     do {                                                                                              \
@@ -406,11 +461,14 @@ void free_batch(pie_ctx* c)
     for (char*& sp : c->bspan) dfree(sp);
     dfree(c->d_mat_tile); dfree(c->d_mat_qmax);
     c->mat_tiles = 0;
-    c->bspan_next = 0;
-    c->b_next = 0;
+    for (int l = 0; l < kLaneMax; ++l) {
+        c->lane_flight[l] = c->lane_next[l] = c->lane_span_next[l] = 0;
+        c->lane_alloc[l] = false;
+    }
+    c->fifo_head = 0;
+    c->lane_rr = 0;
     c->b_flight = 0;
     c->bres = nullptr;
-    c->batch_alloc = false;
 }
 
 void ord_free(pie_ctx* c)
@@ -464,6 +522,8 @@ OrdMirror ord_mirror_of(const pie_ctx* c)
 
 void free_table(pie_ctx* c)
 {
+    for (int l = 1; l < kLaneMax; ++l) // nothing of a lane's may still be running when its arrays go
+        if (c->lane_stream[l]) (void)hipStreamSynchronize(c->lane_stream[l]);
     dfree(c->d_union); dfree(c->d_union_cnt); dfree(c->d_union_local); dfree(c->d_union_off);
     c->union_users = 0;
     ord_free(c);
@@ -490,6 +550,8 @@ DirectSlots direct_of(const pie_ctx* c, const Slot& sl)
 int sync_all(pie_ctx* c)
 {
     PIE_HIP(c, hipStreamSynchronize(c->stream));
+    for (int l = 1; l < kLaneMax; ++l)
+        if (c->lane_stream[l]) PIE_HIP(c, hipStreamSynchronize(c->lane_stream[l]));
     return PIE_OK;
 }
 
@@ -516,8 +578,18 @@ void plan_one(pie_ctx* c, int which, long long want, const char* env)
     if (c->plan_blocks[which] < 1) c->plan_blocks[which] = 1;
 }
 
+// Lanes of the batched scan (see pie_ctx::bslot): as many as the caller pinned, else by the size of the table — a batch over a
+// small table is latency, and several side by side fill the chip; over the whole of cfg3 one batch already does
+// (profiles/r03_zg_lanes.txt).
+void choose_lanes(pie_ctx* c)
+{
+    if (c->lanes_want > 0) c->n_lanes = c->lanes_want;
+    else c->n_lanes = c->n <= (1LL << 25) ? 4 : 3; // (10^8 rows: 53 / 42.5 / 41.5 / 41.6 us per 64-query batch on 1 / 2 / 3 / 4 lanes)
+}
+
 void plan_k1(pie_ctx* c)
 {
+    choose_lanes(c);
     plan_one(c, 0, (long long)c->n_cus * 48, "PIE_K1_BLOCKS");
     plan_one(c, 1, (long long)c->n_cus * 16, "PIE_K1_BLOCKS_LIVE");
     plan_one(c, 2, (long long)c->n_cus * 32, "PIE_K1_BLOCKS_KEYED");
@@ -755,6 +827,8 @@ int build_keys(pie_ctx* c, long long row0, bool rebuild = false)
         PIE_HIP(c, hipStreamSynchronize(s));
         c->key_hist = hist;
         c->key_hist_rows = c->n;
+        c->key_hist_above.assign((size_t)kKeyHistBins + 1, 0ull);
+        for (int b = kKeyHistBins - 1; b >= 0; --b) c->key_hist_above[(size_t)b] = c->key_hist_above[(size_t)b + 1] + hist[(size_t)b];
         unsigned long long cum = 0;
         int bin = 0, top_bin = 0;
         for (int b = 0; b < kKeyHistBins; ++b)
@@ -796,6 +870,14 @@ unsigned host_key_of(const pie_ctx* c, long long e)
     if (e < c->key_base) return 0u;
     const unsigned long long k = ((unsigned long long)e - (unsigned long long)c->key_base) >> c->key_shift;
     return k >= (unsigned long long)(kKeyMax - 1u) ? kKeyMax : (unsigned)k + 1u;
+}
+
+// rows whose 15-bit key lies in the histogram bin of key(now) or above: an upper bound on the rows live at `now`
+// (valid while the histogram describes the table: !key_dirty && key_hist_rows == n)
+unsigned long long rows_keyed_at_or_above(const pie_ctx* c, long long now)
+{
+    const size_t bin = (size_t)(host_key_of(c, now) >> 3);
+    return bin < c->key_hist_above.size() ? c->key_hist_above[bin] : 0ull;
 }
 
 unsigned host_fine_key_of(const pie_ctx* c, long long e)
@@ -1364,9 +1446,7 @@ bool ordered_keyed_form(const pie_ctx* c, long long now)
     if (c->key_poor) return false;
     double frac = c->live_frac >= 0 ? c->live_frac : 1.0;
     if (!c->key_dirty && c->key_hist_rows == c->n && c->n > 0) {
-        unsigned long long at_or_above = 0;
-        for (int b = (int)(host_key_of(c, now) >> 3); b < kKeyHistBins; ++b) at_or_above += c->key_hist[(size_t)b];
-        frac = (double)at_or_above / (double)c->n;
+        frac = (double)rows_keyed_at_or_above(c, now) / (double)c->n;
     }
     return frac < 0.08;
 }
@@ -1508,10 +1588,7 @@ int scan_begin(pie_ctx* c, long long now, long long cutoff, int* msg, int msg_u_
              c->key_hist_rows == c->n && c->n > 0) {
         // first scan of a table: no scan has counted live rows yet, but the key histogram taken when the key columns were
         // built bounds them: rows whose key bin lies at or above the bin of key(now) (an upper bound on the live rows)
-        const int bin = (int)(host_key_of(c, now) >> 3);
-        unsigned long long at_or_above = 0;
-        for (int b = bin; b < kKeyHistBins; ++b) at_or_above += c->key_hist[(size_t)b];
-        if ((double)at_or_above < kLiveFirstBelow * (double)c->n) {
+        if ((double)rows_keyed_at_or_above(c, now) < kLiveFirstBelow * (double)c->n) {
             sl.variant = c->k1_keyed & ~0x800;
             if ((c->k1_keyed & 0x800) && now >= c->fkey_base) sl.variant |= 0x800;
         }
@@ -1954,12 +2031,26 @@ size_t batch_ucap(const pie_ctx* c)
     return slots > rows16 ? slots : rows16;
 }
 
-int ensure_batch(pie_ctx* c)
+bool any_lane_alloc(const pie_ctx* c)
 {
-    if (c->batch_alloc) return PIE_OK;
+    for (bool a : c->lane_alloc)
+        if (a) return true;
+    return false;
+}
+
+hipStream_t lane_stream_of(const pie_ctx* c, int lane) { return lane == 0 ? c->stream : c->lane_stream[lane]; }
+
+// the slot arrays and spans of one lane (and, for lanes above 0, its stream)
+int ensure_batch(pie_ctx* c, int lane)
+{
+    if (c->lane_alloc[lane]) return PIE_OK;
+    if (lane > 0 && !c->lane_stream[lane]) PIE_HIP(c, hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+    for (hipEvent_t& e : c->lane_event[lane])
+        if (!e) PIE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t slots = (size_t)c->cap_users << c->bdshift;
     const size_t ucap = batch_ucap(c);
-    for (BatchSlot& b : c->bslot) {
+    for (int i = 0; i < kBatchSlots; ++i) {
+        BatchSlot& b = c->bslot[lane * kBatchSlots + i];
         PIE_HIP(c, hipMalloc(&b.direct, slots * sizeof(BktRec)));
         PIE_HIP(c, hipMalloc(&b.direct_hi, slots * 4));
         PIE_HIP(c, hipMalloc(&b.uoff, ((size_t)c->cap_users + 2) * 8));
@@ -1967,12 +2058,13 @@ int ensure_batch(pie_ctx* c)
         PIE_HIP(c, hipMalloc(&b.umlo, ucap * 4));
         PIE_HIP(c, hipMalloc(&b.umhi, ucap * 4));
     }
-    for (char*& sp : c->bspan) {
+    for (int i = 0; i < 3; ++i) {
+        char*& sp = c->bspan[lane * 3 + i];
         PIE_HIP(c, hipMalloc(&sp, batch_span_bytes(c)));
-        PIE_HIP(c, hipMemsetAsync(sp, 0, batch_span_bytes(c), c->stream));
+        PIE_HIP(c, hipMemsetAsync(sp, 0, batch_span_bytes(c), lane_stream_of(c, lane)));
     }
-    c->bspan_next = 0;
-    c->batch_alloc = true;
+    c->lane_span_next[lane] = 0;
+    c->lane_alloc[lane] = true;
     return PIE_OK;
 }
 
@@ -1994,10 +2086,43 @@ int ensure_lists(pie_ctx* c, BatchSlot& b, int n_q)
     return PIE_OK;
 }
 
+// batches finish in the order they were begun, whatever lane they ran on
 BatchSlot* oldest_batch(pie_ctx* c)
 {
     if (c->b_flight == 0) return nullptr;
-    return &c->bslot[(c->b_next + kBatchSlots - c->b_flight) % kBatchSlots];
+    const int lane = c->fifo[c->fifo_head];
+    return &c->bslot[lane * kBatchSlots + (c->lane_next[lane] + kBatchSlots - c->lane_flight[lane]) % kBatchSlots];
+}
+
+// bookkeeping of a batch that has been begun on `lane` in slot lane_next[lane]
+void batch_begun(pie_ctx* c, int lane)
+{
+    c->fifo[(c->fifo_head + c->b_flight) % (kLaneMax * kBatchSlots)] = (unsigned char)lane;
+    c->b_flight++;
+    c->lane_flight[lane]++;
+    c->lane_next[lane] = (c->lane_next[lane] + 1) % kBatchSlots;
+}
+
+// ... and of the oldest batch leaving the flight
+void batch_left(pie_ctx* c, BatchSlot& b)
+{
+    b.in_flight = false;
+    c->fifo_head = (c->fifo_head + 1) % (kLaneMax * kBatchSlots);
+    c->b_flight--;
+    c->lane_flight[b.lane]--;
+    if (c->b_flight == 0) c->idle_epoch++;
+}
+
+// Work about to be queued on the context's MAIN stream reads what batch b's kernels wrote on a lane's stream.  The host has
+// seen b's summary, but the launch that carried b's tail (the next table pass of that lane rides in it) may still be running,
+// and plain stores sit in the XCDs' L2s until a kernel ends: the main stream waits for what the lane has queued so far.
+int order_after_batch(pie_ctx* c, BatchSlot& b)
+{
+    if (b.main_ordered || b.stream == c->stream || !b.stream) { b.main_ordered = true; return PIE_OK; }
+    PIE_HIP(c, hipEventRecord(c->lane_event[b.lane][1], b.stream));
+    PIE_HIP(c, hipStreamWaitEvent(c->stream, c->lane_event[b.lane][1], 0));
+    b.main_ordered = true;
+    return PIE_OK;
 }
 
 void fill_tail_args(pie_ctx* c, BatchSlot& b, UnionTailArgs& t)
@@ -2072,13 +2197,48 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     if (c->cap_rows == 0) return fail(c, PIE_E_STATE, "no table loaded");
     if (!qs || n_q < 1 || n_q > kBatchMax) return fail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", kBatchMax, n_q);
     if (c->n_flight) return fail(c, PIE_E_STATE, "a single scan is in flight: finish it before beginning a batch");
-    if (c->b_flight >= kBatchSlots) return fail(c, PIE_E_STATE, "%d batches are already in flight: call pie_scan_batch_finish first", kBatchSlots);
+    PIE_PROF_START();
     if (c->key_rebuild && c->b_flight == 0) {
         int rc = build_keys(c, 0, true);
         if (rc) return rc;
     }
-    BatchSlot& b = c->bslot[c->b_next];
-    hipStream_t s = c->stream;
+    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c) && !c->ord_lists_only;
+    bool unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
+    // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
+    // they would make every row a candidate for all queries; they run on the general path
+    bool dense_q[kBatchMax];
+    int n_batched = 0;
+    bool fine = (c->k1_keyed & 0x800) && !c->fkey_poor;
+    if (!unsupported) {
+        const bool hist_ok = !c->key_dirty && c->key_hist_rows == c->n;
+        for (int q = 0; q < n_q; ++q) {
+            dense_q[q] = hist_ok && (double)rows_keyed_at_or_above(c, qs[q].now) >= kLiveFirstBelow * (double)c->n;
+            if (!dense_q[q]) {
+                ++n_batched;
+                if (qs[q].now < c->fkey_base) fine = false;
+            }
+        }
+        // nothing left to batch (every query is dense): no table pass at all — a pass whose smallest key is the impossible
+        // one would still make nearly every row a candidate (ADVICE r02)
+        if (n_batched == 0) unsupported = true;
+    }
+    // the lane: the general pass deals its batches round robin; a batch on the ordered run (its staging is the scan slots')
+    // and one that only falls back (scans on the main stream) stay on lane 0
+    int lane = 0;
+    {
+        const int lanes = (ord_batch || unsupported) ? 1 : c->n_lanes;
+        int tried = 0;
+        lane = lanes > 1 ? c->lane_rr % lanes : 0;
+        while (tried < lanes && c->lane_flight[lane] >= kBatchSlots) { lane = (lane + 1) % lanes; ++tried; }
+        if (tried == lanes)
+            return fail(c, PIE_E_STATE, "%d batches are already in flight (%d per lane, %d lane%s): call pie_scan_batch_finish first", c->b_flight,
+                        kBatchSlots, lanes, lanes > 1 ? "s" : "");
+        if (lanes > 1) c->lane_rr = (lane + 1) % lanes;
+    }
+    BatchSlot* const lane_slots = c->bslot + lane * kBatchSlots;
+    BatchSlot& b = lane_slots[c->lane_next[lane]];
+    hipStream_t s = lane_stream_of(c, lane);
+    b.lane = lane;
     b.n_q = n_q;
     b.have_result = false;
     b.union_ok = b.union_part = false;
@@ -2090,40 +2250,20 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     for (int q = 0; q < n_q; ++q) { b.q[q] = qs[q]; b.fallback[q] = false; b.idx_of[q] = nullptr; b.list_ok[q] = false; }
     b.ev_index = -1;
     b.ordered = false;
-    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c) && !c->ord_lists_only;
-    b.unsupported = !ord_batch && (!batch_supported(c) || c->key_poor || c->batch_poor);
-    // dense queries (the key histogram bounds their live rows above a tenth of the table) do not belong in a batch:
-    // they would make every row a candidate for all queries; they run on the general path
-    int n_batched = 0;
-    bool fine = (c->k1_keyed & 0x800) && !c->fkey_poor;
-    if (!b.unsupported) {
-        for (int q = 0; q < n_q; ++q) {
-            bool dense = false;
-            if (!c->key_dirty && c->key_hist_rows == c->n) {
-                const int bin = (int)(host_key_of(c, qs[q].now) >> 3);
-                unsigned long long at_or_above = 0;
-                for (int k = bin; k < kKeyHistBins; ++k) at_or_above += c->key_hist[(size_t)k];
-                dense = (double)at_or_above >= kLiveFirstBelow * (double)c->n;
-            }
-            b.fallback[q] = dense;
-            if (!dense) {
-                ++n_batched;
-                if (qs[q].now < c->fkey_base) fine = false;
-            }
-        }
-        // nothing left to batch (every query is dense): no table pass at all — a pass whose smallest key is the impossible
-        // one would still make nearly every row a candidate (ADVICE r02)
-        if (n_batched == 0) b.unsupported = true;
-    }
+    b.unsupported = unsupported;
+    b.stream = s;
+    b.main_ordered = lane == 0;
+    if (!unsupported)
+        for (int q = 0; q < n_q; ++q) b.fallback[q] = dense_q[q];
+    PIE_PROF_TICK(0);
     if (b.unsupported) { // finish() runs every query on the general path
         for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
         b.in_flight = true;
         b.k2_pending = false;
-        c->b_flight++;
-        c->b_next = (c->b_next + 1) % kBatchSlots;
+        batch_begun(c, lane);
         return PIE_OK;
     }
-    if (c->bdshift_want > c->bdshift && c->b_flight == 0 && c->batch_alloc) {
+    if (c->bdshift_want > c->bdshift && c->b_flight == 0 && any_lane_alloc(c)) {
         // larger union buckets for every user (a finished batch found one that outgrew its slots): both slots' arrays are
         // replaced; their contents are per-batch scratch
         int rc0 = sync_all(c);
@@ -2137,13 +2277,18 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
             }
             for (char*& sp : c->bspan) dfree(sp);
             c->bres = nullptr;
-            c->batch_alloc = false;
+            for (bool& a : c->lane_alloc) a = false;
         } else {
             c->bdshift_want = c->bdshift;
         }
     }
-    int rc = ord_batch ? PIE_OK : ensure_batch(c);
+    int rc = ord_batch ? PIE_OK : ensure_batch(c, lane);
     if (rc) return rc;
+    if (lane > 0 && c->lane_epoch[lane] != c->idle_epoch) { // see idle_epoch
+        PIE_HIP(c, hipEventRecord(c->lane_event[lane][0], c->stream));
+        PIE_HIP(c, hipStreamWaitEvent(s, c->lane_event[lane][0], 0));
+        c->lane_epoch[lane] = c->idle_epoch;
+    }
     b.fine_key = fine;
     b.dshift = c->bdshift;
     if (c->profiling && (c->scans_begun % (unsigned long long)c->profile_every) == 0) {
@@ -2166,10 +2311,10 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         // the table's batches do not fit the general pass (skewed users): ONE pass over the run's key column for the batch (pie_ordered.h, the batched union form)
         rc = ord_batch_alloc(c);
         if (rc) return rc;
-        rc = ensure_batch(c);
+        rc = ensure_batch(c, 0);
         if (rc) return rc;
-        BatchSlot& prev = c->bslot[(c->b_next + kBatchSlots - 1) % kBatchSlots];
-        if (c->b_flight >= 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
+        BatchSlot& prev = lane_slots[(c->lane_next[lane] + kBatchSlots - 1) % kBatchSlots];
+        if (c->lane_flight[lane] >= 1 && prev.in_flight && prev.k2_pending) launch_batch_k2(c, prev, s); // nothing carries it along
         b.seq = ++c->bseq_counter;
         c->scans_begun++;
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
@@ -2178,23 +2323,24 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         b.ordered = true;
         b.k2_pending = false;
         b.in_flight = true;
-        c->b_flight++;
-        c->b_next = (c->b_next + 1) % kBatchSlots;
+        batch_begun(c, lane);
         return PIE_OK;
     }
-    // spans: this batch's and the one its tail zeroes
-    b.span = c->bspan[c->bspan_next];
-    c->bspan_next = (c->bspan_next + 1) % 3;
-    b.zero_span = c->bspan[(c->bspan_next + 1) % 3];
+    // spans (the lane's own three): this batch's and the one its tail zeroes
+    char** const lane_spans = c->bspan + lane * 3;
+    b.span = lane_spans[c->lane_span_next[lane]];
+    c->lane_span_next[lane] = (c->lane_span_next[lane] + 1) % 3;
+    b.zero_span = lane_spans[(c->lane_span_next[lane] + 1) % 3];
     b.seq = ++c->bseq_counter;
     const int plan = fine ? 3 : 2;
     b.k1_blocks = c->plan_blocks[plan];
     c->scans_begun++;
-    BatchSlot& other = c->bslot[(c->b_next + kBatchSlots - 1) % kBatchSlots]; // the batch begun just before this one
-    const bool tail_waits = c->b_flight >= 1 && other.in_flight && other.k2_pending && !other.ordered;
+    BatchSlot& other = lane_slots[(c->lane_next[lane] + kBatchSlots - 1) % kBatchSlots]; // the batch begun just before this one on this lane
+    const bool tail_waits = c->lane_flight[lane] >= 1 && other.in_flight && other.k2_pending && !other.ordered;
     const bool ride = tail_waits && !c->no_ride;
     if (tail_waits && !ride) launch_batch_k2(c, other, s);
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e0, s));
+    PIE_PROF_TICK(1);
 #define PIE_BATCH_RIDE(KT, HI)                                                                                          \
     hipLaunchKernelGGL((k_scan_batch_with_tail<8, true, KT, HI>), dim3((unsigned)(b.k1_blocks + t.tiles)), dim3(kK1Threads), 0, s, a, t)
 #define PIE_BATCH(KT, KEYPTR, KEYFN, IMPOSSIBLE)                                                                         \
@@ -2213,6 +2359,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         }                                                                                                               \
         a.min_key = mk;                                                                                                 \
         fill_batch_tables(c, b, qs, nk, a.tab);                                                                         \
+        PIE_PROF_TICK(2);                                                                                               \
         if (ride) {                                                                                                     \
             UnionTailArgs t;                                                                                            \
             fill_tail_args(c, other, t);                                                                                \
@@ -2228,12 +2375,13 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
     else PIE_BATCH(lkey_t, c->d_key, host_key_of, 0xFFFFu);
 #undef PIE_BATCH
 #undef PIE_BATCH_RIDE
+    PIE_PROF_TICK(3);
     PIE_HIP(c, hipGetLastError());
     if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e1, s));
     b.k2_pending = true;
     b.in_flight = true;
-    c->b_flight++;
-    c->b_next = (c->b_next + 1) % kBatchSlots;
+    batch_begun(c, lane);
+    PIE_PROF_TICK(4);
     return PIE_OK;
 }
 
@@ -2380,13 +2528,15 @@ int batch_finish(pie_ctx* c, int* ready_out)
     BatchSlot* bp = oldest_batch(c);
     if (!bp) return fail(c, PIE_E_STATE, "pie_scan_batch_finish without pie_scan_batch_begin");
     BatchSlot& b = *bp;
-    hipStream_t s = c->stream;
+    hipStream_t s = b.stream ? b.stream : c->stream; // the lane the batch runs on
     bool all_ready = true;
+    PIE_PROF_START();
     if (!b.unsupported) {
         if (b.k2_pending) {
             launch_batch_k2(c, b, s);
             PIE_HIP(c, hipGetLastError());
         }
+        PIE_PROF_TICK(5);
         // wait for the batch's summary (mapped host memory, seq last); bounded like the single-scan wait
         timespec t0{};
         clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -2402,8 +2552,7 @@ int batch_finish(pie_ctx* c, int* ready_out)
                     const double waited_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
                     const bool bad = e != hipSuccess && e != hipErrorNotReady;
                     if (bad || waited_ms > c->wait_deadline_ms || (e == hipSuccess && *seq != b.seq && waited_ms > 1000.0)) {
-                        b.in_flight = false;
-                        c->b_flight--;
+                        batch_left(c, b);
                         if (bad) return fail(c, PIE_E_HIP, "batched scan failed: %s", hipGetErrorString(e));
                         return fail(c, PIE_E_HIP, "batch summary not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", waited_ms);
                     }
@@ -2411,6 +2560,7 @@ int batch_finish(pie_ctx* c, int* ready_out)
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        PIE_PROF_TICK(6);
         bool overflow = false;
         {
             const Summary us = b.bh->s;
@@ -2435,15 +2585,16 @@ int batch_finish(pie_ctx* c, int* ready_out)
         }
         if (b.ev_index >= 0) PIE_HIP(c, hipEventRecord(c->ring[b.ev_index].e2, s));
     }
-    b.in_flight = false;
-    c->b_flight--;
+    batch_left(c, b);
     {
         int list[kBatchMax], n_list = 0;
         for (int q = 0; q < b.n_q; ++q)
             if (b.fallback[q]) list[n_list++] = q;
         if (n_list) {
             all_ready = false;
-            int rc = ensure_lists(c, b, b.n_q);
+            int rc = order_after_batch(c, b); // what follows runs on the main stream
+            if (rc) return rc;
+            rc = ensure_lists(c, b, b.n_q);
             if (rc) return rc;
             rc = batch_fallback_many(c, b, list, n_list);
             if (rc) return rc;
@@ -2460,7 +2611,9 @@ int batch_finish(pie_ctx* c, int* ready_out)
         int list[kBatchMax], n_list = 0;
         for (int q = 0; q < b.n_q; ++q)
             if (!b.list_ok[q]) list[n_list++] = q;
-        int rc = batch_materialize(c, b, list, n_list);
+        int rc = order_after_batch(c, b);
+        if (rc) return rc;
+        rc = batch_materialize(c, b, list, n_list);
         if (rc) return rc;
         for (int i = 0; i < n_list; ++i) {
             const int q = list[i];
@@ -2474,10 +2627,13 @@ int batch_finish(pie_ctx* c, int* ready_out)
     if (b.msg_kind == 2 && (!b.union_ok || b.ordered)) {
         // no tail wrote the message (the batch ran on the ordered run: copied from its union; or queries fell back: merged from the lists)
         all_ready = false;
-        int rc = batch_pack_union(c, b, b.msg, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
+        int rc = order_after_batch(c, b);
+        if (rc) return rc;
+        rc = batch_pack_union(c, b, b.msg, (size_t)b.msg_u_pad, (size_t)b.msg_cap);
         if (rc) return rc;
     }
     if (ready_out) *ready_out = b.msg_kind ? (all_ready ? 1 : 0) : 1;
+    PIE_PROF_TICK(7);
     return PIE_OK;
 }
 
@@ -2583,7 +2739,11 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
         return fail(nullptr, PIE_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     }
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    bool ok = (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) == hipSuccess &&
+    bool ok = (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) == hipSuccess;
+    // the lanes' streams right behind the main one: the runtime deals its (four) hardware queues to streams in the order they
+    // first appear, and a lane that ends up sharing a queue with another lane runs behind it, not beside it
+    for (int l = 1; l < kLaneMax && ok; ++l) ok = (e = hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking)) == hipSuccess;
+    ok = ok &&
               (e = hipMalloc(&c->d_summary, sizeof(Summary))) == hipSuccess &&
               (e = hipMalloc(&c->d_range, 16)) == hipSuccess &&
               (e = hipMalloc(&c->d_hist, kKeyHistBins * sizeof(unsigned int))) == hipSuccess &&
@@ -2612,6 +2772,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
+    if (const char* v = getenv("PIE_BATCH_LANES")) { const int l = atoi(v); if (l >= 0 && l <= kLaneMax) c->lanes_want = l; }
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_RUN_SHIFT")) { const int r = atoi(v); if (r >= 0 && r <= 3) { c->run_shift = r; c->run_shift_pinned = true; } }
     if (const char* v = getenv("PIE_ORDERED")) { const int m = atoi(v); if (m >= 0 && m <= 2) c->ord.mode = m; }
@@ -2629,6 +2790,9 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
 int pie_ctx_destroy(pie_ctx* c)
 {
     if (!c) return PIE_OK;
+#ifdef PIE_HOST_PROF
+    g_prof.report();
+#endif
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_table(c);
@@ -2651,9 +2815,27 @@ int pie_ctx_destroy(pie_ctx* c)
     if (c->d_hist) (void)hipFree(c->d_hist);
     if (c->h_summary) (void)hipHostFree(c->h_summary);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (int l = 1; l < kLaneMax; ++l)
+        if (c->lane_stream[l]) (void)hipStreamDestroy(c->lane_stream[l]);
+    for (auto& pair : c->lane_event)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     delete c;
     return PIE_OK;
 }
+
+// Lanes of the batched scan: 1..4 pins the number, 0 chooses by the size of the resident table (whenever it changes).  May be
+// called at any time: a batch in flight stays on the lane it was begun on.
+int pie_set_batch_lanes(pie_ctx* c, int n_lanes)
+{
+    if (!c) return PIE_E_INVAL;
+    if (n_lanes < 0 || n_lanes > kLaneMax) return fail(c, PIE_E_INVAL, "lanes outside 0..%d", kLaneMax);
+    c->lanes_want = n_lanes;
+    choose_lanes(c);
+    return PIE_OK;
+}
+
+int pie_batch_lanes(pie_ctx* c) { return c ? c->n_lanes : 0; }
 
 int pie_ctx_set_stream(pie_ctx* c, void* hip_stream)
 {
@@ -3151,6 +3333,7 @@ int pie_batch_union_device_ptrs(pie_ctx* c, void** uoff_dev, void** rows_dev, vo
     if (mask_hi_dev) *mask_hi_dev = nullptr;
     if (mu_out) *mu_out = 0;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     const BatchSlot& b = *c->bres;
     if (!b.union_ok) return PIE_OK; // queries fell back / the batch ran on the ordered run: per-query lists only
     if (uoff_dev) *uoff_dev = b.uoff;
@@ -3166,6 +3349,7 @@ int pie_batch_read_union(pie_ctx* c, int64_t* uoff_out, int32_t* rows_out, uint6
     if (!c) return PIE_E_INVAL;
     if (mu_out) *mu_out = 0;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     const BatchSlot& b = *c->bres;
     if (!b.union_ok) return fail(c, PIE_E_STATE, "this batch has no union result (queries fell back to the general path, or it ran on the ordered run): read the per-query results");
     PIE_HIP(c, hipSetDevice(c->device));
@@ -3197,6 +3381,7 @@ int pie_batch_result_device_ptrs(pie_ctx* c, int qi, void** counts_dev, void** o
 {
     if (!c) return PIE_E_INVAL;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     if (qi < 0 || qi >= c->bres->n_q) return fail(c, PIE_E_INVAL, "query %d outside the batch of %d", qi, c->bres->n_q);
     PIE_HIP(c, hipSetDevice(c->device));
     int rc = batch_need_list(c, *c->bres, qi);
@@ -3213,6 +3398,7 @@ int pie_batch_read_user_feed(pie_ctx* c, int qi, int32_t user, int32_t* idx_out,
     if (!c) return PIE_E_INVAL;
     if (k_out) *k_out = 0;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     BatchSlot& b = *c->bres;
     if (qi < 0 || qi >= b.n_q) return fail(c, PIE_E_INVAL, "query %d outside the batch of %d", qi, b.n_q);
     if (user < 0 || user >= c->n_users) return PIE_OK;
@@ -3270,6 +3456,7 @@ int pie_batch_fetch_requests(pie_ctx* c, const int32_t* qi, const int32_t* user,
     if (!c) return PIE_E_INVAL;
     if (total_out) *total_out = 0;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     if (n_req == 0) return PIE_OK;
     if (!qi || !user || !req_off_out || n_req > (size_t)1 << 24) return fail(c, PIE_E_INVAL, "bad request list");
     BatchSlot& b = *c->bres;
@@ -3459,6 +3646,7 @@ int pie_batch_pack_union_device(pie_ctx* c, void* dst_i32, size_t u_pad, size_t 
 {
     if (!c) return PIE_E_INVAL;
     if (!c->bres || !c->bres->have_result) return fail(c, PIE_E_STATE, "no batch result on this context");
+    if (int rc_o = order_after_batch(c, *c->bres)) return rc_o; // the batch may have run on another lane's stream
     if (!dst_i32 || u_pad < (size_t)c->n_users || u_pad > 0x7FFFFFF0u) return fail(c, PIE_E_INVAL, "bad union destination / u_pad < n_users");
     PIE_HIP(c, hipSetDevice(c->device));
     return batch_pack_union(c, *c->bres, dst_i32, u_pad, cap);
@@ -3739,8 +3927,10 @@ int pie_table_info_get(pie_ctx* c, pie_table_info* out)
         per_slot += (uint64_t)kPartMax * kPartCap * sizeof(SelRec);
     }
     out->workspace_bytes = rows ? 2 * per_slot + 3 * (uint64_t)counts_span(c) : 0;
-    if (c->batch_alloc) // batched scans: per slot the union bucket slots (20 B each) + the union result (12 B per slot, 8 per user), 3 spans
-        out->workspace_bytes += 2 * (((uint64_t)users << c->bdshift) * (sizeof(BktRec) + 4 + 12) + ((uint64_t)users + 2) * 8) + 3 * (uint64_t)batch_span_bytes(c);
+    for (bool alloc : c->lane_alloc) // batched scans, per lane: three slots (union bucket slots 20 B each, the union result 12 B per entry, 8 per user), three spans
+        if (alloc)
+            out->workspace_bytes += kBatchSlots * (((uint64_t)users << c->bdshift) * (sizeof(BktRec) + 4) + (uint64_t)batch_ucap(c) * 12 + ((uint64_t)users + 2) * 8) +
+                                    3 * (uint64_t)batch_span_bytes(c);
     for (const BatchSlot& b : c->bslot) // per-query list storage, where somebody asked for lists
         out->workspace_bytes += (uint64_t)b.lists_q * ((uint64_t)batch_users_stride(c) * 12 + (uint64_t)batch_out_stride(c) * 4);
     out->index_build_ms = c->index_build_ms;

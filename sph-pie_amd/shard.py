@@ -76,6 +76,10 @@ class HipShardBackend:
         """-> ([M per query], ready)"""
         return self.ctx.scan_batch_finish(packed=True)
 
+    def batch_depth(self):
+        """batches the context takes in flight: three per lane (pie_set_batch_lanes)"""
+        return 3 * self.ctx.batch_lanes()
+
     union_direct = True   # batch_begin_union: the batch's own kernels write the union message
 
     def batch_begin_union(self, queries, dst, u_pad, cap):
@@ -636,11 +640,17 @@ class BatchedFeeds:
             overflow = overflow or res is None
             last = res if res is not None else last
 
-        begin(0)
+        # batches in flight when the host waits for one: two on one lane's stream; a backend with batch lanes (the HIP library on a
+        # shard-sized table: several batches side by side on the chip) takes what its lanes hold.  A step's message slot belongs to
+        # group i // G, whose buffer set comes round again N_SETS groups later and is collected two groups after its own: D <= 2 G
+        # keeps every begin off a set that is still being gathered or read.
+        D = max(2, min(int(getattr(self.backend, "batch_depth", lambda: 2)()), 2 * G))
+        begun = 0
         group_ready = True
         for i in range(k):
-            if i + 1 < k:
-                begin(i + 1)
+            while begun < k and begun - i < D:
+                begin(begun)
+                begun += 1
             if pending is not None:   # the gather of the group before runs beside this group's scans
                 self._issue(st, pending[0], pending[1])
                 if flying is not None:

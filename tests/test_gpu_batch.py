@@ -573,6 +573,7 @@ def test_three_batches_in_flight(gpu_ctx, oracle, pie):
     cols = oracle.gen(SEED, n, 0, n, U, D, 0)
     gpu_ctx.load_columns(*cols, U)
     gpu_ctx.set_disciplines(ALL, D)
+    gpu_ctx.set_batch_lanes(1)   # one lane: three slots (test_batch_lanes covers more)
     sets = [mixed_queries(oracle, k) for k in (5, 40, 16, 64, 3, 33)]
     wants = [oracle_answers(oracle, cols, U, D, qs) for qs in sets]
     begun = done = 0
@@ -591,3 +592,73 @@ def test_three_batches_in_flight(gpu_ctx, oracle, pie):
         un = gpu_ctx.batch_read_union()
         assert un is not None and un[1].size >= max(ms)
         done += 1
+    gpu_ctx.set_batch_lanes(0)
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_batch_lanes(gpu_ctx, oracle, pie, lanes):
+    """Batch lanes (pie_set_batch_lanes): batches are dealt to independent streams and run side by side; up to three per lane are
+    in flight, one more is refused, finish returns them in the order they were begun, and every result — per-query lists, the
+    union, a user's feed, the union message written by the batch's own tail into mapped host memory — is exact whatever lane
+    the batch ran on.  The mix holds a dense query (rerun on the general path, on the main stream, while other lanes' batches
+    fly) and changes the lane count with batches in flight."""
+    n, U, D = 900001, 5003, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    gpu_ctx.set_batch_lanes(lanes)
+    assert gpu_ctx.batch_lanes() == lanes
+    t0 = oracle.T0_MS
+    sizes = (5, 40, 16, 64, 3, 33, 64, 1, 17, 48, 2, 64, 9, 31)
+    sets = [mixed_queries(oracle, k) for k in sizes]
+    sets[4] = sets[4] + [(t0 - 100 * DAY, t0 - 61 * DAY, 0xAAAAAAAAAAAAAAAA)]   # a dense query: falls back inside finish
+    wants = [oracle_answers(oracle, cols, U, D, qs) for qs in sets]
+    L = U + 2 + 3 * 60000
+    host, dev, host_addr = gpu_ctx.host_alloc(L * 3 * lanes)
+    msgs = host.reshape(3 * lanes, L)
+    try:
+        begun = done = 0
+        cap = 3 * lanes
+        while done < len(sets):
+            while begun < len(sets) and begun - done < cap:
+                if begun % 2:
+                    gpu_ctx.scan_batch_begin_union(sets[begun], dev + 4 * L * (begun % (3 * lanes)), U, 60000)
+                else:
+                    gpu_ctx.scan_batch_begin(sets[begun])
+                begun += 1
+            if begun - done == cap and done < 5:   # every lane holds three: one more is refused
+                with pytest.raises(pie.PieError) as ei:
+                    gpu_ctx.scan_batch_begin(sets[0])
+                assert ei.value.code == -6
+            ms, ready = gpu_ctx.scan_batch_finish(packed=True)
+            want = wants[done]
+            assert ms == [int(w[2].size) for w in want], done
+            nq = len(sets[done])
+            for q in (0, nq - 1, nq // 2):
+                assert_same(gpu_ctx.batch_read_results(q), want[q], "batch %d query %d" % (done, q))
+            uu = (done * 977) % U
+            c, o, ix = want[nq - 1]
+            assert np.array_equal(gpu_ctx.batch_read_user_feed(nq - 1, uu), ix[o[uu]:o[uu + 1]])
+            un = gpu_ctx.batch_read_union()
+            if done % 2 and un is not None:   # the message the tail wrote (or, not ready, the one packed behind it)
+                if not ready:
+                    gpu_ctx.synchronize()
+                m = msgs[done % (3 * lanes)]
+                mu = int(m[U + 1])
+                assert mu == un[1].size
+                assert np.array_equal(m[: U + 1], un[0].astype(np.int32))
+                assert np.array_equal(m[U + 2: U + 2 + mu], un[1])
+                lo = m[U + 2 + 60000: U + 2 + 60000 + mu].view(np.uint32).astype(np.uint64)
+                if nq > 32:
+                    lo |= m[U + 2 + 120000: U + 2 + 120000 + mu].view(np.uint32).astype(np.uint64) << np.uint64(32)
+                assert np.array_equal(lo, un[2])
+            done += 1
+            if done == 5:
+                gpu_ctx.set_batch_lanes(1)       # batches in flight stay on their lanes
+            if done == 8:
+                gpu_ctx.set_batch_lanes(lanes)
+            cap = 3 * gpu_ctx.batch_lanes() if done >= 8 or done < 5 else 3
+    finally:
+        gpu_ctx.synchronize()
+        gpu_ctx.host_free(host_addr)
+        gpu_ctx.set_batch_lanes(0)

@@ -137,7 +137,7 @@ while time.time() < t_end:
                     lim = 2 ** 64 - 1 if D >= 64 else (1 << D) - 1
                     def batch_size():   # 1 .. 64 queries; more than 16 and more than 32 are shapes of their own
                         return int(rng.choice([int(rng.integers(1, 17)), int(rng.integers(17, 33)), int(rng.integers(33, 65))], p=[0.6, 0.2, 0.2]))
-                    batches = [[rand_query() for _ in range(batch_size())] for _ in range(int(rng.integers(1, 6)))]
+                    batches = [[rand_query() for _ in range(batch_size())] for _ in range(int(rng.integers(1, 10)))]
                     if rng.random() < 0.3:   # the requests of a few seconds: clocks a second apart, two cutoffs, three masks
                         base_now = int(T0 - rng.integers(0, 20 * 3600 * 1000))
                         mk3 = [int(rng.integers(0, 2 ** 63)), 2 ** 64 - 1, int(rng.integers(0, 2 ** 63))]
@@ -156,7 +156,8 @@ while time.time() < t_end:
                         else:
                             ctx.scan_batch_begin(batches[k])
 
-                    depth = int(rng.integers(1, 4))   # one, two or three batches in flight
+                    ctx.set_batch_lanes(int(rng.integers(0, 5)))   # 0: by table size; batches of different lanes run side by side
+                    depth = int(rng.integers(1, 3 * ctx.batch_lanes() + 1))   # up to three batches in flight per lane
                     begun_b = 0
                     for k in range(len(batches)):
                         while begun_b < len(batches) and begun_b - k < depth:
