@@ -449,6 +449,29 @@ def main():
     arch_stats = tuple(arch_acc)
     ctx.set_profiling(0)
     st = ctx.stats()
+    # With batch lanes (pie_set_batch_lanes: several batches side by side on the chip) a launch's event time is its duration
+    # while it SHARES the GPU with the other lanes' launches.  The roofline figure wants the kernel alone: the same steps once
+    # more on one lane, profiled, after the timed regions (not part of value).
+    lanes = ctx.batch_lanes()
+    k1_ms_lanes = None
+    if lanes > 1 and Q > 1 and not gather and args.mode == "scan":
+        k1_ms_lanes = statistics.median(kernel_ms_regions) if kernel_ms_regions else None
+        ctx.set_batch_lanes(1)
+        ctx.scan_batch_pipelined(max(args.warmup, 1), batch_queries)
+        ctx.stats_reset()
+        ctx.set_profiling(profile_every)
+        kernel_ms_regions, scan_ms_regions, n_prof = [], [], 0
+        for _ in range(max(args.repeat, 1)):
+            ctx.scan_batch_pipelined(args.steps, batch_queries)
+            s1l = ctx.stats()
+            if s1l["n_profiled"]:
+                kernel_ms_regions.append(s1l["k1_ms_sum"] / s1l["n_profiled"])
+                scan_ms_regions.append(s1l["scan_ms_sum"] / s1l["n_profiled"])
+                n_prof += s1l["n_profiled"]
+            ctx.stats_reset()
+        ctx.set_profiling(0)
+        st = ctx.stats()
+        ctx.set_batch_lanes(int(os.environ.get("PIE_BATCH_LANES", "0")))
     batch_ms = None
     def union_masks64(res, r, mu):
         """the 64-bit query mask of every union row of rank r in a gathered union result"""
@@ -605,6 +628,9 @@ def main():
                                      "sessions really scanned at 24 B each per second is roofline.full_read.sessions_per_sec",
             "physical_bytes_per_step": basis,
             "queries_per_launch": Q if batch_ms is not None else 1,
+            "batch_lanes": lanes if batch_ms is not None else None,
+            "batch_lanes_note": "batches in flight are dealt to this many independent streams of the context (pie_set_batch_lanes; chosen by "
+                                "table size) and run side by side on the chip; three batches in flight per lane",
             "union_rows_rank0": union_rows,
             "table_passes_per_sec": 1.0 / (ms_per_step * 1e-3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -647,6 +673,10 @@ def main():
                                   "kernel; NOT a bandwidth — the keyed pass streams a 1- or 2-byte liveness key per row and gathers one 16-byte "
                                   "payload record per candidate (DESIGN.md sections 3, 4, 6); see roofline_full_read for the every-byte form",
                 "kernel_ms": k1_ms, "kernel_ms_regions": spread(kernel_ms_regions) if kernel_ms_regions else None,
+                "kernel_ms_sharing_the_chip": k1_ms_lanes,
+                "kernel_ms_note": None if k1_ms_lanes is None else "kernel_ms: the launch alone on the chip (the same steps on ONE lane, after the timed "
+                                  "regions); kernel_ms_sharing_the_chip: the same launch's event time inside the timed regions, where %d lanes' "
+                                  "launches overlap (ms_per_step < kernel_ms is that overlap)" % lanes,
                 "launches_timed": n_prof,
                 "note": "the timed launch is the table pass of one scan plus, in its first blocks, the offsets + order kernel of the scan "
                         "before it" if rides else "the timed launch is the table pass",

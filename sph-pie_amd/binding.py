@@ -184,6 +184,7 @@ class PieScan:
         self.n_users = 0
         self._begun = []   # scans begun and not finished, oldest first: True = begun with scan_begin_packed
         self._m_buf, self._ready_buf = (C.c_size_t * PIE_BATCH_MAX)(), C.c_int(0)
+        self._ready_ref = C.byref(self._ready_buf)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -463,16 +464,18 @@ class PieScan:
         self._check(self._lib.pie_batch_union_device_ptrs(self._ctx, C.byref(a), C.byref(b), C.byref(lo), C.byref(hi), C.byref(mu)))
         return a.value, b.value, lo.value, hi.value, int(mu.value)
 
-    def scan_batch_finish(self, packed=False):
-        """-> list of M per query of the oldest batch in flight (packed: (list, ready))."""
+    def scan_batch_finish(self, packed=False, want_m=True):
+        """-> list of M per query of the oldest batch in flight (packed: (list, ready)).  want_m=False: the list is not built
+        (a step loop that only moves messages: 64 Python ints per step are a microsecond it does not have)."""
         nq = self._batches[0] if getattr(self, "_batches", None) else PIE_BATCH_MAX
         m = self._m_buf
         ready = self._ready_buf
-        rc = self._lib.pie_scan_batch_finish_packed(self._ctx, m, C.byref(ready))
+        rc = self._lib.pie_scan_batch_finish_packed(self._ctx, m, self._ready_ref)
         if getattr(self, "_batches", None) and rc != -6:
             self._batches.pop(0)
-        self._check(rc)
-        ms = m[:nq]
+        if rc:
+            self._check(rc)
+        ms = m[:nq] if want_m else None
         return (ms, bool(ready.value)) if packed else ms
 
     def batch_pack_union_device(self, dst_ptr, u_pad, cap):
@@ -693,6 +696,7 @@ class PieComm:
         p = PieScan.__new__(PieScan)
         p._lib, p._ctx, p._begun = self._lib, _P(h), []
         p._m_buf, p._ready_buf = (C.c_size_t * PIE_BATCH_MAX)(), C.c_int(0)
+        p._ready_ref = C.byref(p._ready_buf)
         st = PieStats()
         st.struct_size = C.sizeof(PieStats)
         p._check(self._lib.pie_stats_get(p._ctx, C.byref(st)))

@@ -256,6 +256,12 @@ struct pie_ctx {
     char* h_stage = nullptr;       // pinned host + device staging of the small mutations (append, touch): grown, never per call
     char* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // Appends and touches that need nothing back from the device (no ordered run to keep in step: its spare-slot bookkeeping is
+    // read by the host) do not wait for it: the rows are validated on the host, staged in one of two pinned areas and queued; the
+    // next scan runs behind them in stream order.  A server's turn — logins, touches, one feed scan — is then ONE wait, not three.
+    struct AsyncStage { char* h = nullptr; char* d = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; } astage[2];
+    int astage_next = 0;
+    bool async_mutations = true;   // PIE_ASYNC_MUTATIONS=0: every append / touch waits for its kernel (A/B runs)
     int* d_shard_rows = nullptr;   // pie_shard_table: local row -> global row
     int* d_shard_users = nullptr;  // ... local user -> global user
     long long shard_rows_n = 0;
@@ -754,6 +760,30 @@ int ensure_stage(pie_ctx* c, size_t bytes)
     PIE_HIP(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
     PIE_HIP(c, hipMalloc(&c->d_stage, want));
     c->stage_bytes = want;
+    return PIE_OK;
+}
+
+// one of the two staging areas of the queued mutations, free to be written: *out
+int async_stage(pie_ctx* c, size_t bytes, pie_ctx::AsyncStage** out)
+{
+    pie_ctx::AsyncStage& a = c->astage[c->astage_next];
+    c->astage_next ^= 1;
+    if (a.pending) { // the copy out of it was queued two mutations ago
+        PIE_HIP(c, hipEventSynchronize(a.ev));
+        a.pending = false;
+    }
+    if (!a.ev) PIE_HIP(c, hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+    if (bytes > a.bytes) {
+        size_t want = a.bytes ? a.bytes : (size_t)64 << 10;
+        while (want < bytes) want *= 2;
+        if (a.h) (void)hipHostFree(a.h);
+        if (a.d) { PIE_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(a.d); } // a kernel queued earlier may still read it
+        a.h = nullptr; a.d = nullptr; a.bytes = 0;
+        PIE_HIP(c, hipHostMalloc(&a.h, want, hipHostMallocDefault));
+        PIE_HIP(c, hipMalloc(&a.d, want));
+        a.bytes = want;
+    }
+    *out = &a;
     return PIE_OK;
 }
 
@@ -2772,6 +2802,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
+    if (const char* v = getenv("PIE_ASYNC_MUTATIONS")) c->async_mutations = atoi(v) != 0;
     if (const char* v = getenv("PIE_BATCH_LANES")) { const int l = atoi(v); if (l >= 0 && l <= kLaneMax) c->lanes_want = l; }
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
     if (const char* v = getenv("PIE_RUN_SHIFT")) { const int r = atoi(v); if (r >= 0 && r <= 3) { c->run_shift = r; c->run_shift_pinned = true; } }
@@ -2800,6 +2831,11 @@ int pie_ctx_destroy(pie_ctx* c)
     dfree(c->d_shard_users);
     dfree(c->d_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& a : c->astage) {
+        if (a.h) (void)hipHostFree(a.h);
+        if (a.d) (void)hipFree(a.d);
+        if (a.ev) (void)hipEventDestroy(a.ev);
+    }
     for (auto& e : c->ring) {
         (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2);
     }
@@ -2887,6 +2923,39 @@ int pie_append_rows(pie_ctx* c, const int64_t* start, const int64_t* end, const 
         // burst costs tens of microseconds, not the half-dozen blocking calls of the general path below.
         if (c->n_flight || c->b_flight) return fail(c, PIE_E_STATE, "table change while a scan is in flight");
         if (old_n + (long long)k >= (1LL << 31) - 1) return fail(c, PIE_E_INVAL, "row count outside [0, 2^31 - 1)");
+        if (c->async_mutations && !c->ord.valid) {
+            // nothing to read back: user ids are checked here, the rows are staged and queued, the call returns (see AsyncStage)
+            unsigned bad = 0;
+            for (size_t i = 0; i < k; ++i) bad += (unsigned)user[i] >= (unsigned)n_users ? 1u : 0u;
+            if (bad) return fail(c, PIE_E_INVAL, "%u rows carry a user id outside [0, %d)", bad, n_users);
+            pie_ctx::AsyncStage* a = nullptr;
+            int rca = async_stage(c, k * 24 + 64, &a);
+            if (rca) return rca;
+            memcpy(a->h, start, k * 8);
+            memcpy(a->h + k * 8, end, k * 8);
+            memcpy(a->h + k * 16, user, k * 4);
+            memcpy(a->h + k * 20, disc, k * 4);
+            hipStream_t s = c->stream;
+            PIE_HIP(c, hipMemcpyAsync(a->d, a->h, k * 24, hipMemcpyHostToDevice, s));
+            const unsigned grid = (unsigned)((k + 255) / 256) < (unsigned)c->n_cus * 8 ? (unsigned)((k + 255) / 256) : (unsigned)c->n_cus * 8;
+            hipLaunchKernelGGL(k_append_rows, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(a->d),
+                               reinterpret_cast<const long long*>(a->d + k * 8), reinterpret_cast<const int*>(a->d + k * 16),
+                               reinterpret_cast<const int*>(a->d + k * 20), (long long)k, old_n, n_users, c->d_start, c->d_end, c->d_user,
+                               c->d_disc, c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift, c->d_pay,
+                               &c->d_summary->bad_rows);
+            PIE_HIP(c, hipGetLastError());
+            PIE_HIP(c, hipEventRecord(a->ev, s));
+            a->pending = true;
+            c->n = old_n + (long long)k;
+            ord_invalidate(c);
+            if (n_users > c->n_users) set_user_count(c, n_users);
+            c->key_dirty = true;
+            c->res = nullptr;
+            for (Slot& sl : c->slot) sl.have_result = false;
+            c->bres = nullptr;
+            plan_k1(c);
+            return ensure_sel(c);
+        }
         int rc0 = ensure_stage(c, k * 24 + 64);
         if (rc0) return rc0;
         char* h = c->h_stage;
@@ -3113,6 +3182,22 @@ int pie_set_end(pie_ctx* c, const int32_t* rows, const int64_t* new_end, size_t 
     for (size_t i = 0; i < k; ++i)
         if (rows[i] < 0 || rows[i] >= c->n) return fail(c, PIE_E_INVAL, "row %d outside the table", rows[i]);
     PIE_HIP(c, hipSetDevice(c->device));
+    if (c->async_mutations && !c->ord.valid) { // queued, not waited for (see AsyncStage); the rows were checked above
+        pie_ctx::AsyncStage* a = nullptr;
+        int rca = async_stage(c, k * 12 + 64, &a);
+        if (rca) return rca;
+        memcpy(a->h, new_end, k * 8);
+        memcpy(a->h + k * 8, rows, k * 4);
+        PIE_HIP(c, hipMemcpyAsync(a->d, a->h, k * 12, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_set_end, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, c->d_end,
+                           reinterpret_cast<const int*>(a->d + k * 8), reinterpret_cast<const long long*>(a->d), (long long)k, c->n,
+                           c->d_key, c->key_base, c->key_shift, c->d_fkey, c->fkey_base, c->fkey_shift, ord_mirror_of(c));
+        PIE_HIP(c, hipGetLastError());
+        PIE_HIP(c, hipEventRecord(a->ev, c->stream));
+        a->pending = true;
+        c->key_dirty = true;
+        return PIE_OK;
+    }
     // staged like the append path: one upload of [new_end k | rows k], one kernel (end + both keys), one wait
     int rc = ensure_stage(c, k * 12 + 64);
     if (rc) return rc;

@@ -72,9 +72,9 @@ class HipShardBackend:
         else:
             self.ctx.scan_batch_begin_packed(queries, dst.data_ptr(), stride, u_pad, cap)
 
-    def batch_finish(self):
-        """-> ([M per query], ready)"""
-        return self.ctx.scan_batch_finish(packed=True)
+    def batch_finish(self, want_m=True):
+        """-> ([M per query] (None when not wanted), ready)"""
+        return self.ctx.scan_batch_finish(packed=True, want_m=want_m)
 
     def batch_depth(self):
         """batches the context takes in flight: three per lane (pie_set_batch_lanes)"""
@@ -83,8 +83,9 @@ class HipShardBackend:
     union_direct = True   # batch_begin_union: the batch's own kernels write the union message
 
     def batch_begin_union(self, queries, dst, u_pad, cap):
-        """A batch whose tail kernel writes the ONE union message of the step into dst as it goes."""
-        self.ctx.scan_batch_begin_union(queries, dst.data_ptr(), u_pad, cap)
+        """A batch whose tail kernel writes the ONE union message of the step into dst (an int32 device tensor, or its address)
+        as it goes."""
+        self.ctx.scan_batch_begin_union(queries, dst if isinstance(dst, int) else dst.data_ptr(), u_pad, cap)
 
     def batch_pack_union(self, dst, u_pad, cap):
         """Enqueue (on result_stream) the UNION message of the last finished batch into dst: u_pad + 2 + 2 * cap int32 words
@@ -625,9 +626,16 @@ class BatchedFeeds:
             return st["msg"][(i // G) % N_SETS][(i % G) * Qm * L: (i % G + 1) * Qm * L]
 
         direct_union = self.union and bool(getattr(self.backend, "union_direct", False))
+        # addresses of the message slots, once (a tensor slice per step is a microsecond of Python the step does not have)
+        slot_addr = None
+        if direct_union and self.cuda:
+            slot_addr = [st["msg"][p].data_ptr() + 4 * g * Qm * L for p in range(N_SETS) for g in range(G)]
+        slim = bool(getattr(self.backend, "union_direct", False))   # the HIP backend: finish need not build the list of M
 
         def begin(i):
-            if direct_union:   # the batch's tail kernel writes the step's ONE message itself
+            if slot_addr is not None:
+                self.backend.batch_begin_union(queries, slot_addr[i % (N_SETS * G)], self.u_pad, cap)
+            elif direct_union:   # the batch's tail kernel writes the step's ONE message itself
                 self.backend.batch_begin_union(queries, slot_of(i), self.u_pad, cap)
             elif self.union:
                 self.backend.batch_begin(queries)
@@ -656,7 +664,7 @@ class BatchedFeeds:
                 if flying is not None:
                     collect(flying)
                 flying, pending = pending, None
-            _, ready = self.backend.batch_finish()
+            _, ready = self.backend.batch_finish(want_m=False) if slim else self.backend.batch_finish()
             p = (i // G) % N_SETS
             if self.union and not direct_union:   # packed from the finished batch, on the result stream
                 self.backend.batch_pack_union(slot_of(i), self.u_pad, cap)
