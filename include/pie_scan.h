@@ -223,6 +223,9 @@ int pie_batch_read_union(pie_ctx *ctx, int64_t *uoff_out, int32_t *rows_out, uin
  * server/index.js:293-302). */
 int pie_set_batch_lanes(pie_ctx *ctx, int n_lanes);
 int pie_batch_lanes(pie_ctx *ctx); /* lanes in use now */
+/* Batches pie_scan_batch_begin would take right now (0: finish one first): three per lane less those in flight; a table whose
+ * batches run on the ordered run uses lane 0 only, whatever the lane count.  A pipelined caller asks this instead of counting. */
+int pie_batch_room(pie_ctx *ctx);
 /* A batch that also writes the multi-GPU exchange message as it goes — ONE union message for the whole batch:
  *   msg (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | mask_lo[0..cap) | mask_hi[0..cap) (only when n_q > 32) ]
  * u_pad + 2 + 2 * cap words (3 * cap for n_q > 32); uoff[u] = Mu for u >= users; rows beyond cap are dropped (Mu says how many

@@ -86,6 +86,7 @@ _SIGS = [
     ("pie_set_ordered_run", C.c_int, [_P, C.c_int]),
     ("pie_set_batch_lanes", C.c_int, [_P, C.c_int]),
     ("pie_batch_lanes", C.c_int, [_P]),
+    ("pie_batch_room", C.c_int, [_P]),
     ("pie_batch_pack_union_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
@@ -534,13 +535,18 @@ class PieScan:
     def batch_lanes(self):
         return int(self._lib.pie_batch_lanes(self._ctx))
 
+    def batch_room(self):
+        """batches scan_batch_begin would take right now (pie_batch_room)"""
+        return int(self._lib.pie_batch_room(self._ctx))
+
     def scan_batch_pipelined(self, k, queries, depth=3):
         """k batches of the same queries with up to `depth` (<= 3) in flight PER LANE: the next launch is queued before the host
         waits for a summary.  -> list of M of the last batch."""
         ms, begun, done = [], 0, 0
         depth = depth * self.batch_lanes()
+        room = self._lib.pie_batch_room
         while done < k:
-            while begun < k and begun - done < depth:
+            while begun < k and begun - done < depth and room(self._ctx) > 0:
                 self.scan_batch_begin(queries)
                 begun += 1
             ms = self.scan_batch_finish()

@@ -523,26 +523,18 @@ int pie_comm_step_reserve(pie_comm* c, int32_t n_q, int32_t u_pad_in, size_t uni
     return ensure_step_buffers(c, n_q, u_pad, (long long)(union_cap > 0 ? union_cap : 1024));
 }
 
-constexpr int kMaxLanesOfAShard = 4;
-
 int pie_comm_step_begin(pie_comm* c, const pie_query* queries, int32_t n_q)
 {
     if (!c) return PIE_E_INVAL;
     if (!queries || n_q < 1 || n_q > PIE_BATCH_MAX) return cfail(c, PIE_E_INVAL, "a batch holds 1..%d queries (got %d)", PIE_BATCH_MAX, n_q);
     if (c->UL <= 0) return cfail(c, PIE_E_STATE, "pie_comm_step_reserve first");
     if ((n_q > 32 ? 3 : 2) > c->u_words) return cfail(c, PIE_E_STATE, "reserved for batches of at most 32 queries: pie_comm_step_reserve again");
-    {
-        // steps begun and unfinished: what the shards' batch lanes hold (three batches per lane, pie_set_batch_lanes), at least two
-        int depth = 3 * kMaxLanesOfAShard;
-        for (int k = 0; k < c->n_local; ++k) {
-            const int d = 3 * pie_batch_lanes(c->ctx[k]);
-            if (d < depth) depth = d;
-        }
-        if (depth > pie_comm::kSets - 4) depth = pie_comm::kSets - 4;
-        if (depth < 2) depth = 2;
-        if (c->begun - c->finished >= depth)
-            return cfail(c, PIE_E_STATE, "%d steps are already begun (three per batch lane of the shards): pie_comm_step_finish first", depth);
-    }
+    // steps begun and unfinished: what the shards' batch lanes hold (three per lane, pie_set_batch_lanes; lane 0 only on the ordered run)
+    if (c->begun - c->finished >= pie_comm::kSets - 4)
+        return cfail(c, PIE_E_STATE, "%d steps are already begun: pie_comm_step_finish first", pie_comm::kSets - 4);
+    for (int k = 0; k < c->n_local; ++k)
+        if (pie_batch_room(c->ctx[k]) <= 0)
+            return cfail(c, PIE_E_STATE, "rank %d: the steps begun fill its batch slots (three per batch lane): pie_comm_step_finish first", c->rank_of[k]);
     if (c->begun - c->collected >= pie_comm::kSets) return cfail(c, PIE_E_STATE, "%d steps are uncollected: pie_comm_step_collect first", pie_comm::kSets);
     const int s = (int)(c->begun % pie_comm::kSets);
     int begun = 0, rc = PIE_OK;

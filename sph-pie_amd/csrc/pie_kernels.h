@@ -3612,8 +3612,11 @@ __global__ __launch_bounds__(256) void k_shard_row_write(const long long* __rest
 
 // exclusive prefix over blk[0..nb) by ONE block of 1024 threads in a single sweep: thread t owns the contiguous
 // chunk [t*per, (t+1)*per), so 16 K wave counts cost one block-wide scan instead of 64 of them
+// host != nullptr: the total also goes to mapped host memory (seq last) — the caller learns the queue's length when THIS kernel
+// ends, not after a copy behind the gather that follows it
 __global__ __launch_bounds__(1024) void k_block_prefix_wide(const int* __restrict__ blk, int nb, long long* __restrict__ off,
-                                                            unsigned long long* __restrict__ total_out)
+                                                            unsigned long long* __restrict__ total_out, HostSummary* __restrict__ host,
+                                                            unsigned long long seq)
 {
     __shared__ long long wsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3636,6 +3639,11 @@ __global__ __launch_bounds__(1024) void k_block_prefix_wide(const int* __restric
     if (threadIdx.x == 1023) {
         off[nb] = run;
         if (total_out) *total_out = (unsigned long long)run;
+        if (host) {
+            host->s.m = (unsigned long long)run;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -3700,18 +3708,18 @@ __global__ __launch_bounds__(kK1Threads) void k_expired_stage(const long long* _
 // kn = key(now), a row with kp < key < kn is a hit without looking at `end` (key(end) > key(prev) => end > prev,
 // key(end) < key(now) => end < now), a row with key == kp or key == kn needs the full compare, every other row is a
 // miss.  2 B/row instead of 8 B/row; output identical (each lane holds eight consecutive rows, so lane order is row order).
+// (the stage of block `bid`; returns the wave's number of hits, staged in order at stage[w0 ..))
 template <int UNROLL>
-__global__ __launch_bounds__(kK1Threads) void k_expired_stage_keyed(const lkey_t* __restrict__ key, const long long* __restrict__ end,
-                                                                    long long n, long long rows_per_block, long long prev_now,
-                                                                    long long now, unsigned kp, unsigned kn,
-                                                                    int* __restrict__ stage, int* __restrict__ wave_count)
+__device__ __forceinline__ int expired_stage_keyed_body(const lkey_t* __restrict__ key, const long long* __restrict__ end, long long n,
+                                                        long long rows_per_block, long long prev_now, long long now, unsigned kp, unsigned kn,
+                                                        int* __restrict__ stage, int bid)
 {
     constexpr int kTile = kKeyRowsPerLoad * UNROLL;
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const long long rows_per_wave = rows_per_block / kK1Waves; // a multiple of kTile (block range is 4096-aligned, UNROLL <= 2)
-    const long long w0 = (long long)blockIdx.x * rows_per_block + (long long)wave * rows_per_wave;
+    const long long w0 = (long long)bid * rows_per_block + (long long)wave * rows_per_wave;
     long long w1 = w0 + rows_per_wave;
     if (w1 > n) w1 = n;
     int fill = 0; // wave-uniform
@@ -3770,7 +3778,17 @@ __global__ __launch_bounds__(kK1Threads) void k_expired_stage_keyed(const lkey_t
             }
         }
     }
-    if (lane == 0) wave_count[blockIdx.x * kK1Waves + wave] = w0 < n ? fill : 0;
+    return w0 < n ? fill : 0;
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(kK1Threads) void k_expired_stage_keyed(const lkey_t* __restrict__ key, const long long* __restrict__ end,
+                                                                    long long n, long long rows_per_block, long long prev_now,
+                                                                    long long now, unsigned kp, unsigned kn,
+                                                                    int* __restrict__ stage, int* __restrict__ wave_count)
+{
+    const int fill = expired_stage_keyed_body<UNROLL>(key, end, n, rows_per_block, prev_now, now, kp, kn, stage, (int)blockIdx.x);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_count[blockIdx.x * kK1Waves + (threadIdx.x >> 6)] = fill;
 }
 
 __global__ __launch_bounds__(256) void k_expired_gather(const int* __restrict__ stage, const int* __restrict__ wave_count,

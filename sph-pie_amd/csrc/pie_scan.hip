@@ -256,6 +256,7 @@ struct pie_ctx {
     char* h_stage = nullptr;       // pinned host + device staging of the small mutations (append, touch): grown, never per call
     char* d_stage = nullptr;
     size_t stage_bytes = 0;
+    bool expired_copy_total = false; // PIE_EXPIRED_COPY_TOTAL=1: the queue's length by a copy behind the gather, as before round 3 (A/B runs)
     // Appends and touches that need nothing back from the device (no ordered run to keep in step: its spare-slot bookkeeping is
     // read by the host) do not wait for it: the rows are validated on the host, staged in one of two pinned areas and queued; the
     // next scan runs behind them in stream order.  A server's turn — logins, touches, one feed scan — is then ONE wait, not three.
@@ -2149,6 +2150,7 @@ void batch_left(pie_ctx* c, BatchSlot& b)
 int order_after_batch(pie_ctx* c, BatchSlot& b)
 {
     if (b.main_ordered || b.stream == c->stream || !b.stream) { b.main_ordered = true; return PIE_OK; }
+    if (!c->lane_event[b.lane][1]) PIE_HIP(c, hipEventCreateWithFlags(&c->lane_event[b.lane][1], hipEventDisableTiming));
     PIE_HIP(c, hipEventRecord(c->lane_event[b.lane][1], b.stream));
     PIE_HIP(c, hipStreamWaitEvent(c->stream, c->lane_event[b.lane][1], 0));
     b.main_ordered = true;
@@ -2252,11 +2254,11 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         // one would still make nearly every row a candidate
         if (n_batched == 0) unsupported = true;
     }
-    // the lane: the general pass deals its batches round robin; a batch on the ordered run (its staging is the scan slots')
-    // and one that only falls back (scans on the main stream) stay on lane 0
+    // the lane: batches are dealt round robin; a batch on the ordered run (its staging is the scan slots') stays on lane 0 (one
+    // that only falls back queues nothing here: any lane's slot will do)
     int lane = 0;
     {
-        const int lanes = (ord_batch || unsupported) ? 1 : c->n_lanes;
+        const int lanes = ord_batch ? 1 : c->n_lanes;
         int tried = 0;
         lane = lanes > 1 ? c->lane_rr % lanes : 0;
         while (tried < lanes && c->lane_flight[lane] >= kBatchSlots) { lane = (lane + 1) % lanes; ++tried; }
@@ -2290,6 +2292,7 @@ int batch_begin(pie_ctx* c, const pie_query* qs, int n_q, int msg_kind, int* msg
         for (int q = 0; q < n_q; ++q) b.fallback[q] = true;
         b.in_flight = true;
         b.k2_pending = false;
+        b.main_ordered = true; // nothing of it runs on the lane's stream
         batch_begun(c, lane);
         return PIE_OK;
     }
@@ -2802,6 +2805,7 @@ int pie_ctx_create(int device_id, pie_ctx** ctx_out)
     if (const char* v = getenv("PIE_FAST_PATH")) c->fast_env = atoi(v) != 0;
     if (const char* v = getenv("PIE_FUSED_ORDER")) c->no_fused_order = atoi(v) == 0;
     if (const char* v = getenv("PIE_K2_RIDE")) c->no_ride = atoi(v) == 0;
+    if (const char* v = getenv("PIE_EXPIRED_COPY_TOTAL")) c->expired_copy_total = atoi(v) != 0;
     if (const char* v = getenv("PIE_ASYNC_MUTATIONS")) c->async_mutations = atoi(v) != 0;
     if (const char* v = getenv("PIE_BATCH_LANES")) { const int l = atoi(v); if (l >= 0 && l <= kLaneMax) c->lanes_want = l; }
     if (const char* v = getenv("PIE_ORDER_BLOCK")) { const int b = atoi(v); if (b == 256 || b == 512 || b == 1024) c->order_block = b; }
@@ -2872,6 +2876,17 @@ int pie_set_batch_lanes(pie_ctx* c, int n_lanes)
 }
 
 int pie_batch_lanes(pie_ctx* c) { return c ? c->n_lanes : 0; }
+
+// how many more batches pie_scan_batch_begin would take right now
+int pie_batch_room(pie_ctx* c)
+{
+    if (!c || c->n_flight) return 0;
+    const bool ord_batch = batch_supported(c) && ordered_batch_wanted(c) && !c->ord_lists_only;
+    const int lanes = ord_batch ? 1 : c->n_lanes;
+    int room = 0;
+    for (int l = 0; l < lanes; ++l) room += kBatchSlots - c->lane_flight[l];
+    return room;
+}
 
 int pie_ctx_set_stream(pie_ctx* c, void* hip_stream)
 {
@@ -3806,7 +3821,10 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
         hipLaunchKernelGGL(k_expired_stage<8>, dim3(blocks), dim3(kK1Threads), 0, s, c->d_end, c->n, rpb, (long long)prev_now,
                            (long long)now, st.out_idx, q.blk_count);
     if (prof) PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e1, s));
-    hipLaunchKernelGGL(k_block_prefix_wide, dim3(1), dim3(1024), 0, s, q.blk_count, n_waves, c->d_blk_off, &c->d_summary->m);
+    // the prefix kernel hands the queue's length to the host itself (mapped memory, seq last): no copy, no stream drain
+    const unsigned long long seq = ++c->seq_counter;
+    hipLaunchKernelGGL(k_block_prefix_wide, dim3(1), dim3(1024), 0, s, q.blk_count, n_waves, c->d_blk_off, &c->d_summary->m,
+                       c->expired_copy_total ? (HostSummary*)nullptr : q.h_sum_dev, seq);
     hipLaunchKernelGGL(k_expired_gather, dim3(blocks < c->n_cus * 8 ? blocks : c->n_cus * 8), dim3(256), 0, s, st.out_idx,
                        q.blk_count, c->d_blk_off, n_waves, rpb / kK1Waves, q.out_idx, c->cap_rows);
     PIE_HIP(c, hipGetLastError());
@@ -3814,9 +3832,33 @@ int pie_expired_queue(pie_ctx* c, int64_t prev_now, int64_t now, int32_t* queue_
         PIE_HIP(c, hipEventRecord(c->ring[c->ring_used].e2, s));
         c->ring_used++;
     }
-    PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
-    PIE_HIP(c, hipStreamSynchronize(s));
-    const size_t k = (size_t)c->h_summary->m;
+    size_t k = 0;
+    if (c->expired_copy_total) {
+        PIE_HIP(c, hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(Summary), hipMemcpyDeviceToHost, s));
+        PIE_HIP(c, hipStreamSynchronize(s));
+        k = (size_t)c->h_summary->m;
+    } else {
+        // bounded wait like a scan's; the gather behind the prefix kernel may still run when the length is known (everything that
+        // reads the queue afterwards is queued on this stream, behind it)
+        volatile unsigned long long* hs = &q.h_sum->seq;
+        unsigned long long spins = 0;
+        timespec t0{};
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        while (*hs != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFFF) == 0) {
+                const hipError_t e = hipStreamQuery(s);
+                timespec t1{};
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                const double waited_ms = (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6;
+                if (e != hipSuccess && e != hipErrorNotReady) return fail(c, PIE_E_HIP, "expired queue failed: %s", hipGetErrorString(e));
+                if (waited_ms > c->wait_deadline_ms || (e == hipSuccess && *hs != seq && waited_ms > 1000.0))
+                    return fail(c, PIE_E_HIP, "expired-queue length not published within %.0f ms (PIE_WAIT_DEADLINE_MS): kernel hung?", waited_ms);
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        k = (size_t)q.h_sum->s.m;
+    }
     if (q_out) *q_out = k;
     if (queue_out && k > cap) return fail(c, PIE_E_CAPACITY, "queue cap %zu < %zu", cap, k);
     if (queue_out && k) {

@@ -80,6 +80,9 @@ class HipShardBackend:
         """batches the context takes in flight: three per lane (pie_set_batch_lanes)"""
         return 3 * self.ctx.batch_lanes()
 
+    def batch_room(self):
+        return self.ctx.batch_room()
+
     union_direct = True   # batch_begin_union: the batch's own kernels write the union message
 
     def batch_begin_union(self, queries, dst, u_pad, cap):
@@ -654,9 +657,10 @@ class BatchedFeeds:
         # keeps every begin off a set that is still being gathered or read.
         D = max(2, min(int(getattr(self.backend, "batch_depth", lambda: 2)()), 2 * G))
         begun = 0
+        room = getattr(self.backend, "batch_room", lambda: 1)   # (a table whose batches run on the ordered run takes three, whatever the lanes)
         group_ready = True
         for i in range(k):
-            while begun < k and begun - i < D:
+            while begun < k and begun - i < D and (begun == i or room() > 0):
                 begin(begun)
                 begun += 1
             if pending is not None:   # the gather of the group before runs beside this group's scans

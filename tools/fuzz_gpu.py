@@ -160,7 +160,7 @@ while time.time() < t_end:
                     depth = int(rng.integers(1, 3 * ctx.batch_lanes() + 1))   # up to three batches in flight per lane
                     begun_b = 0
                     for k in range(len(batches)):
-                        while begun_b < len(batches) and begun_b - k < depth:
+                        while begun_b < len(batches) and begun_b - k < depth and ctx.batch_room() > 0:
                             begin(begun_b)
                             begun_b += 1
                         ms, ready = ctx.scan_batch_finish(packed=True)
