@@ -802,6 +802,37 @@ def main():
             "feeds_per_sec": U / (fr_ms * 1e-3),
             "traffic": fr_doc["hbm_bytes_per_launch"] if fr_doc else None, "traffic_source": fr_src,
         }
+        # ---- what a kernel that ONLY reads reaches on this very GPU, now (libpie_ubench.so: 16-byte nontemporal loads over a
+        # buffer of the table's size, eight grid / unroll / split forms, median of 7 launches each): boxes of one pool differ by
+        # 5 - 8 % in HBM throughput, so the every-byte scan is also quoted against this box's own read ceiling
+        ceiling = None
+        try:
+            import ctypes
+            ub = ctypes.CDLL(pie.build_ubench())
+            ub.pie_ubench_read_bw.restype = ctypes.c_int
+            ub.pie_ubench_read_bw.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+            ms8 = (ctypes.c_double * 8)()
+            ctx.synchronize()
+            rc_ub = ub.pie_ubench_read_bw(local_rank, 24 * N, 7, ms8)
+            if rc_ub == 0:
+                forms = ["grid-stride, 16 blocks/CU, unroll 4", "grid-stride, 16 blocks/CU, unroll 8", "grid-stride, 48 blocks/CU, unroll 4",
+                         "grid-stride, 48 blocks/CU, unroll 8", "contiguous ranges, 16 blocks/CU, unroll 4", "contiguous ranges, 16 blocks/CU, unroll 8",
+                         "contiguous ranges, 48 blocks/CU, unroll 4", "contiguous ranges, 48 blocks/CU, unroll 8"]
+                best = min(range(8), key=lambda i: ms8[i])
+                ceiling = {"bytes": 24 * N, "best_ms": ms8[best], "best_form": forms[best], "best_gbs": 24.0 * N / (ms8[best] * 1e-3) / 1e9,
+                           "all_ms": {forms[i]: ms8[i] for i in range(8)},
+                           "note": "a kernel that only reads (folds every 16-byte load into a word nobody stores): the streaming-read "
+                                   "ceiling of THIS GPU in THIS run; the scan's table pass reads the same bytes and also evaluates, "
+                                   "counts and scatters"}
+            else:
+                log("read-ceiling probe failed: rc %d" % rc_ub)
+        except Exception as ex:   # a measurement aid: its absence must not cost the bench line
+            log("read-ceiling probe unavailable: %r" % (ex,))
+        if ceiling is not None:
+            fr = line["roofline_full_read"]
+            fr["read_ceiling"] = ceiling
+            fr["kernel_frac_of_read_ceiling"] = ceiling["best_ms"] / fr["kernel_ms"]
+            fr["t_scan_frac_of_read_ceiling"] = ceiling["best_ms"] / fr["t_scan_ms"]
         # ---- the headline loop with counts + offsets delivered to pinned host memory by every scan
         sets = []
         for _ in range(3):
@@ -851,6 +882,10 @@ def main():
             "kernel": fr["kernel"], "alg_bytes_per_scan": fr["alg_bytes_per_scan"], "kernel_ms": fr["kernel_ms"], "t_scan_ms": fr["t_scan_ms"],
             "frac_kernel": fr["kernel_frac"], "frac_t_scan": fr["frac"], "ms_per_step": fr["ms_per_step"], "frac_step": fr["step_frac"],
             "sessions_per_sec": N / (fr["t_scan_ms"] * 1e-3), "feeds_per_sec": U / (fr["t_scan_ms"] * 1e-3), "traffic": fr["traffic"],
+            "read_ceiling_gbs": fr["read_ceiling"]["best_gbs"] if "read_ceiling" in fr else None,
+            "frac_kernel_of_read_ceiling": fr.get("kernel_frac_of_read_ceiling"), "frac_t_scan_of_read_ceiling": fr.get("t_scan_frac_of_read_ceiling"),
+            "read_ceiling_note": "read_ceiling_gbs: what a kernel that only reads reaches on this GPU in this run (libpie_ubench.so, best of "
+                                 "eight forms); frac_*_of_read_ceiling = that kernel's time / the scan's",
             "note": "the same query on the same table with the table pass pinned to the form that reads every byte of the four columns "
                     "(24 B/row = SURVEY 8d's algorithmic bytes; PMC traffic = algorithmic): frac_* = 24 B x N / time / 8 TB/s; t_scan = first "
                     "kernel start -> last kernel end of ONE scan; sessions_per_sec = rows really read per second",

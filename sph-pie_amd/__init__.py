@@ -8,7 +8,7 @@ BASELINE.json's north_star; nothing else of sph-pie is rebuilt here).
 """
 from .binding import (ABI_SYMBOLS, PIE_BATCH_MAX, PIE_END_NONE, PIE_GEN_CLUSTERED, PIE_GEN_INTERVAL, PIE_GEN_TIME_ORDERED, PieComm, PieError, PieScan,
                       load_library, shard_of, tz_table)
-from .build import build_all, build_hip, build_napi, build_oracle
+from .build import UBENCH_LIB, build_all, build_hip, build_napi, build_oracle, build_ubench
 
 
 def zipf_cdf(n_users, exponent=1.1):
@@ -21,4 +21,4 @@ def zipf_cdf(n_users, exponent=1.1):
     return np.maximum.accumulate(thr)
 
 __all__ = ["ABI_SYMBOLS", "PIE_BATCH_MAX", "PIE_END_NONE", "PIE_GEN_CLUSTERED", "PIE_GEN_INTERVAL", "PIE_GEN_TIME_ORDERED", "PieComm", "PieError", "PieScan",
-           "load_library", "shard_of", "tz_table", "zipf_cdf", "build_all", "build_hip", "build_napi", "build_oracle"]
+           "load_library", "shard_of", "tz_table", "zipf_cdf", "build_all", "build_hip", "build_napi", "build_oracle", "build_ubench", "UBENCH_LIB"]

@@ -10,6 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 HIP_LIB = os.path.join(PKG_DIR, "libpie_hip.so")
+UBENCH_LIB = os.path.join(PKG_DIR, "libpie_ubench.so")
 NAPI_ADDON = os.path.join(PKG_DIR, "host", "pie_napi.node")
 ORACLE_LIB = os.path.join(REPO, "oracle", "libpie_oracle.so")
 
@@ -74,6 +75,14 @@ def build_hip(force=False):
                                               "-ldl"], force)
 
 
+def build_ubench(force=False):
+    """hipcc --offload-arch=gfx950 -> sph-pie_amd/libpie_ubench.so: the streaming-read ceiling bench.py measures beside the scan
+    (a measurement aid with its own shared object: the scan library's source digest does not move with it)."""
+    src = os.path.join(CSRC, "pie_ubench.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return _build(UBENCH_LIB, [src], lambda out: [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, src], force)
+
+
 def build_oracle(force=False):
     """gcc -> oracle/libpie_oracle.so (test infrastructure only)."""
     odir = os.path.join(REPO, "oracle")
@@ -99,6 +108,6 @@ def build_napi(force=False):
 
 
 def build_all(force=False):
-    out = {"hip": build_hip(force), "oracle": build_oracle(force)}
+    out = {"hip": build_hip(force), "ubench": build_ubench(force), "oracle": build_oracle(force)}
     out["napi"] = build_napi(force)
     return out

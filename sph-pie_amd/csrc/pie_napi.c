@@ -49,6 +49,8 @@
     X(int, pie_archive_queue, (pie_ctx *, int64_t, int64_t, int32_t *, size_t, size_t *))                           \
     X(int, pie_set_profiling, (pie_ctx *, int))                                                                     \
     X(int, pie_set_ordered_run, (pie_ctx *, int))                                                                   \
+    X(int, pie_set_batch_lanes, (pie_ctx *, int))                                                                   \
+    X(int, pie_batch_lanes, (pie_ctx *))                                                                            \
     X(int, pie_stats_get, (pie_ctx *, pie_stats *))                                                                 \
     X(int, pie_stats_reset, (pie_ctx *))                                                                            \
     X(int, pie_scan_batch, (pie_ctx *, const pie_query *, int, size_t *))                                           \
@@ -1383,8 +1385,8 @@ static napi_value fn_comm_step_reserve(napi_env env, napi_callback_info info)
     return js_int(env, 0);
 }
 
-static int step_nq_ring[8];
-static unsigned step_nq_head = 0, step_nq_tail = 0; /* queries of the steps begun and not finished (at most two) */
+static int step_nq_ring[16];
+static unsigned step_nq_head = 0, step_nq_tail = 0; /* queries of the steps begun and not finished (three per batch lane of the shards: at most twelve) */
 
 static napi_value fn_comm_step_begin(napi_env env, napi_callback_info info)
 {
@@ -1399,7 +1401,7 @@ static napi_value fn_comm_step_begin(napi_env env, napi_callback_info info)
     }
     int rc = p_pie_comm_step_begin(cbx->comm, q, n_q);
     if (rc) return throw_comm(env, cbx->comm, rc);
-    step_nq_ring[step_nq_head++ & 7] = n_q;
+    step_nq_ring[step_nq_head++ & 15] = n_q;
     return js_int(env, 0);
 }
 
@@ -1409,7 +1411,7 @@ static napi_value fn_comm_step_finish(napi_env env, napi_callback_info info)
     comm_box *cbx = get_comm_box(env, argv[0]);
     if (!cbx) return NULL;
     if (step_nq_tail == step_nq_head) return throw_state(env, "pie_comm error -6: commStepFinish without commStepBegin");
-    const int n_q = step_nq_ring[step_nq_tail++ & 7];
+    const int n_q = step_nq_ring[step_nq_tail++ & 15];
     const int world = p_pie_comm_world(cbx->comm);
     size_t *m = (size_t *)calloc((size_t)world * (size_t)n_q, sizeof *m);
     if (!m) {
@@ -1535,6 +1537,20 @@ static napi_value fn_set_ordered_run(napi_env env, napi_callback_info info)
     return js_int(env, 0);
 }
 
+/* setBatchLanes(ctx, n): lanes of the batched scan — independent streams whose batches run side by side — 1..4, 0 = by table
+ * size (pie_set_batch_lanes) -> lanes in use now */
+static napi_value fn_set_batch_lanes(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    pie_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t n = 0;
+    CHECK(env, napi_get_value_int32(env, argv[1], &n));
+    const int rc = p_pie_set_batch_lanes(ctx, n);
+    if (rc != 0) return throw_pie(env, ctx, rc);
+    return js_int(env, p_pie_batch_lanes(ctx));
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     static const struct {
@@ -1546,7 +1562,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"readColumns", fn_read_columns}, {"saveColumns", fn_save_columns}, {"loadColumnsDir", fn_load_columns_dir}, {"setEnd", fn_set_end}, {"deleteUser", fn_delete_user}, {"retentionPurgeTz", fn_retention_purge_tz},
         {"setDisciplines", fn_set_disc}, {"scan", fn_scan}, {"scanDevice", fn_scan_device}, {"userFeed", fn_user_feed}, {"scanAsync", fn_scan_async}, {"fetchRows", fn_fetch_rows},
         {"expiredQueue", fn_expired_queue}, {"archiveQueue", fn_archive_queue}, {"serializeEvents", fn_serialize_events}, {"serializeICal", fn_serialize_ical}, {"stats", fn_stats}, {"setProfiling", fn_set_profiling},
-        {"setOrderedRun", fn_set_ordered_run},
+        {"setOrderedRun", fn_set_ordered_run}, {"setBatchLanes", fn_set_batch_lanes},
         {"serializeCsv", fn_serialize_csv}, {"scanBatch", fn_scan_batch}, {"batchUserFeed", fn_batch_user_feed}, {"batchFetchRequests", fn_batch_fetch_requests},
         {"commCreate", fn_comm_create}, {"commDestroy", fn_comm_destroy}, {"commWorld", fn_comm_world}, {"commCtx", fn_comm_ctx},
         {"commGenSyntheticSharded", fn_comm_gen}, {"commScanBatchGather", fn_comm_scan_gather}, {"commReadGathered", fn_comm_read}, {"commUPad", fn_comm_upad},

@@ -34,6 +34,8 @@ function createStore(options){
   const ctx = native.ctxCreate(opts.device === undefined ? 0 : opts.device);   // throws without a GPU
   // the ordered run (pie_set_ordered_run): 0 never, 1 where the general path is weak (the library's default), 2 always
   if(opts.orderedRun !== undefined){ native.setOrderedRun(ctx, opts.orderedRun); }
+  // lanes of the batched scan (pie_set_batch_lanes): 1..4 independent streams, 0 / absent = chosen by table size
+  if(opts.batchLanes !== undefined){ native.setBatchLanes(ctx, opts.batchLanes); }
 
   const rowOfToken = new Map();                    // tokenHash -> row
   const rows = [];                                 // row -> {tokenHash|null, userId, createdAt, expiresAt}

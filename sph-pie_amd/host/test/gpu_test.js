@@ -576,6 +576,36 @@ function get(port, cookie){
     a.st.close();
     b.st.close();
   }
+  // ---- 9. batch lanes behind the store (createStore({batchLanes})): batches of consecutive turns run on different streams of
+  //         the context; every request's feed equals the one-lane store's
+  {
+    const base = 1790100000000;
+    const mk = batchLanes => {
+      const st = createStore({batchLanes});
+      for(let i = 0; i < 3000; i++){
+        fakeNow = base + i * 997;
+        st.createSession('user-' + (i % 53), dc.DISCIPLINES[i % dc.DISCIPLINES.length].id);
+      }
+      return st;
+    };
+    const a = mk(4), b = mk(1);
+    eq(a.native.setBatchLanes(a.ctx, 4), 4, 'four lanes');
+    const t1 = base + 3000 * 997 + 5;
+    fakeNow = t1;
+    for(let turn = 0; turn < 6; turn++){                 // six batches: lanes 0, 1, 2, 3, 0, 1
+      const qs = [];
+      for(let q = 0; q < 5 + turn; q++){ qs.push({now: t1 - 40000000 + 1000 * q + turn, cutoff: base + 200000 * (q % 3), disciplines: q % 2 ? undefined : [dc.DISCIPLINES[q % dc.DISCIPLINES.length].id]}); }
+      const ma = a.scanBatchDevice(qs), mb = b.scanBatchDevice(qs);
+      eq(Array.from(ma, Number), Array.from(mb, Number), 'turn ' + turn + ' selected rows per query');
+      for(const u of [0, 7, 52]){
+        for(const qi of [0, qs.length - 1]){
+          eq(Array.from(a.batchUserFeed(qi, u)), Array.from(b.batchUserFeed(qi, u)), 'turn ' + turn + ' feed of user ' + u + ' query ' + qi);
+        }
+      }
+    }
+    a.close();
+    b.close();
+  }
   Date.now = realNow;
   console.log('host gpu_test ok: ' + checks + ' checks');
 })().catch(err => { console.error(err); process.exit(1); });
