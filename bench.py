@@ -663,6 +663,12 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic, "traffic_source": traffic_src, "lib_srchash": lib_srchash(),
+                # with batch lanes the launches of consecutive steps overlap: HBM bytes per second while the pipeline runs =
+                # bytes per launch over the STEP time (one launch per step), beside bytes over the launch's own duration above
+                "achieved_pipelined": (basis / (ms_per_step * 1e-3) / 1e9) if (basis and k1_ms_lanes is not None) else None,
+                "frac_pipelined": (basis / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if (basis and k1_ms_lanes is not None) else None,
+                "pipelined_note": None if k1_ms_lanes is None else "achieved / frac: bytes per launch over the launch's own time (alone on the chip); "
+                                  "*_pipelined: the same bytes over ms_per_step — what the HBM delivers while %d lanes' launches overlap" % lanes,
                 "traffic_model": model,
                 "traffic_model_note": "bytes from this run's own counters: key stream N x key bytes + 128 B per candidate payload record + 128 B "
                                       "per ambiguous `end` + 64 B per selected row stored + K2 outputs; `achieved` uses the PMC traffic when the "
