@@ -180,6 +180,29 @@ def _batch_worker(rank, world, port, tmp, n, U):
             check(gl.run_steps(k, sparse), sparse)
             assert gl.run_steps(g + 1, dense) is None   # a group that outgrows the capacity: raised for all of it, call again
             check(gl.run_steps(g + 1, dense), dense)
+        # a backend with batch lanes (the HIP library on a shard-sized table): twelve batches in flight, bounded by two message
+        # groups — the driver asks batch_room before every begin and never exceeds what the backend takes
+        class DeepBackend(OracleBatchBackend):
+            max_seen = 0
+
+            def batch_depth(self):
+                return 12
+
+            def batch_room(self):
+                return 12 - len(self.pending)
+
+            def batch_begin(self, queries, dst=None, stride=0, u_pad=0, cap=0):
+                assert len(self.pending) < 12
+                OracleBatchBackend.batch_begin(self, queries, dst, stride, u_pad, cap)
+                DeepBackend.max_seen = max(DeepBackend.max_seen, len(self.pending))
+
+        for g, k in ((8, 30), (3, 11), (1, 5)):
+            DeepBackend.max_seen = 0
+            df = BatchedFeeds(DeepBackend(oracle_py, sh, D), rank, world, sh["n_users"], q_max=6, union=True, steps_per_gather=g)
+            check_union(df.run_steps(k, sparse), sparse)
+            assert DeepBackend.max_seen == min(12, 2 * g, k) if g > 1 else DeepBackend.max_seen == 2, (g, k, DeepBackend.max_seen)
+            dl = BatchedFeeds(DeepBackend(oracle_py, sh, D), rank, world, sh["n_users"], q_max=6, steps_per_gather=g)
+            check(dl.run_steps(k, sparse), sparse)
         check_union(ufeeds.run_steps(3, sparse[:2]), sparse[:2])
         try:   # dense queries: hundreds of rows per user — the union form declines, the caller uses the lists
             ufeeds.run_steps(1, dense)
