@@ -226,6 +226,11 @@ int pie_batch_lanes(pie_ctx *ctx); /* lanes in use now */
 /* Batches pie_scan_batch_begin would take right now (0: finish one first): three per lane less those in flight; a table whose
  * batches run on the ordered run uses lane 0 only, whatever the lane count.  A pipelined caller asks this instead of counting. */
 int pie_batch_room(pie_ctx *ctx);
+/* The end of a burst: no further begin is coming for now.  The tail of a batch normally rides in its lane's next launch and,
+ * for a lane's last batch, is queued when that batch is finished — one after the other as the caller works through them.
+ * pie_scan_batch_flush queues the waiting tails of all lanes at once (they run side by side); optional, results unchanged; a
+ * begin after it simply carries no tail. */
+int pie_scan_batch_flush(pie_ctx *ctx);
 /* A batch that also writes the multi-GPU exchange message as it goes — ONE union message for the whole batch:
  *   msg (int32 words) = [ uoff[0..u_pad] | Mu | rows[0..cap) | mask_lo[0..cap) | mask_hi[0..cap) (only when n_q > 32) ]
  * u_pad + 2 + 2 * cap words (3 * cap for n_q > 32); uoff[u] = Mu for u >= users; rows beyond cap are dropped (Mu says how many

@@ -87,6 +87,7 @@ _SIGS = [
     ("pie_set_batch_lanes", C.c_int, [_P, C.c_int]),
     ("pie_batch_lanes", C.c_int, [_P]),
     ("pie_batch_room", C.c_int, [_P]),
+    ("pie_scan_batch_flush", C.c_int, [_P]),
     ("pie_batch_pack_union_device", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("pie_table_info_get", C.c_int, [_P, C.POINTER(PieTableInfo)]),
     ("pie_scan_batch_begin", C.c_int, [_P, C.POINTER(PieQuery), C.c_int]),
@@ -549,9 +550,15 @@ class PieScan:
             while begun < k and begun - done < depth and room(self._ctx) > 0:
                 self.scan_batch_begin(queries)
                 begun += 1
+                if begun == k:   # the burst ends here: the lanes' last tails go out together, not one by one as they are finished
+                    self._check(self._lib.pie_scan_batch_flush(self._ctx))
             ms = self.scan_batch_finish()
             done += 1
         return ms
+
+    def scan_batch_flush(self):
+        """No further begin is coming for now: queue the waiting tails of all lanes at once (pie_scan_batch_flush)."""
+        self._check(self._lib.pie_scan_batch_flush(self._ctx))
 
     def result_device_ptrs(self):
         a, b, c = _P(), _P(), _P()

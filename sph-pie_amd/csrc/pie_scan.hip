@@ -3402,6 +3402,22 @@ int pie_scan_batch_begin_union(pie_ctx* c, const pie_query* queries, int n_q, vo
     return batch_begin(c, queries, n_q, 2, (int*)msg_i32, 0, (int)u_pad, (long long)cap, nullptr, 0);
 }
 
+// No further begin is coming for now: the tails that were waiting for a ride in their lane's next launch are queued at once,
+// side by side, instead of one by one as their batches are finished (the end of a burst: 20 batches on three lanes drained
+// through three tail launches in a row).
+int pie_scan_batch_flush(pie_ctx* c)
+{
+    if (!c) return PIE_E_INVAL;
+    PIE_HIP(c, hipSetDevice(c->device));
+    for (int lane = 0; lane < kLaneMax; ++lane) {
+        if (c->lane_flight[lane] == 0) continue;
+        BatchSlot& b = c->bslot[lane * kBatchSlots + (c->lane_next[lane] + kBatchSlots - 1) % kBatchSlots]; // the lane's youngest batch
+        if (b.in_flight && b.k2_pending && !b.ordered && !b.unsupported) launch_batch_k2(c, b, b.stream ? b.stream : c->stream);
+    }
+    PIE_HIP(c, hipGetLastError());
+    return PIE_OK;
+}
+
 int pie_scan_batch_finish_packed(pie_ctx* c, size_t* m_out, int* ready_out)
 {
     if (!c) return PIE_E_INVAL;

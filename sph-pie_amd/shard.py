@@ -83,6 +83,9 @@ class HipShardBackend:
     def batch_room(self):
         return self.ctx.batch_room()
 
+    def batch_flush(self):
+        self.ctx.scan_batch_flush()
+
     union_direct = True   # batch_begin_union: the batch's own kernels write the union message
 
     def batch_begin_union(self, queries, dst, u_pad, cap):
@@ -658,11 +661,14 @@ class BatchedFeeds:
         D = max(2, min(int(getattr(self.backend, "batch_depth", lambda: 2)()), 2 * G))
         begun = 0
         room = getattr(self.backend, "batch_room", lambda: 1)   # (a table whose batches run on the ordered run takes three, whatever the lanes)
+        flush = getattr(self.backend, "batch_flush", None)
         group_ready = True
         for i in range(k):
             while begun < k and begun - i < D and (begun == i or room() > 0):
                 begin(begun)
                 begun += 1
+                if begun == k and flush is not None:   # the run's last batch: the lanes' waiting tails go out together
+                    flush()
             if pending is not None:   # the gather of the group before runs beside this group's scans
                 self._issue(st, pending[0], pending[1])
                 if flying is not None:

@@ -630,6 +630,10 @@ def test_batch_lanes(gpu_ctx, oracle, pie, lanes):
                 with pytest.raises(pie.PieError) as ei:
                     gpu_ctx.scan_batch_begin(sets[0])
                 assert ei.value.code == -6
+            if begun == len(sets) and done == begun - gpu_ctx.batch_lanes():
+                gpu_ctx.scan_batch_flush()   # the burst is over: the lanes' waiting tails are queued together (results unchanged)
+            if done == 3:
+                gpu_ctx.scan_batch_flush()   # ... and a flush in mid-stream only means the next begins carry no tail
             ms, ready = gpu_ctx.scan_batch_finish(packed=True)
             want = wants[done]
             assert ms == [int(w[2].size) for w in want], done
