@@ -3409,10 +3409,15 @@ int pie_scan_batch_flush(pie_ctx* c)
 {
     if (!c) return PIE_E_INVAL;
     PIE_HIP(c, hipSetDevice(c->device));
+    // Oldest first, every batch of the lane whose tail still waits — not only the youngest: a batch that only falls back queues no
+    // launch, so the batch before it keeps its tail until its finish, and tails must run in the order of their batches (a tail
+    // zeroes the span of the batch after the next: found by the differential fuzz, which flushed the third batch of a lane
+    // while the first one's tail was still waiting behind such a batch).
     for (int lane = 0; lane < kLaneMax; ++lane) {
-        if (c->lane_flight[lane] == 0) continue;
-        BatchSlot& b = c->bslot[lane * kBatchSlots + (c->lane_next[lane] + kBatchSlots - 1) % kBatchSlots]; // the lane's youngest batch
-        if (b.in_flight && b.k2_pending && !b.ordered && !b.unsupported) launch_batch_k2(c, b, b.stream ? b.stream : c->stream);
+        for (int age = c->lane_flight[lane]; age >= 1; --age) {
+            BatchSlot& b = c->bslot[lane * kBatchSlots + (c->lane_next[lane] + kBatchSlots - age) % kBatchSlots];
+            if (b.in_flight && b.k2_pending && !b.ordered && !b.unsupported) launch_batch_k2(c, b, b.stream ? b.stream : c->stream);
+        }
     }
     PIE_HIP(c, hipGetLastError());
     return PIE_OK;

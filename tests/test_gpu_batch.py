@@ -666,3 +666,33 @@ def test_batch_lanes(gpu_ctx, oracle, pie, lanes):
         gpu_ctx.synchronize()
         gpu_ctx.host_free(host_addr)
         gpu_ctx.set_batch_lanes(0)
+
+
+def test_flush_keeps_tails_in_batch_order(gpu_ctx, oracle):
+    """pie_scan_batch_flush behind a batch that only falls back.  Such a batch (every query dense) queues no launch, so the batch
+    before it keeps its tail until its finish; a flush must queue that tail BEFORE the younger batch's (a tail zeroes the span
+    of the batch after the next — here the first batch's own histogram).  Found by the differential fuzz; one lane and four."""
+    n, U, D = 300007, 2003, 32
+    cols = oracle.gen(SEED, n, 0, n, U, D, 0)
+    gpu_ctx.load_columns(*cols, U)
+    gpu_ctx.set_disciplines(ALL, D)
+    t0 = oracle.T0_MS
+    a, c = mixed_queries(oracle, 40), mixed_queries(oracle, 7)
+    dense = [(t0 - 100 * DAY, INT64_MIN, ALL), (t0 - 90 * DAY, t0 - 110 * DAY, 0xFFFF)]
+    want = {id(q): oracle_answers(oracle, cols, U, D, q) for q in (a, dense, c)}
+    try:
+        for lanes in (1, 4):
+            gpu_ctx.set_batch_lanes(lanes)
+            for order in ((a, dense, c), (a, dense, dense), (dense, a, c)):
+                if gpu_ctx.batch_room() < 3:
+                    continue
+                for q in order:
+                    gpu_ctx.scan_batch_begin(q)
+                gpu_ctx.scan_batch_flush()
+                for q in order:
+                    ms = gpu_ctx.scan_batch_finish()
+                    assert ms == [int(w[2].size) for w in want[id(q)]], (lanes, len(q))
+                    for qi in (0, len(q) - 1):
+                        assert_same(gpu_ctx.batch_read_results(qi), want[id(q)][qi], "lanes %d query %d" % (lanes, qi))
+    finally:
+        gpu_ctx.set_batch_lanes(0)

@@ -157,15 +157,37 @@ while time.time() < t_end:
                             ctx.scan_batch_begin(batches[k])
 
                     ctx.set_batch_lanes(int(rng.integers(0, 5)))   # 0: by table size; batches of different lanes run side by side
+                    if os.environ.get("PIE_FUZZ_LANES"):   # (debugging a case: same random stream, lanes pinned)
+                        ctx.set_batch_lanes(int(os.environ["PIE_FUZZ_LANES"]))
                     depth = int(rng.integers(1, 3 * ctx.batch_lanes() + 1))   # up to three batches in flight per lane
                     begun_b = 0
                     for k in range(len(batches)):
                         while begun_b < len(batches) and begun_b - k < depth and ctx.batch_room() > 0:
                             begin(begun_b)
                             begun_b += 1
+                            fl_mid, fl_end = rng.random() < 0.15, begun_b == len(batches)
+                            if os.environ.get("PIE_FUZZ_DEBUG"):
+                                print("begun", begun_b - 1, "flush mid", fl_mid, "end", fl_end, flush=True)
+                            if os.environ.get("PIE_FUZZ_FLUSH") == "end":
+                                fl_mid = False
+                            if os.environ.get("PIE_FUZZ_FLUSH") == "mid":
+                                fl_end = False
+                            if (fl_mid or fl_end) and not os.environ.get("PIE_FUZZ_NO_FLUSH"):   # a burst ends (or seems to): waiting tails go out together
+                                ctx.scan_batch_flush()
                         ms, ready = ctx.scan_batch_finish(packed=True)
                         wants_k = [oracle.scan(s, e, u, d, U, nw, ct, mk & lim) for nw, ct, mk in batches[k]]
                         nqk = len(batches[k])
+                        if os.environ.get("PIE_FUZZ_DEBUG"):
+                            print("batch", k, "of", len(batches), "nq", nqk, "depth", depth, "lanes", ctx.batch_lanes(), "direct", direct[k], "ready", ready,
+                                  "got", list(ms), "want", [int(w[2].size) for w in wants_k], "stats", ctx.stats(), flush=True)
+                        if os.environ.get("PIE_FUZZ_DEBUG"):
+                            und = ctx.batch_read_union()
+                            bad = [qi for qi, w in enumerate(wants_k) if ms[qi] != w[2].size]
+                            print("  union", None if und is None else und[1].size, "bad queries", bad, flush=True)
+                            for qi in bad:
+                                got_q = ctx.batch_read_results(qi)
+                                print("  query", qi, batches[k][qi], "lists: M", got_q[2].size, "want", wants_k[qi][2].size,
+                                      "union count", None if und is None else int((((und[2] >> np.uint64(qi)) & np.uint64(1)) == 1).sum()), flush=True)
                         for qi, w in enumerate(wants_k):
                             if ms[qi] != w[2].size:
                                 raise AssertionError(what + " batch %d query %d: M differs" % (k, qi))
